@@ -1,0 +1,281 @@
+"""ORACLE (test infrastructure only) - CPU fp32 restatement of the E_align hot path.
+
+This file is NOT part of the product.  Only tests/, __graft_entry__.smoke() and the
+`cpu_baseline` leg of bench.py may import it, and only as the checker.  It restates,
+from the math, what the reference computes, as plain functional
+torch-fp32-on-CPU code over flat parameter dicts keyed like the reference's
+state_dict.  It is pinned against tests/golden/*.npz, which were produced by running
+the reference itself (tools/gen_golden.py).  Unpinned part: LPIPS (third-party `lpips`
+package + VGG16 weights are absent from /root/reference and from this image) - the
+structure is restated in oracle/lpips_ref.py and used with seeded stand-in weights.
+
+Reference lines followed by each function are cited in its docstring
+(paths relative to /root/reference).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SQRT2 = math.sqrt(2.0)
+
+
+# ----------------------------------------------------------------------------- StyleGAN2
+def s2_dense(x, weight, bias, lr_mul=1.0, additional_bias=0.0, act="lrelu"):
+    """DenseBlock.forward, model/stylegan2_generator.py:990-996 (wscale :964-967)."""
+    wscale = lr_mul / math.sqrt(weight.shape[1])
+    y = x.reshape(x.shape[0], -1) @ (weight * wscale).t() + bias * lr_mul + additional_bias
+    if act == "lrelu":
+        y = F.leaky_relu(y, 0.2) * SQRT2
+    return y
+
+
+def s2_mapping(P, z, prefix="mapping."):
+    """MappingModule.forward :246-278 with PixelNormLayer :550-553 (eps 1e-8)."""
+    w = z / torch.sqrt(torch.mean(z * z, dim=1, keepdim=True) + 1e-8)
+    i = 0
+    while f"{prefix}dense{i}.weight" in P:
+        w = s2_dense(w, P[f"{prefix}dense{i}.weight"], P[f"{prefix}dense{i}.bias"], lr_mul=0.01)
+        i += 1
+    return w
+
+
+def s2_truncation(w_avg, w, num_layers, psi=None, layers=None):
+    """TruncationModule.forward :311-333."""
+    wp = w.unsqueeze(1).repeat(1, num_layers, 1) if w.ndim == 2 else w
+    psi = 1.0 if psi is None else psi
+    layers = 0 if layers is None else layers
+    if psi < 1.0 and layers > 0:
+        coef = torch.ones(1, num_layers, 1)
+        coef[:, :layers] = psi
+        wp = w_avg.view(1, 1, -1) + (wp - w_avg.view(1, 1, -1)) * coef
+    return wp
+
+
+def fir_kernel(gain=4.0):
+    k = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32)
+    return torch.from_numpy(k / k.sum() * gain)
+
+
+def s2_upsample_skip(img):
+    """UpsamplingLayer.forward :603-615 with scale_factor=2: zero-insert, pad (2,1,2,1), 4x4 FIR (sum 4)."""
+    B, C, H, W = img.shape
+    z = torch.zeros(B, C, 2 * H, 2 * W, dtype=img.dtype)
+    z[:, :, ::2, ::2] = img
+    z = F.pad(z, (2, 1, 2, 1))
+    k = fir_kernel().view(1, 1, 4, 4).repeat(C, 1, 1, 1)
+    return F.conv2d(z, k, groups=C)
+
+
+def s2_filter_after_up(x):
+    """The `filter` of an up ModulateConvBlock (:802-807): pad (1,1,1,1) + 4x4 FIR (sum 4)."""
+    C = x.shape[1]
+    k = fir_kernel().view(1, 1, 4, 4).repeat(C, 1, 1, 1)
+    return F.conv2d(F.pad(x, (1, 1, 1, 1)), k, groups=C)
+
+
+def s2_style(P, name, w):
+    """style = Dense(w) + 1, linear (:825-829)."""
+    return s2_dense(w, P[name + ".style.weight"], P[name + ".style.bias"], additional_bias=1.0, act="linear")
+
+
+def s2_modconv(P, name, x, w, up=False, demodulate=True, add_noise=True, act="lrelu", noise=None):
+    """ModulateConvBlock.forward :855-922, restated in the *shared-weight* form
+    (scale activations by s, divide by the norm afterwards - the algebra of :876-877,
+    :908-909), which is what the HIP kernels implement."""
+    weight = P[name + ".weight"]
+    cout, cin, k, _ = weight.shape
+    s = s2_style(P, name, w)                                     # [B, cin]
+    wh = weight * (1.0 / math.sqrt(cin * k * k))
+    xm = x * s.view(-1, cin, 1, 1)
+    if up:
+        # conv_transpose2d stride 2 with the flipped kernel (:879-895), then FIR (:896)
+        y = F.conv_transpose2d(xm, wh.flip(2, 3).permute(1, 0, 2, 3), stride=2)
+        y = s2_filter_after_up(y)
+    else:
+        y = F.conv2d(xm, wh, padding=k // 2)
+    if demodulate:
+        wsq = (wh * wh).sum(dim=(2, 3))                          # [cout, cin]
+        d = torch.rsqrt((s * s) @ wsq.t() + 1e-8)                # [B, cout]
+        y = y * d.view(-1, cout, 1, 1)
+    if add_noise:
+        nz = P[name + ".noise"] if noise is None else noise
+        y = y + nz * P[name + ".noise_strength"].view(1, 1, 1, 1)
+    y = y + P[name + ".bias"].view(1, -1, 1, 1)
+    if act == "lrelu":
+        y = F.leaky_relu(y, 0.2) * SQRT2
+    return y, s
+
+
+def s2_num_layers(P, prefix="synthesis."):
+    n = 0
+    while f"{prefix}layer{n}.weight" in P:
+        n += 1
+    return n + 1
+
+
+def s2_synthesis(P, wp, prefix="synthesis.", collect=None):
+    """SynthesisModule.forward :492-539 (architecture 'skip'); latent indexing :511-517."""
+    B = wp.shape[0]
+    x = P[prefix + "early_layer.const"].repeat(B, 1, 1, 1)
+    nl = s2_num_layers(P, prefix)
+    image = None
+    for i in range(nl - 1):
+        x, _ = s2_modconv(P, f"{prefix}layer{i}", x, wp[:, i], up=(i % 2 == 1))
+        if collect is not None:
+            collect[f"layer{i}"] = x
+        if i % 2 == 0:
+            rgb, _ = s2_modconv(P, f"{prefix}output{i // 2}", x, wp[:, i + 1], demodulate=False,
+                                add_noise=False, act="linear")
+            image = rgb if image is None else rgb + s2_upsample_skip(image)
+    return image
+
+
+def s2_generator_eval(P, z, psi=0.7, layers=8):
+    w = s2_mapping(P, z)
+    nl = s2_num_layers(P)
+    wp = s2_truncation(P["truncation.w_avg"], w, nl, psi, layers)
+    return w, wp, s2_synthesis(P, wp)
+
+
+def s2_generator_train(P, z, new_z, u, cutoff, psi=0.7, layers=8, decay=0.995, mix_prob=0.9):
+    """StyleGAN2Generator.forward in train mode :174-196 (quirk Q1): returns
+    (wp, new w_avg).  `new_z`, `u`, `cutoff` are the RNG draws (:185,187,188)."""
+    nl = s2_num_layers(P)
+    w = s2_mapping(P, z)
+    w_avg = P["truncation.w_avg"] * decay + w.mean(0) * (1 - decay)
+    if mix_prob > 0:
+        new_w = s2_mapping(P, new_z)
+        if u < mix_prob:
+            w = s2_truncation(w_avg, w, nl).clone()
+            new_w = s2_truncation(w_avg, new_w, nl)
+            w[:, :cutoff] = new_w[:, :cutoff]
+    return s2_truncation(w_avg, w, nl, psi, layers), w_avg
+
+
+# ----------------------------------------------------------------------------- encoder E.BE
+def enc_stats(x):
+    """mean / biased std without eps, model/E/E.py:51-52."""
+    m = x.mean(dim=(2, 3))
+    v = ((x - m[:, :, None, None]) ** 2).mean(dim=(2, 3))
+    return m, v
+
+
+def inorm(x, m, v, eps=1e-8):
+    return (x - m[:, :, None, None]) * torch.rsqrt(v + eps)[:, :, None, None]
+
+
+def enc_block(P, pre, x, n1, n2, last):
+    """BEBlock.forward model/E/E.py:50-85.  n1/n2: injected N(0,1) noise [B,1,H,W]."""
+    m1, v1 = enc_stats(x)
+    w1 = torch.cat([m1, v1.sqrt()], 1) @ P[pre + "inver_mod1.weight"].t() + P[pre + "inver_mod1.bias"]
+    res = x
+    y = F.conv2d(inorm(x, m1, v1), P[pre + "conv_1.weight"], padding=1)
+    y = F.leaky_relu(y + P[pre + "noise_weight_1"] * n1 + P[pre + "bias_1"], 0.2)
+    m2, v2 = enc_stats(y)
+    w2 = torch.cat([m2, v2.sqrt()], 1) @ P[pre + "inver_mod2.weight"].t() + P[pre + "inver_mod2.bias"]
+    y = inorm(y, m2, v2)
+    if not last:
+        y = F.conv2d(y, P[pre + "conv_2.weight"], padding=1)
+        y = F.leaky_relu(y + P[pre + "noise_weight_2"] * n2 + P[pre + "bias_2"], 0.2)
+        y = F.avg_pool2d(y, 2, 2)
+        res = F.avg_pool2d(res, 2, 2)
+    if pre + "conv_3.weight" in P:
+        res = F.conv2d(res, P[pre + "conv_3.weight"], P[pre + "conv_3.bias"])
+    return 0.111 * y + 0.889 * res, w1, w2
+
+
+def enc_forward(P, img, noises, collect=None):
+    """BE.forward model/E/E.py:122-136 + FromRGB model/utils/net.py:231-240.
+    `noises`: list in the reference's draw order (2 per block, 1 for the last)."""
+    x = F.leaky_relu(F.conv2d(img, P["FromRGB.from_rgb.weight"], P["FromRGB.from_rgb.bias"]), 0.2)
+    L = 0
+    while f"decode_block.{L}.conv_1.weight" in P:
+        L += 1
+    ws, ni = [], 0
+    for j in range(L):
+        last = (j == L - 1)
+        n1 = noises[ni]; ni += 1
+        n2 = None
+        if not last:
+            n2 = noises[ni]; ni += 1
+        x, w1, w2 = enc_block(P, f"decode_block.{j}.", x, n1, n2, last)
+        if collect is not None:
+            collect[j] = (x, w1, w2)
+        ws = [w2, w1] + ws                      # E.py:130-134: later blocks go first
+    return x, torch.stack(ws, dim=1)
+
+
+def enc_noise_shapes(L, B, res):
+    shp = []
+    for j in range(L):
+        r = res >> j
+        shp.append((B, 1, r, r))
+        if j != L - 1:
+            shp.append((B, 1, r, r))
+    return shp
+
+
+# ----------------------------------------------------------------------------- losses
+def ssim_window(size=11, sigma=1.5):
+    g = torch.tensor([math.exp(-(x - size // 2) ** 2 / (2.0 * sigma ** 2)) for x in range(size)])
+    return g / g.sum()
+
+
+def ssim(a, b):
+    """metric/pytorch_ssim.py:18-38 (11x11 Gaussian, zero pad 5, C1=1e-4, C2=9e-4), mean over all."""
+    C = a.shape[1]
+    g = ssim_window()
+    w2 = (g[:, None] @ g[None, :]).float().view(1, 1, 11, 11).repeat(C, 1, 1, 1)
+    f = lambda t: F.conv2d(t, w2, padding=5, groups=C)
+    mu1, mu2 = f(a), f(b)
+    s11, s22, s12 = f(a * a) - mu1 * mu1, f(b * b) - mu2 * mu2, f(a * b) - mu1 * mu2
+    m = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s11 + s22 + 9e-4))
+    return m.mean()
+
+
+def space_loss(a, b, image_space=True, lpips_fn=None):
+    """training_utils.py:54-99.  Returns (loss, dict of logged terms)."""
+    a, b = a.contiguous(), b.contiguous()
+    mse = ((a - b) ** 2).mean()
+    mse_mean = (a.mean() - b.mean()) ** 2
+    mse_std = (a.std() - b.std()) ** 2
+    # softmax with implicit dim (:67): dim 1 for 4-D, dim 0 for 3-D tensors
+    dim = 1 if a.ndim == 4 else 0
+    pa, pb = F.softmax(a, dim), F.softmax(b, dim)
+    kl = (pa * (torch.log(pa) - torch.log(pb))).mean()          # KLDivLoss(reduction='mean') (:68)
+    kl = torch.where(torch.isnan(kl), torch.zeros_like(kl), kl)
+    kl = torch.where(torch.isinf(kl), torch.ones_like(kl), kl)
+    fa, fb = a.view(-1), b.view(-1)
+    cos = 1 - fa.dot(fb) / (fa.dot(fa).sqrt() * fb.dot(fb).sqrt())
+    ssim_l = torch.tensor(0.0)
+    lp = torch.tensor(0.0)
+    if image_space:
+        while a.shape[2] > 256:
+            a, b = F.avg_pool2d(a, 2, 2), F.avg_pool2d(b, 2, 2)
+        ssim_l = 1 - ssim(a, b)
+        lp = lpips_fn(a, b).mean()
+    loss = 5 * mse + 3 * cos + ssim_l + 2 * lp
+    return loss, dict(mse=mse, mse_mean=mse_mean, mse_std=mse_std, kl=kl, cos=cos, ssim=ssim_l, lpips=lp)
+
+
+def attention_crops(img):
+    """AT1 / AT2 crops of E_align_s2.py:188-199."""
+    H, W = img.shape[2], img.shape[3]
+    at1 = img[:, :, :, W // 8: W - W // 8]
+    oy, ox = H // 8 + H // 32, W // 8 + W // 32
+    at2 = img[:, :, oy: H - oy, ox: W - ox]
+    return at1, at2
+
+
+# ----------------------------------------------------------------------------- optimiser
+def lreq_adam_step(p, g, v, step, lr, beta2=0.99, eps=1e-8, coef=None):
+    """LREQAdam.step model/utils/custom_adam.py:24-76 for one tensor; returns (p, v).
+    `step` is the 1-based count for this parameter."""
+    v = v * beta2 + (1 - beta2) * g * g
+    denom = v.sqrt() + eps
+    step_size = lr * math.sqrt(1 - beta2 ** step)
+    if coef is not None and coef >= 0:
+        step_size *= coef
+    return p - step_size * g / denom, v

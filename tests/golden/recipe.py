@@ -1,0 +1,89 @@
+"""Deterministic tensor recipes shared by tools/gen_golden.py (run once in the build
+container, with /root/reference importable) and by the tests (run anywhere).
+
+Fixtures under tests/golden/ hold only *inputs that cannot be re-derived* and the
+*expected outputs of the reference*; weights and most inputs are regenerated from the
+recipes below so the committed files stay small.  Nothing here imports the reference.
+"""
+import zlib
+import numpy as np
+import torch
+
+_torch_randn = torch.randn   # bound early: gen_golden.py patches torch.randn
+
+
+def _seed_for(name: str, seed: int) -> int:
+    return (zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF
+
+
+def randn(name: str, shape, seed: int = 0, scale: float = 1.0, shift: float = 0.0) -> torch.Tensor:
+    """N(shift, scale) tensor that depends only on (name, shape, seed)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(_seed_for(name, seed))
+    return _torch_randn(tuple(shape), generator=g, dtype=torch.float32) * scale + shift
+
+
+def fill_like(shapes: dict, seed: int, rules=None) -> dict:
+    """Fill a {key: shape} description with seeded values.
+
+    `rules` is a list of (substring, scale, shift); first match wins.  Default N(0,1).
+    Non-trivial values are used for tensors the reference initialises to 0/1 (biases,
+    noise strengths, w_avg ...) so a kernel that ignores them cannot pass."""
+    rules = rules or []
+    out = {}
+    for k, shp in shapes.items():
+        scale, shift = 1.0, 0.0
+        for sub, sc, sh in rules:
+            if sub in k:
+                scale, shift = sc, sh
+                break
+        out[k] = randn(k, shp, seed, scale, shift)
+    return out
+
+
+# StyleGAN2 generator (reference: model/stylegan2_generator.py ctor defaults are
+# zeros for bias / noise_strength / w_avg).
+S2_RULES = [
+    ("filter.kernel", None, None),       # handled by caller (buffers keep reference values)
+    ("upsample.kernel", None, None),
+    ("noise_strength", 0.3, 0.1),
+    ("style.bias", 0.2, 0.0),
+    (".bias", 0.2, 0.0),
+    ("w_avg", 0.5, 0.0),
+]
+
+
+def fill_s2(shapes: dict, seed: int) -> dict:
+    out = {}
+    fir = np.outer([1, 3, 3, 1], [1, 3, 3, 1]).astype(np.float32)
+    fir = fir / fir.sum() * 4.0
+    for k, shp in shapes.items():
+        if k.endswith("filter.kernel") or k.endswith("upsample.kernel"):
+            out[k] = torch.from_numpy(fir.copy()).view(1, 1, 4, 4)
+            continue
+        scale, shift = 1.0, 0.0
+        for sub, sc, sh in S2_RULES:
+            if sc is not None and sub in k:
+                scale, shift = sc, sh
+                break
+        out[k] = randn(k, shp, seed, scale, shift)
+    return out
+
+
+# Encoder E.BE (reference: model/E/E.py; noise_weight_* / bias_* start at zero, lreq
+# weights start at N(0, gain/sqrt(fan_in))).
+def fill_encoder(shapes: dict, seed: int) -> dict:
+    out = {}
+    for k, shp in shapes.items():
+        if "noise_weight" in k:
+            out[k] = randn(k, shp, seed, 0.2, 0.05)
+        elif k.endswith("bias") or "bias_" in k:
+            out[k] = randn(k, shp, seed, 0.1, 0.0)
+        else:
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else 1
+            out[k] = randn(k, shp, seed, float(np.sqrt(2.0) / np.sqrt(max(fan_in, 1))), 0.0)
+    return out
+
+
+def checksum(sd: dict) -> float:
+    return float(sum(v.double().abs().sum().item() for v in sd.values()))

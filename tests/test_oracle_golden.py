@@ -1,0 +1,185 @@
+"""Pins the oracle (oracle/ref_torch.py) against the golden vectors produced by the
+reference itself (tools/gen_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden, ROOT
+from tests.golden import recipe as R
+from oracle import ref_torch as O
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=2e-4, atol=2e-5):
+    a = a.detach() if torch.is_tensor(a) else torch.as_tensor(a)
+    b = torch.as_tensor(np.asarray(b))
+    scale = b.abs().max().item() + 1e-30
+    err = (a.double() - b.double()).abs().max().item()
+    assert err <= atol + rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def s2_small_params():
+    from tests.helpers import s2_shapes
+    shapes = s2_shapes(64, fmaps_base=2048, fmaps_max=128)
+    return R.fill_s2(shapes, seed=11)
+
+
+def test_s2_blocks():
+    g = golden("s2_blocks.npz")
+    from tests.helpers import modconv_shapes
+    for ci in range(6):
+        cin, cout, res, up, k = [int(v) for v in g[f"c{ci}_cfg"]]
+        torgb = (k == 1)
+        shapes = modconv_shapes(cin, cout, res, k, noise=not torgb, up=bool(up))
+        P = {"L." + kk: v for kk, v in R.fill_s2(shapes, seed=100 + ci).items()}
+        rin = res // 2 if up else res
+        x = R.randn(f"mc{ci}.x", (2, cin, rin, rin), 7)
+        w = R.randn(f"mc{ci}.w", (2, 512), 7)
+        y, s = O.s2_modconv(P, "L", x, w, up=bool(up), demodulate=not torgb, add_noise=not torgb,
+                            act="linear" if torgb else "lrelu")
+        close(s, g[f"c{ci}_style"])
+        close(y, g[f"c{ci}_y"])
+        close(y, g[f"c{ci}_y_nonfused"])
+    close(O.s2_upsample_skip(R.randn("ups.up", (2, 3, 8, 8), 3)), g["ups_up_y"])
+    close(O.s2_filter_after_up(R.randn("ups.filt", (2, 3, 9, 9), 3)), g["ups_filt_y"])
+
+
+def test_s2_synthesis_and_generator():
+    g = golden("s2_small.npz")
+    P = s2_small_params()
+    assert abs(R.checksum(P) - float(g["state_checksum"])) < 1e-6 * float(g["state_checksum"])
+    wp = R.randn("s2.wp", (2, 10, 512), 5)
+    feats = {}
+    img = O.s2_synthesis(P, wp, collect=feats)
+    for name in ("layer0", "layer1", "layer2", "layer7", "layer8"):
+        close(feats[name], g["syn_" + name])
+    close(img, g["syn_image"])
+    z = R.randn("s2.z", (2, 512), 5)
+    w, wp2, img2 = O.s2_generator_eval(P, z)
+    close(w, g["eval_w"]); close(wp2, g["eval_wp"]); close(img2, g["eval_image"])
+    # layers >= trunc_layers carry coef 1: w_avg + (w - w_avg)*1 (not bit-identical to w, as in the reference)
+    close(wp2[:, 8:], w[:, None].repeat(1, 2, 1), rtol=1e-6, atol=5e-7)
+
+
+def test_s2_train_mode_quirk_q1():
+    g = golden("s2_small.npz")
+    P = s2_small_params()
+    z = R.randn("s2.z", (2, 512), 5)
+    new_z = R.randn("s2.new_z", (2, 512), 5)
+    for tag in ("a", "b"):
+        u, cutoff = g[f"train_{tag}_u_cutoff"]
+        P["truncation.w_avg"] = T(g[f"train_{tag}_w_avg_before"])
+        wp, w_avg = O.s2_generator_train(P, z, new_z, float(u), int(cutoff))
+        close(w_avg, g[f"train_{tag}_w_avg_after"])
+        close(wp, g[f"train_{tag}_wp"])
+        P2 = dict(P); P2["truncation.w_avg"] = w_avg
+        close(O.s2_synthesis(P2, wp), g[f"train_{tag}_image"])
+
+
+def test_s2_grad_wp():
+    g = golden("s2_small.npz")
+    P = s2_small_params()
+    wp = R.randn("s2.wp", (2, 10, 512), 5).requires_grad_(True)
+    img = O.s2_synthesis(P, wp)
+    gimg = R.randn("s2.gimg", tuple(img.shape), 5, 1.0 / img.numel() ** 0.5)
+    (img * gimg).sum().backward()
+    close(wp.grad, g["grad_wp"], rtol=1e-3)
+
+
+def enc_small_params():
+    from tests.helpers import enc_shapes
+    return R.fill_encoder(enc_shapes(16, 64, 4), seed=21)
+
+
+def test_encoder_forward_backward():
+    g = golden("enc_small.npz")
+    P = {k: v.requires_grad_(True) for k, v in enc_small_params().items()}
+    assert abs(R.checksum(P) - float(g["state_checksum"])) < 1e-6 * float(g["state_checksum"])
+    img = R.randn("enc.img", (2, 3, 32, 32), 9, 0.5).requires_grad_(True)
+    shp = O.enc_noise_shapes(4, 2, 32)
+    assert [list(s) for s in shp] == g["noise_shapes"].tolist()
+    noises = [R.randn(f"enc.noise{i}", s, 9) for i, s in enumerate(shp)]
+    feats = {}
+    x, w = O.enc_forward(P, img, noises, collect=feats)
+    close(x, g["x"]); close(w, g["w"])
+    # bit-exact index map: w[:, 2(L-1-j)] = w2_j, w[:, 2(L-1-j)+1] = w1_j (E.py:130-134)
+    for j in range(4):
+        assert torch.equal(w[:, 2 * (3 - j)], feats[j][2]) and torch.equal(w[:, 2 * (3 - j) + 1], feats[j][1])
+        close(feats[j][0], g[f"blk{j}_x"])
+    gw = R.randn("enc.gw", tuple(w.shape), 9, 0.05)
+    (w * gw).sum().backward()
+    close(img.grad, g["grad_img"], rtol=1e-3)
+    for k, p in P.items():
+        if "grad:" + k in g.files:
+            close(p.grad, g["grad:" + k], rtol=1e-3)
+        else:
+            assert p.grad is None or float(p.grad.abs().sum()) == 0.0, k
+
+
+def test_losses():
+    g = golden("loss.npz")
+    a = R.randn("loss.a", (2, 3, 64, 64), 1, 0.5).clamp(-1, 1)
+    b = (a + R.randn("loss.b", (2, 3, 64, 64), 1, 0.1)).clamp(-1, 1)
+    close(O.ssim(a, b), g["ssim_64"]); close(O.ssim(a, a), g["ssim_same"])
+    assert abs(float(O.ssim(a, a)) - 1.0) < 1e-6      # comparing-baseline.py:88 known answer
+    a2 = R.randn("loss.a2", (1, 3, 40, 24), 1, 0.5)
+    close(O.ssim(a2, a2 * 0.7 + 0.1), g["ssim_40x24"])
+    standin = lambda x, y: ((x - y) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    big_a = R.randn("loss.big_a", (2, 3, 512, 384), 2, 0.5)
+    big_b = (big_a + R.randn("loss.big_b", (2, 3, 512, 384), 2, 0.2)).requires_grad_(True)
+    l, info = O.space_loss(big_a, big_b, lpips_fn=standin)
+    l.backward()
+    close(l, g["img_loss"])
+    ref = g["img_info"]
+    for i, k in enumerate(("mse", "mse_mean", "mse_std", "kl", "cos", "ssim", "lpips")):
+        assert abs(float(info[k]) - ref[i]) <= 2e-4 * abs(ref[i]) + 1e-6, k
+    close(big_b.grad[:, :, 100:116, 200:216], g["img_grad_b_crop"], rtol=1e-3)
+    w1 = R.randn("loss.w1", (2, 18, 512), 2)
+    w2 = (w1 * 0.9 + R.randn("loss.w2", (2, 18, 512), 2, 0.3)).requires_grad_(True)
+    l, info = O.space_loss(w1, w2, image_space=False)
+    l.backward()
+    close(l, g["w_loss"]); close(w2.grad, g["w_grad"], rtol=1e-3)
+    ref = g["w_info"]
+    for i, k in enumerate(("mse", "mse_mean", "mse_std", "kl", "cos")):
+        assert abs(float(info[k]) - ref[i]) <= 2e-4 * abs(ref[i]) + 1e-6, k
+
+
+def test_lreq_adam():
+    g = golden("adam.npz")
+    names = ["lin.weight", "lin.bias", "conv.weight", "plain"]
+    shapes = [(7, 12), (7,), (6, 4, 3, 3), (1, 6, 1, 1)]
+    coef = g["coef"]
+    p = [R.randn("adam.p." + k, s, 0, 0.3) for k, s in zip(names, shapes)]
+    v = [torch.zeros(s) for s in shapes]
+    cnt = [0] * 4
+    for step in range(3):
+        for i, k in enumerate(names):
+            if step == 1 and k == "plain":
+                continue
+            gr = R.randn(f"adam.g{step}." + k, shapes[i], 0, 0.01 * (step + 1))
+            cnt[i] += 1
+            p[i], v[i] = O.lreq_adam_step(p[i], gr, v[i], cnt[i], 0.0015, coef=coef[i])
+        for i, k in enumerate(names):
+            close(p[i], g[f"s{step}:{k}"], rtol=1e-5, atol=1e-7)
+
+
+def test_shape_tables_match_reference_state_dicts():
+    from tests.helpers import s2_shapes, enc_shapes
+    with open(os.path.join(ROOT, "tests", "golden", "s2_keys.json")) as f:
+        s2 = json.load(f)
+    for res in (1024, 256):
+        mine = s2_shapes(res)
+        assert list(mine.keys()) == list(s2[str(res)].keys())
+        assert all(list(mine[k]) == s2[str(res)][k] for k in mine)
+    assert len(s2["1024"]) == 165
+    with open(os.path.join(ROOT, "tests", "golden", "enc_keys.json")) as f:
+        ek = json.load(f)
+    for tag, (sf, lc) in (("1024_16_9", (16, 9)), ("256_64_7", (64, 7))):
+        mine = enc_shapes(sf, 512, lc)
+        assert set(mine.keys()) == set(ek[tag].keys())
+        assert all(list(mine[k]) == ek[tag][k] for k in mine)
+    assert len(ek["1024_16_9"]) == 101 and len(ek["256_64_7"]) == 77

@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the reference's PyTorch CPU path.
+
+Runs ONLY in the build container (needs /root/reference; it is a no-op elsewhere).
+Imports the reference modules (never copies them), feeds them seeded inputs built by
+tests/golden/recipe.py and stores the reference's outputs under tests/golden/.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [section ...]
+
+Sections: s2 enc loss adam step
+"""
+import json
+import os
+import sys
+import types
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+if not os.path.isdir(REF):
+    print("reference not present; nothing to do")
+    sys.exit(0)
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+torch.set_num_threads(8)
+from tests.golden import recipe as R
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+# training_utils imports torchvision + PIL at module scope
+_tv = _stub("torchvision")
+_tv.transforms = _stub("torchvision.transforms", Compose=lambda x: None, ToTensor=lambda: None)
+try:
+    import PIL  # noqa
+except Exception:
+    _stub("PIL").Image = None
+
+
+def shapes_of(sd):
+    return {k: list(v.shape) for k, v in sd.items()}
+
+
+def save_npz(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+# --------------------------------------------------------------------------- S2
+def gen_s2():
+    from model.stylegan2_generator import (StyleGAN2Generator, ModulateConvBlock,
+                                           UpsamplingLayer)
+    # key/shape lists of the real configurations (state_dict surface)
+    keys = {}
+    for res in (1024, 256):
+        g = StyleGAN2Generator(res)
+        keys[str(res)] = shapes_of(g.state_dict())
+        del g
+    with open(os.path.join(OUT, "s2_keys.json"), "w") as f:
+        json.dump(keys, f)
+
+    # -- single ModulateConvBlock cases (a1) and UpsamplingLayer (a2)
+    cases = [  # in, out, res(out), up, k, demod, noise, act
+        (128, 128, 8, False, 3),
+        (128, 64, 16, True, 3),
+        (64, 32, 32, True, 3),
+        (32, 32, 32, False, 3),
+        (32, 3, 32, False, 1),
+        (512, 512, 4, False, 3),
+    ]
+    out = {}
+    for ci, (cin, cout, res, up, k) in enumerate(cases):
+        torgb = (k == 1)
+        blk = ModulateConvBlock(cin, cout, res, 512, kernel_size=k, scale_factor=2 if up else 1,
+                                demodulate=not torgb, add_noise=not torgb,
+                                activation_type="linear" if torgb else "lrelu")
+        sd = R.fill_s2(shapes_of(blk.state_dict()), seed=100 + ci)
+        blk.load_state_dict(sd)
+        rin = res // 2 if up else res
+        x = R.randn(f"mc{ci}.x", (2, cin, rin, rin), 7)
+        w = R.randn(f"mc{ci}.w", (2, 512), 7)
+        with torch.no_grad():
+            y, style = blk(x, w)
+            # metamorphic: non-fused form (stylegan2_generator.py:876-877,908-909)
+            blk.fused_modulate = False
+            y2, _ = blk(x, w)
+        out[f"c{ci}_y"] = y
+        out[f"c{ci}_style"] = style
+        out[f"c{ci}_y_nonfused"] = y2
+        out[f"c{ci}_cfg"] = np.array([cin, cout, res, int(up), k])
+    for mode, kw in (("up", dict()), ("filt", dict(scale_factor=1, extra_padding=-1, kernel_gain=2))):
+        up = UpsamplingLayer(**kw)
+        x = R.randn(f"ups.{mode}", (2, 3, 9 if mode == "filt" else 8, 9 if mode == "filt" else 8), 3)
+        out[f"ups_{mode}_y"] = up(x)
+    save_npz("s2_blocks.npz", **out)
+
+    # -- whole generator, reduced width (128/128/128/64/32 channels @ 4..64)
+    torch.manual_seed(0)
+    G = StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128)
+    sd = R.fill_s2(shapes_of(G.state_dict()), seed=11)
+    G.load_state_dict(sd)
+    out = {}
+    # (i) synthesis(wp) with hooks on intermediates
+    wp = R.randn("s2.wp", (2, G.num_layers, 512), 5)
+    feats = {}
+    hooks = []
+    for name in ("layer0", "layer1", "layer2", "layer7", "layer8", "output0", "output4"):
+        hooks.append(getattr(G.synthesis, name).register_forward_hook(
+            lambda m, i, o, name=name: feats.__setitem__(name, o[0].detach().clone())))
+    G.eval()
+    with torch.no_grad():
+        r = G.synthesis(wp)
+    for h in hooks:
+        h.remove()
+    out["syn_image"] = r["image"]
+    out["syn_style00"] = r["style00"]
+    out["syn_output_style4"] = r["output_style4"]
+    for k, v in feats.items():
+        out["syn_" + k] = v
+    # (ii) eval-mode full forward: mapping + truncation + synthesis
+    z = R.randn("s2.z", (2, 512), 5)
+    with torch.no_grad():
+        r = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+    out["eval_w"] = r["w"]
+    out["eval_wp"] = r["wp"]
+    out["eval_image"] = r["image"]
+    # (iii) train-mode forward as E_align_s2.py runs it (Q1): w_avg EMA + style mixing.
+    G.train()
+    new_z = R.randn("s2.new_z", (2, 512), 5)
+    orig_randn_like = torch.randn_like
+    torch.randn_like = lambda t, **kw: new_z.clone()
+    try:
+        for it, tag in ((3, "a"), (4, "b")):   # two iterations: seeds chosen to hit mix / no-mix
+            np.random.seed(it)
+            u = np.random.uniform()
+            cutoff = np.random.randint(1, G.num_layers) if u < 0.9 else -1
+            np.random.seed(it)
+            w_avg_before = G.truncation.w_avg.clone()
+            with torch.no_grad():
+                r = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+            out[f"train_{tag}_u_cutoff"] = np.array([u, cutoff], dtype=np.float64)
+            out[f"train_{tag}_w_avg_before"] = w_avg_before
+            out[f"train_{tag}_w_avg_after"] = G.truncation.w_avg.clone()
+            out[f"train_{tag}_wp"] = r["wp"]
+            out[f"train_{tag}_image"] = r["image"]
+    finally:
+        torch.randn_like = orig_randn_like
+    # force a no-mix case explicitly (style_mixing_prob = 0)
+    G.truncation.w_avg.copy_(sd["truncation.w_avg"])
+    with torch.no_grad():
+        r = G(z, style_mixing_prob=0.0, trunc_psi=0.7, trunc_layers=8)
+    out["train_nomix_wp"] = r["wp"]
+    out["train_nomix_w_avg_after"] = G.truncation.w_avg.clone()
+    out["state_checksum"] = np.array(R.checksum(sd))
+    # (iv) gradient of an image functional w.r.t. wp (what the encoder receives, phase E)
+    G.truncation.w_avg.copy_(sd["truncation.w_avg"])
+    wp_g = wp.clone().requires_grad_(True)
+    img = G.synthesis(wp_g)["image"]
+    gimg = R.randn("s2.gimg", tuple(img.shape), 5, 1.0 / img.numel() ** 0.5)
+    (img * gimg).sum().backward()
+    out["grad_wp"] = wp_g.grad
+    save_npz("s2_small.npz", **out)
+
+
+# --------------------------------------------------------------------------- encoder
+class _NoiseFeeder:
+    """Replaces torch.randn inside the reference encoder so that noise tensors are the
+    recipe's (reference draws them with the CPU generator, model/E/E.py:60,73 - Q6)."""
+
+    def __init__(self, prefix, seed):
+        self.prefix, self.seed, self.i, self.log = prefix, seed, 0, []
+        self.orig = torch.randn
+
+    def __call__(self, *size, **kw):
+        if len(size) == 1 and isinstance(size[0], (list, tuple)):
+            size = tuple(size[0])
+        t = R.randn(f"{self.prefix}.noise{self.i}", size, self.seed)
+        self.i += 1
+        self.log.append(tuple(size))
+        return t
+
+    def __enter__(self):
+        torch.randn = self
+        return self
+
+    def __exit__(self, *a):
+        torch.randn = self.orig
+
+
+def gen_enc():
+    import model.E.E as EE
+    keys = {}
+    for tag, (sf, lc) in (("1024_16_9", (16, 9)), ("256_64_7", (64, 7))):
+        e = EE.BE(startf=sf, maxf=512, layer_count=lc)
+        keys[tag] = shapes_of(e.state_dict())
+        keys[tag + "_lreq"] = {k: float(getattr(p, "lr_equalization_coef", -1.0))
+                               for k, p in e.named_parameters()}
+        del e
+    with open(os.path.join(OUT, "enc_keys.json"), "w") as f:
+        json.dump(keys, f)
+
+    # small encoder: startf=16, maxf=64, 4 blocks, 32x32 input: ch 16->32->64->64(->64)
+    E = EE.BE(startf=16, maxf=64, layer_count=4)
+    sd = R.fill_encoder(shapes_of(E.state_dict()), seed=21)
+    E.load_state_dict(sd)
+    img = R.randn("enc.img", (2, 3, 32, 32), 9, 0.5)
+    img.requires_grad_(True)
+    feats = {}
+    hooks = [E.decode_block[j].register_forward_hook(
+        lambda m, i, o, j=j: feats.__setitem__(j, [t.detach().clone() for t in o])) for j in range(4)]
+    with _NoiseFeeder("enc", 9) as nf:
+        x, w = E(img)
+    for h in hooks:
+        h.remove()
+    out = {"x": x, "w": w, "noise_shapes": np.array([list(s) for s in nf.log])}
+    for j, (xo, w1, w2) in feats.items():
+        out[f"blk{j}_x"], out[f"blk{j}_w1"], out[f"blk{j}_w2"] = xo, w1, w2
+    gw = R.randn("enc.gw", tuple(w.shape), 9, 0.05)
+    (w * gw).sum().backward()
+    out["grad_img"] = img.grad
+    for k, p in E.named_parameters():
+        if p.grad is not None:
+            out["grad:" + k] = p.grad
+        else:
+            out["nograd:" + k] = np.zeros(1)
+    out["state_checksum"] = np.array(R.checksum(sd))
+    save_npz("enc_small.npz", **out)
+
+
+# --------------------------------------------------------------------------- losses
+def gen_loss():
+    import training_utils as TU
+    import metric.pytorch_ssim as PS
+    out = {}
+    a = R.randn("loss.a", (2, 3, 64, 64), 1, 0.5).clamp(-1, 1)
+    b = (a + R.randn("loss.b", (2, 3, 64, 64), 1, 0.1)).clamp(-1, 1)
+    out["ssim_64"] = PS.ssim(a, b)
+    out["ssim_same"] = PS.ssim(a, a)
+    a2 = R.randn("loss.a2", (1, 3, 40, 24), 1, 0.5)
+    b2 = a2 * 0.7 + 0.1
+    out["ssim_40x24"] = PS.ssim(a2, b2)
+
+    # stand-in LPIPS: the real package/weights are absent (parity unpinned there)
+    standin = lambda x, y: ((x - y) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    big_a = R.randn("loss.big_a", (2, 3, 512, 384), 2, 0.5)
+    big_b = big_a + R.randn("loss.big_b", (2, 3, 512, 384), 2, 0.2)
+    big_b.requires_grad_(True)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        l, info = TU.space_loss(big_a, big_b, lpips_model=standin)
+        l.backward()
+        out["img_loss"] = l.detach()
+        out["img_info"] = np.array([info[0][0], info[0][1], info[0][2], info[1], info[2], info[3], info[4]])
+        out["img_grad_b_sum"] = np.array([big_b.grad.double().sum().item(), big_b.grad.double().abs().sum().item()])
+        out["img_grad_b_crop"] = big_b.grad[:, :, 100:116, 200:216].clone()
+        w1 = R.randn("loss.w1", (2, 18, 512), 2)
+        w2 = (w1 * 0.9 + R.randn("loss.w2", (2, 18, 512), 2, 0.3)).requires_grad_(True)
+        l, info = TU.space_loss(w1, w2, image_space=False)
+        l.backward()
+        out["w_loss"] = l.detach()
+        out["w_info"] = np.array([info[0][0], info[0][1], info[0][2], info[1], info[2], info[3], info[4]])
+        out["w_grad"] = w2.grad
+    save_npz("loss.npz", **out)
+
+
+# --------------------------------------------------------------------------- adam
+def gen_adam():
+    from model.utils.custom_adam import LREQAdam
+    import model.utils.lreq as ln
+    lin = ln.Linear(12, 7)
+    conv = ln.Conv2d(4, 6, 3, 1, 1, bias=False)
+    plain = torch.nn.Parameter(torch.zeros(1, 6, 1, 1))
+    params = {"lin.weight": lin.weight, "lin.bias": lin.bias, "conv.weight": conv.weight, "plain": plain}
+    with torch.no_grad():
+        for k, p in params.items():
+            p.copy_(R.randn("adam.p." + k, tuple(p.shape), 0, 0.3))
+    opt = LREQAdam([{"params": list(params.values())}], lr=0.0015, betas=(0.0, 0.99), weight_decay=0)
+    out = {"coef": np.array([getattr(p, "lr_equalization_coef", -1.0) for p in params.values()])}
+    import warnings
+    for step in range(3):
+        for k, p in params.items():
+            p.grad = R.randn(f"adam.g{step}." + k, tuple(p.shape), 0, 0.01 * (step + 1))
+        if step == 1:
+            plain.grad = None    # skipped param must not advance its step counter
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.step()
+        for k, p in params.items():
+            out[f"s{step}:{k}"] = p.detach().clone()
+    save_npz("adam.npz", **out)
+
+
+SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam}
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        print("==", s)
+        SECTIONS[s]()
