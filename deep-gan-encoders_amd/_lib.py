@@ -1,0 +1,62 @@
+"""ctypes binding of libdge_hip.so (C ABI: include/dge_hip.h).  Fails loudly when missing."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdge_hip.so")
+
+
+class DgeError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w_packed", C.c_void_p), ("y", C.c_void_p), ("addend", C.c_void_p),
+        ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("out_scale", C.c_void_p),
+        ("bias", C.c_void_p), ("noise", C.c_void_p), ("noise_w", C.c_void_p), ("stats", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+        ("ksize", C.c_int), ("up", C.c_int), ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int),
+        ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float), ("add_scale", C.c_float),
+        ("dtype", C.c_int),
+    ]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+# name -> argtypes; every symbol declared in include/dge_hip.h must be listed here
+SIGNATURES = {
+    "dge_conv2d": [C.POINTER(ConvDesc), _P],
+    "dge_packed_n": [_I],
+    "dge_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "dge_weight_sumsq": [_P, _P, _I, _I, _I, _F, _P],
+    "dge_linear": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _I, _F, _I, _P],
+    "dge_pixelnorm": [_P, _P, _I, _I, _F, _P],
+    "dge_truncation": [_P, _P, _P, _I, _I, _I, _F, _I, _I, _P],
+    "dge_torgb": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "dge_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dge_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _P],
+    "dge_version": [],
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DgeError(f"{LIB_PATH} is missing: build it with deep-gan-encoders_amd/csrc/build.sh "
+                           "(__graft_entry__.build()). There is no fallback path.")
+        _lib = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        _lib.dge_last_error.restype = C.c_char_p
+        _lib.dge_last_error.argtypes = []
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise DgeError(f"{what} failed ({rc}): {lib().dge_last_error().decode()}")

@@ -1,0 +1,35 @@
+// C ABI glue: error string, version, and the fused-convolution entry point.
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+#include "conv_params.h"
+#include "../../include/dge_hip.h"
+
+static thread_local char g_err[512] = "";
+void dge_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* dge_last_error(void) { return g_err; }
+extern "C" int dge_version(void) { return 100; }
+
+extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
+    DGE_CHECK(d && d->x && d->w_packed && d->y, "conv2d: null tensor");
+    DGE_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: bad shape");
+    DGE_CHECK(d->dtype == DGE_F32 || d->dtype == DGE_BF16, "conv2d: bad dtype %d", d->dtype);
+    DGE_CHECK(!(d->up && d->stats), "conv2d: stats are not available in up mode");
+    DGE_CHECK(!d->noise || d->noise_w, "conv2d: noise without noise_w");
+    ConvParams p;
+    p.x = d->x; p.w = d->w_packed; p.y = d->y; p.addend = d->addend;
+    p.in_scale = d->in_scale; p.in_shift = d->in_shift; p.out_scale = d->out_scale;
+    p.bias = d->bias; p.noise = d->noise; p.noise_w = d->noise_w; p.stats = d->stats;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.Ntot_valid = d->up ? 4 * d->Cout : d->Cout;
+    p.Ntot = dge_packed_n(p.Ntot_valid);
+    p.up = d->up;
+    const int OH = d->up ? 2 * d->H : d->H, OW = d->up ? 2 * d->W : d->W;
+    p.noise_bstride = d->noise_batch > 1 ? OH * OW : 0;
+    p.noise_w_stride = d->noise_w_per_channel ? 1 : 0;
+    p.act = d->act; p.bias_scale = d->bias_scale; p.gain = d->gain; p.add_scale = d->add_scale;
+    p.tiles_x = p.tiles_y = 0;
+    return dge_conv_launch(p, d->dtype, d->ksize, s);
+}

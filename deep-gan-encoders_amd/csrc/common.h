@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 kernels (NHWC activations, bf16 or f32 storage).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+enum { DGE_F32 = 0, DGE_BF16 = 1 };
+enum { DGE_ACT_NONE = 0, DGE_ACT_LRELU = 1, DGE_ACT_RELU = 2 };
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-even
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PER16 = 4;
+    __device__ static float ld(const float* p) { return *p; }
+    __device__ static void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int PER16 = 8;
+    __device__ static float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// unpack a 16-byte chunk into floats / pack back
+__device__ __forceinline__ void unpack16(const uint4& v, float (&f)[4], float*) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+}
+__device__ __forceinline__ void unpack16(const uint4& v, float (&f)[8], bf16_t*) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack16(const float (&f)[4], float*) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+}
+__device__ __forceinline__ uint4 pack16(const float (&f)[8], bf16_t*) {
+    return make_uint4(pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7]));
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == DGE_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+    if (act == DGE_ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// error plumbing shared by the C ABI translation units
+void dge_set_error(const char* fmt, ...);
+#define DGE_CHECK(cond, ...) do { if (!(cond)) { dge_set_error(__VA_ARGS__); return -1; } } while (0)
+#define DGE_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) { dge_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return -3; } } while (0)

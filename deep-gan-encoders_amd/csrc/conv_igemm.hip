@@ -1,0 +1,304 @@
+// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 (MI355X), NHWC activations.
+//
+//   M = output pixels of a TH x TW spatial tile, N = output channels, K = taps x Cin.
+//   The input halo tile ((TH+2) x (TW+2) x KC channels) is staged ONCE per K-chunk into LDS
+//   and re-read at 9 shifted offsets (one per tap), so activations cross HBM/L2 once, not 9x.
+//   Weights are pre-packed [tap][N][Cin] (K contiguous) so both MFMA operands are read from
+//   LDS as 16-byte K-contiguous fragments (ds_read_b128, rows padded by 16 B: conflict free).
+//   MFMA: v_mfma_f32_32x32x16_bf16 (bf16 storage) or v_mfma_f32_32x32x2_f32 (f32 storage,
+//   exact f32 - the parity path); 64-wide wavefronts, 4 waves per workgroup.
+//
+// Fused prologue : per-(sample, in-channel) affine a*x+b applied while staging
+//                  (StyleGAN2 style modulation s[b,i]; instance-norm apply in the encoder).
+// Fused epilogue : per-(sample, out-channel) scale (demodulation d[b,o]), noise*weight, bias,
+//                  lrelu/relu, gain, optional addend (residual blend), optional per-(b,c)
+//                  sum / sum-of-squares for the next instance norm, depth-to-space x2 store
+//                  (the folded transposed-conv+FIR up layer: N = 4 phases x Cout).
+//
+// Reference math: model/stylegan2_generator.py:855-922 (ModulateConvBlock.forward, shared-weight
+// form :876-877,:908-909), model/E/E.py:50-85 (BEBlock.forward).
+#include "common.h"
+#include "conv_params.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
+struct ConvCfg {
+    static constexpr int BM = TH * TW;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;
+    static constexpr int MT = WTM / 32, NT = WTN / 32;
+    static constexpr int KCB = KC * (int)sizeof(T);
+    static constexpr int CH = KCB / 16;
+    static constexpr int PSTR = KCB + 16;
+    static constexpr int HALO = KS / 2;
+    static constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO;
+    static constexpr int RPITCH = rup(HW * PSTR, 256);
+    static constexpr int A_BYTES = HH * RPITCH;
+    static constexpr int B_BYTES = BN * PSTR;
+    static constexpr int ESTR = 32 * (int)sizeof(T) + 16;
+    static constexpr int E_BYTES = 4 * 32 * ESTR;
+    static constexpr int LDS_BYTES = cmax(A_BYTES + 2 * B_BYTES, E_BYTES);
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(MT >= 1 && NT >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+    static_assert(KCB % 32 == 0, "K chunk");
+};
+
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>;
+    constexpr int EP16 = Elem<T>::PER16;
+    __shared__ __attribute__((aligned(256))) unsigned char lds[C::LDS_BYTES];
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + C::A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    int bid = blockIdx.x;
+    const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
+    const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
+    const int b = bid % p.B;
+    const int ntile = bid / p.B;
+    const int x0 = tx_i * TW, y0 = ty_i * TH;
+    const int bn0 = ntile * BN;
+    const T* __restrict__ X = (const T*)p.x;
+    const T* __restrict__ Wp = (const T*)p.w;
+
+    f32x16_t acc[C::MT][C::NT];
+#pragma unroll
+    for (int i = 0; i < C::MT; i++)
+#pragma unroll
+        for (int j = 0; j < C::NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // per-lane LDS offsets of the MFMA fragments
+    int aoff[C::MT];
+#pragma unroll
+    for (int i = 0; i < C::MT; i++) {
+        const int m = wm * C::WTM + i * 32 + (lane & 31);
+        aoff[i] = (m / TW) * C::RPITCH + (m % TW) * C::PSTR + (lane >> 5) * 16;
+    }
+    int boff[C::NT];
+#pragma unroll
+    for (int j = 0; j < C::NT; j++) boff[j] = (wn * C::WTN + j * 32 + (lane & 31)) * C::PSTR + (lane >> 5) * 16;
+
+    constexpr int NTAP = KS * KS;
+    constexpr int NB_ITEMS = BN * C::CH;
+    constexpr int NB_PER = (NB_ITEMS + 255) / 256;
+    const int nchunks = p.Cin / KC;
+    uint4 breg[NB_PER];
+
+    auto load_b = [&](int tap, int kc) {
+#pragma unroll
+        for (int i = 0; i < NB_PER; i++) {
+            const int idx = tid + i * 256;
+            if (NB_ITEMS % 256 == 0 || idx < NB_ITEMS) {
+                const int c = idx % C::CH, row = idx / C::CH;
+                const T* src = Wp + ((size_t)(tap * p.Ntot + bn0 + row) * p.Cin + kc * KC) + c * EP16;
+                breg[i] = *(const uint4*)src;
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NB_PER; i++) {
+            const int idx = tid + i * 256;
+            if (NB_ITEMS % 256 == 0 || idx < NB_ITEMS) {
+                const int c = idx % C::CH, row = idx / C::CH;
+                *(uint4*)(ldsB + buf * C::B_BYTES + row * C::PSTR + c * 16) = breg[i];
+            }
+        }
+    };
+
+    int buf = 0;
+    for (int kc = 0; kc < nchunks; kc++) {
+        __syncthreads();               // everyone finished reading A / B of the previous chunk
+        // ---- stage the input halo tile for this K chunk (prologue affine fused) ----
+        {
+            constexpr int ITEMS = C::HH * C::HW * C::CH;
+            static_assert(256 % C::CH == 0, "a thread keeps one channel sub-range");
+            const int cbase = kc * KC;
+            const int c = tid % C::CH;
+            const bool affine = p.in_scale || p.in_shift;
+            float sc[EP16], sh[EP16];
+            if (affine) {
+                const int ci = b * p.Cin + cbase + c * EP16;
+#pragma unroll
+                for (int e = 0; e < EP16; e++) {
+                    sc[e] = p.in_scale ? p.in_scale[ci + e] : 1.f;
+                    sh[e] = p.in_shift ? p.in_shift[ci + e] : 0.f;
+                }
+            }
+            for (int idx = tid; idx < ITEMS; idx += 256) {
+                const int pix = idx / C::CH;
+                const int hx = pix % C::HW, hy = pix / C::HW;
+                const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    v = *(const uint4*)(X + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cin + cbase + c * EP16);
+                    if (affine) {
+                        float f[EP16];
+                        unpack16(v, f, (T*)nullptr);
+#pragma unroll
+                        for (int e = 0; e < EP16; e++) f[e] = f[e] * sc[e] + sh[e];
+                        v = pack16(f, (T*)nullptr);
+                    }
+                }
+                *(uint4*)(ldsA + hy * C::RPITCH + hx * C::PSTR + c * 16) = v;
+            }
+        }
+        load_b(0, kc);
+        for (int tap = 0; tap < NTAP; tap++) {
+            store_b(buf);
+            __syncthreads();
+            if (tap + 1 < NTAP) load_b(tap + 1, kc);      // global loads fly under the MFMAs
+            const int tapoff = (tap / KS) * C::RPITCH + (tap % KS) * C::PSTR;
+            const unsigned char* bb = ldsB + buf * C::B_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < C::KCB / 32; ks++) {
+                uint4 af[C::MT], bf[C::NT];
+#pragma unroll
+                for (int i = 0; i < C::MT; i++) af[i] = *(const uint4*)(ldsA + aoff[i] + tapoff + ks * 32);
+#pragma unroll
+                for (int j = 0; j < C::NT; j++) bf[j] = *(const uint4*)(bb + boff[j] + ks * 32);
+#pragma unroll
+                for (int i = 0; i < C::MT; i++)
+#pragma unroll
+                    for (int j = 0; j < C::NT; j++) Mma<T>::run(af[i], bf[j], acc[i][j]);
+            }
+            buf ^= 1;
+        }
+    }
+    __syncthreads();   // LDS is re-used as the epilogue transpose buffer from here
+
+    // ---------------------------------------------------------------- epilogue
+    unsigned char* est = lds + wave * (32 * C::ESTR);
+    const int OH = p.up ? 2 * p.H : p.H, OW = p.up ? 2 * p.W : p.W;
+    T* __restrict__ Y = (T*)p.y;
+    const T* __restrict__ ADD = (const T*)p.addend;
+    constexpr int CPR = 32 / EP16;              // 16-byte chunks per 32-channel row
+    constexpr int PPP = 64 / CPR;               // pixels per read-back pass
+#pragma unroll
+    for (int j = 0; j < C::NT; j++) {
+        const int n0 = bn0 + wn * C::WTN + j * 32;          // first N of this 32-wide tile
+        if (n0 >= p.Ntot_valid) continue;                   // wave-uniform
+        const int phase = p.up ? n0 / p.Cout : 0;
+        const int o0 = p.up ? n0 % p.Cout : n0;
+        const int py = phase >> 1, px = phase & 1;
+        const int o = o0 + (lane & 31);
+        const bool ovalid = o < p.Cout;
+        const float osc = (p.out_scale && ovalid) ? p.out_scale[b * p.Cout + o] : 1.f;
+        const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale : 0.f;
+        const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] : 0.f;
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::MT; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = wm * C::WTM + i * 32 + ml;
+                const int gy = y0 + m / TW, gx = x0 + m % TW;
+                const bool pvalid = gy < p.H && gx < p.W;
+                const int oy = p.up ? 2 * gy + py : gy, ox = p.up ? 2 * gx + px : gx;
+                float v = acc[i][j][r] * osc;
+                if (p.noise && pvalid) v += nw * p.noise[(size_t)b * p.noise_bstride + (size_t)oy * OW + ox];
+                v += bia;
+                v = act_apply(v, p.act) * p.gain;
+                if (ADD && pvalid && ovalid)
+                    v += p.add_scale * Elem<T>::ld(ADD + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o);
+                if (pvalid) { ssum += v; ssq += v * v; }
+                Elem<T>::st((T*)(est + ml * C::ESTR) + (lane & 31), v);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 32 / PPP; q++) {
+                const int ml = q * PPP + lane / CPR, ch = lane % CPR;
+                const int m = wm * C::WTM + i * 32 + ml;
+                const int gy = y0 + m / TW, gx = x0 + m % TW;
+                const int oy = p.up ? 2 * gy + py : gy, ox = p.up ? 2 * gx + px : gx;
+                if (gy < p.H && gx < p.W && o0 + ch * EP16 < p.Cout) {
+                    const uint4 v = *(const uint4*)(est + ml * C::ESTR + ch * 16);
+                    *(uint4*)(Y + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o0 + ch * EP16) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (p.stats) {
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            if (lane < 32 && ovalid) {
+                atomicAdd(p.stats + ((size_t)b * p.Cout + o) * 2, ssum);
+                atomicAdd(p.stats + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- dispatch
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
+static int launch_cfg(const ConvParams& p0, hipStream_t s) {
+    ConvParams p = p0;
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    const int ntiles = (p.Ntot + BN - 1) / BN;
+    const long grid = (long)p.tiles_x * p.tiles_y * p.B * ntiles;
+    hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    DGE_LAUNCH_CHECK("conv_igemm");
+    return 0;
+}
+
+// N-tile width the launcher will use for a given Ntot (the packer pads Ntot to this).
+extern "C" int dge_conv_ntile(int ntot) { return ntot >= 128 ? 128 : (ntot > 32 ? 64 : 32); }
+// K-chunk (elements) the launcher will use for a given Cin / dtype.
+static int kchunk(int cin, int esize) {
+    const int maxkc = 128 / esize;
+    if (cin % maxkc == 0) return maxkc;
+    if (cin % (maxkc / 2) == 0) return maxkc / 2;
+    return maxkc / 4;
+}
+
+template <typename T, int KS>
+static int launch_t(const ConvParams& p, hipStream_t s) {
+    constexpr int E = (int)sizeof(T);
+    constexpr int K0 = 128 / E, K1 = 64 / E, K2 = 32 / E;
+    const int bn = dge_conv_ntile(p.Ntot);
+    const int kc = kchunk(p.Cin, E);
+    const bool small = (p.H <= 8 && p.W <= 8) || ((long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn) < 256L * 256);
+#define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
+    if (small) {           // 8x8 pixel tiles: more workgroups for the low-resolution layers
+        if (bn == 128) { if (kc == K0) GO(8, 8, 128, K0, 1, 4); if (kc == K1) GO(8, 8, 128, K1, 1, 4); GO(8, 8, 128, K2, 1, 4); }
+        if (bn == 64)  { if (kc == K0) GO(8, 8, 64, K0, 2, 2);  if (kc == K1) GO(8, 8, 64, K1, 2, 2);  GO(8, 8, 64, K2, 2, 2); }
+        if (kc == K0) GO(8, 16, 32, K0, 4, 1); if (kc == K1) GO(8, 16, 32, K1, 4, 1); GO(8, 16, 32, K2, 4, 1);
+    }
+    if (bn == 128) { if (kc == K0) GO(16, 16, 128, K0, 2, 2); if (kc == K1) GO(16, 16, 128, K1, 2, 2); GO(16, 16, 128, K2, 2, 2); }
+    if (bn == 64)  { if (kc == K0) GO(16, 16, 64, K0, 4, 1);  if (kc == K1) GO(16, 16, 64, K1, 4, 1);  GO(16, 16, 64, K2, 4, 1); }
+    if (kc == K0) GO(16, 16, 32, K0, 4, 1); if (kc == K1) GO(16, 16, 32, K1, 4, 1); GO(16, 16, 32, K2, 4, 1);
+#undef GO
+}
+
+int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s) {
+    const int esize = dtype == DGE_BF16 ? 2 : 4;
+    DGE_CHECK(ksize == 1 || ksize == 3, "conv: ksize %d unsupported", ksize);
+    DGE_CHECK(p.Cin % (32 / esize) == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, 32 / esize);
+    DGE_CHECK(p.Cout % (16 / esize) == 0, "conv: Cout=%d must be a multiple of %d", p.Cout, 16 / esize);
+    DGE_CHECK(p.Ntot % dge_conv_ntile(p.Ntot) == 0, "conv: packed N=%d not padded to the N tile", p.Ntot);
+    DGE_CHECK(!p.up || p.Cout % 32 == 0, "conv: up mode needs Cout %% 32 == 0 (got %d)", p.Cout);
+    if (dtype == DGE_BF16) return ksize == 3 ? launch_t<bf16_t, 3>(p, s) : launch_t<bf16_t, 1>(p, s);
+    return ksize == 3 ? launch_t<float, 3>(p, s) : launch_t<float, 1>(p, s);
+}

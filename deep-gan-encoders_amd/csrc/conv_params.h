@@ -1,0 +1,29 @@
+// Kernel-side description of one implicit-GEMM convolution launch (see conv_igemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct ConvParams {
+    const void* x;            // [B,H,W,Cin]  T
+    const void* w;            // packed [KS*KS][Ntot][Cin] T  (dge_pack_conv_weight)
+    void* y;                  // [B,OH,OW,Cout] T   (OH = 2H in up mode)
+    const void* addend;       // optional [B,OH,OW,Cout] T, y += add_scale*addend
+    const float* in_scale;    // optional [B,Cin]
+    const float* in_shift;    // optional [B,Cin]
+    const float* out_scale;   // optional [B,Cout]
+    const float* bias;        // optional [Cout]
+    const float* noise;       // optional [nB,OH,OW]
+    const float* noise_w;     // [Cout] (stride 1) or scalar (stride 0)
+    float* stats;             // optional [B,Cout,2] (sum, sum of squares), atomically accumulated
+    int B, H, W, Cin, Cout;
+    int Ntot;                 // packed N (padded to the N tile); = 4*Cout (+pad) in up mode
+    int Ntot_valid;           // unpadded N
+    int up;                   // 1: depth-to-space x2 store of the 4 folded phases
+    int noise_bstride;        // 0 (shared noise) or OH*OW
+    int noise_w_stride;       // 0 or 1
+    int act;
+    float bias_scale, gain, add_scale;
+    int tiles_x, tiles_y;     // filled by the launcher
+};
+
+int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);
+extern "C" int dge_conv_ntile(int ntot);

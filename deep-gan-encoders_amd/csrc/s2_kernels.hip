@@ -1,0 +1,267 @@
+// StyleGAN2 support kernels around the implicit-GEMM conv: weight packing (incl. the folded
+// transposed-conv + FIR up layer), sum-of-squares for demodulation, small dense layers
+// (mapping MLP / style affine), toRGB + skip-branch upsample, layout conversion.
+// Reference math: model/stylegan2_generator.py (lines cited per kernel).
+#include "common.h"
+#include "conv_params.h"
+
+// ------------------------------------------------------------------ weight packing
+// in : OIHW f32 [Cout][Cin][KS][KS]       out: [tap][Ntot][Cin] T (rows >= valid N are zero)
+// mode 0: forward conv          out[tap][o][i]      = scale * W[o][i][tap]
+// mode 1: folded up layer       out[tap][ph*Cout+o][i] = scale * sum_{ty,tx} K[ty][tx] W[o][i][3-py-ty+2dy][3-px-tx+2dx]
+//         (conv_transpose2d stride 2 with the flipped kernel followed by the 4x4 FIR,
+//          stylegan2_generator.py:879-896 + :802-807, folded per output phase)
+// mode 2: data-gradient conv    out[tap][i][o]      = scale * W[o][i][KS*KS-1-tap]   (N = Cin, K = Cout)
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KS,
+                                   int Ntot, int mode, float scale) {
+    const int ntap = KS * KS;
+    const int Kdim = (mode == 2) ? Cout : Cin;
+    const long total = (long)ntap * Ntot * Kdim;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k = idx % Kdim;
+        const int n = (idx / Kdim) % Ntot;
+        const int tap = idx / ((long)Kdim * Ntot);
+        float v = 0.f;
+        if (mode == 0) {
+            if (n < Cout) v = w[((size_t)n * Cin + k) * ntap + tap];
+        } else if (mode == 2) {
+            if (n < Cin) v = w[((size_t)k * Cin + n) * ntap + (ntap - 1 - tap)];
+        } else {
+            if (n < 4 * Cout) {
+                const int ph = n / Cout, o = n % Cout;
+                const int py = ph >> 1, px = ph & 1;
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};      // outer(k1,k1) = FIR/64*4
+                for (int ty = 0; ty < 4; ty++) {
+                    const int wy = 3 - py - ty + 2 * dy;
+                    if (wy < 0 || wy > 2) continue;
+                    for (int tx = 0; tx < 4; tx++) {
+                        const int wx = 3 - px - tx + 2 * dx;
+                        if (wx < 0 || wx > 2) continue;
+                        v += k1[ty] * k1[tx] * w[((size_t)o * Cin + k) * 9 + wy * 3 + wx];
+                    }
+                }
+            }
+        }
+        Elem<T>::st(out + idx, v * scale);
+    }
+}
+
+// wsq[o][i] = scale^2 * sum_taps W[o][i][t]^2     (demodulation norm, :867-870)
+__global__ void wsq_kernel(const float* __restrict__ w, float* __restrict__ wsq, int n_oi, int ntap, float scale2) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_oi) return;
+    float s = 0.f;
+    for (int t = 0; t < ntap; t++) { const float v = w[(size_t)idx * ntap + t]; s += v * v; }
+    wsq[idx] = s * scale2;
+}
+
+// ------------------------------------------------------------------ small dense layers
+// y[b][o] = act( (sum_i f(x[b][i]) * W[o][i]) * wscale + bias[o]*bscale + add ) * gain
+// f = identity or square (square: demodulation d = rsqrt(s^2 . wsq + eps) with act = rsqrt).
+// x rows may be strided (ldx) so a [B, L, 512] wp tensor can be indexed per layer.
+enum { LIN_ACT_NONE = 0, LIN_ACT_LRELU = 1, LIN_ACT_RSQRT = 3 };
+__global__ void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                              const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int I, int O,
+                              float wscale, float bscale, float add, int act, float gain, int square) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * O) return;
+    const int b = wave / O, o = wave % O;
+    const float* xr = x + (size_t)b * ldx;
+    const float* wr = W + (size_t)o * I;
+    float s = 0.f;
+    for (int i = lane; i < I; i += 64) { float xv = xr[i]; if (square) xv *= xv; s += xv * wr[i]; }
+    s = wave_sum(s);
+    if (lane == 0) {
+        float v = s * wscale + (bias ? bias[o] * bscale : 0.f) + add;
+        if (act == LIN_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        else if (act == LIN_ACT_RSQRT) v = rsqrtf(v);
+        y[(size_t)b * ldy + o] = v * gain;
+    }
+}
+
+// pixel norm over rows: y = x / sqrt(mean(x^2) + eps)   (:550-553)
+__global__ void pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D, float eps) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B) return;
+    float s = 0.f;
+    for (int i = lane; i < D; i += 64) { const float v = x[(size_t)wave * D + i]; s += v * v; }
+    s = wave_sum(s);
+    const float r = rsqrtf(s / D + eps);
+    for (int i = lane; i < D; i += 64) y[(size_t)wave * D + i] = x[(size_t)wave * D + i] * r;
+}
+
+// truncation: wp[b][l][:] = w_avg + (w[b][:] - w_avg) * (l < layers ? psi : 1)      (:311-333)
+// w is [B, D] (repeat) when w_is_wp == 0, else [B, L, D].
+__global__ void truncation_kernel(const float* __restrict__ w, const float* __restrict__ w_avg, float* __restrict__ wp,
+                                  int B, int L, int D, float psi, int layers, int w_is_wp, int apply) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)B * L * D) return;
+    const int d = idx % D, l = (idx / D) % L, b = idx / ((long)D * L);
+    const float v = w_is_wp ? w[idx] : w[(size_t)b * D + d];
+    if (!apply) { wp[idx] = v; return; }
+    const float coef = l < layers ? psi : 1.f;
+    wp[idx] = w_avg[d] + (v - w_avg[d]) * coef;
+}
+
+// ------------------------------------------------------------------ toRGB + skip upsample
+// img[b][c][y][x] (NCHW f32) = sum_i x[b,y,x,i] * (Wrgb[c][i]*wscale*s[b][i]) + bias[c]
+//                              + up2(prev)[b][c][y][x]        (prev: [B,3,H/2,W/2] f32 or null)
+// ModulateConvBlock k=1, demodulate=False, linear (:465-474) and UpsamplingLayer scale 2
+// (:603-615): zero-insert, pad (2,1), 4x4 FIR (sum 4) == per-axis taps {.25,.75} / {.75,.25}.
+template <typename T, int NC>
+__global__ void torgb_kernel(const T* __restrict__ x, const float* __restrict__ wrgb, const float* __restrict__ s,
+                             const float* __restrict__ bias, const float* __restrict__ prev, float* __restrict__ img,
+                             int B, int H, int W, int Cin, float wscale) {
+    extern __shared__ float wl[];                 // [NC][Cin] modulated weights of this sample
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < NC * Cin; i += blockDim.x) wl[i] = wrgb[i] * wscale * s[(size_t)b * Cin + i % Cin];
+    __syncthreads();
+    constexpr int EP16 = Elem<T>::PER16;
+    const int HW = H * W;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < HW; pix += gridDim.x * blockDim.x) {
+        const T* xp = x + ((size_t)b * HW + pix) * Cin;
+        float acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[c] = 0.f;
+        for (int i = 0; i < Cin; i += EP16) {
+            const uint4 v = *(const uint4*)(xp + i);
+            float f[EP16];
+            unpack16(v, f, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < EP16; e++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) acc[c] += f[e] * wl[c * Cin + i + e];
+        }
+        const int y = pix / W, xx = pix % W;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float v = acc[c] + bias[c];
+            if (prev) {
+                const int h2 = H >> 1, w2 = W >> 1;
+                const float* pp = prev + ((size_t)b * NC + c) * h2 * w2;
+                const int my = y >> 1, mx = xx >> 1;
+                // even output: .25*x[m-1] + .75*x[m];  odd output: .75*x[m] + .25*x[m+1]
+                const int ya = (y & 1) ? my : my - 1, yb = (y & 1) ? my + 1 : my;
+                const int xa = (xx & 1) ? mx : mx - 1, xb = (xx & 1) ? mx + 1 : mx;
+                const float wya = (y & 1) ? 0.75f : 0.25f, wyb = 1.f - wya;
+                const float wxa = (xx & 1) ? 0.75f : 0.25f, wxb = 1.f - wxa;
+                auto at = [&](int yy, int xq) { return (yy >= 0 && yy < h2 && xq >= 0 && xq < w2) ? pp[yy * w2 + xq] : 0.f; };
+                v += wya * (wxa * at(ya, xa) + wxb * at(ya, xb)) + wyb * (wxa * at(yb, xa) + wxb * at(yb, xb));
+            }
+            img[((size_t)b * NC + c) * HW + pix] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ layout conversion
+// NCHW f32 (batch-broadcast when src_B == 1) -> NHWC T
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int HW, int src_B) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)B * C * HW) return;
+    const int c = idx % C; const long r = idx / C; const int pix = r % HW; const int b = r / HW;
+    const int sb = src_B == 1 ? 0 : b;
+    Elem<T>::st(dst + idx, src[((size_t)sb * C + c) * HW + pix]);
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int C, int HW) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)B * C * HW) return;
+    const int pix = idx % HW; const long r = idx / HW; const int c = r % C; const int b = r / C;
+    dst[idx] = Elem<T>::ld(src + ((size_t)b * HW + pix) * C + c);
+}
+
+// =================================================================== C ABI
+#include "../../include/dge_hip.h"
+
+extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
+                                    float scale, hipStream_t s) {
+    DGE_CHECK(mode >= 0 && mode <= 2, "pack: bad mode %d", mode);
+    DGE_CHECK(mode != 1 || ksize == 3, "pack: up fold needs a 3x3 kernel");
+    const int nvalid = mode == 1 ? 4 * cout : (mode == 2 ? cin : cout);
+    const int ntot = dge_packed_n(nvalid);
+    const int kdim = mode == 2 ? cout : cin;
+    const long total = (long)ksize * ksize * ntot * kdim;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w_oihw, (bf16_t*)out, cout, cin, ksize, ntot, mode, scale);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(grid), dim3(256), 0, s, w_oihw, (float*)out, cout, cin, ksize, ntot, mode, scale);
+    DGE_LAUNCH_CHECK("pack_conv_weight");
+    return 0;
+}
+
+extern "C" int dge_packed_n(int nvalid) {
+    const int t = dge_conv_ntile(nvalid);
+    return (nvalid + t - 1) / t * t;
+}
+
+extern "C" int dge_weight_sumsq(const float* w_oihw, float* wsq, int cout, int cin, int ksize, float scale, hipStream_t s) {
+    const int n = cout * cin;
+    hipLaunchKernelGGL(wsq_kernel, dim3((n + 255) / 256), dim3(256), 0, s, w_oihw, wsq, n, ksize * ksize, scale * scale);
+    DGE_LAUNCH_CHECK("weight_sumsq");
+    return 0;
+}
+
+extern "C" int dge_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int I, int O,
+                          float wscale, float bscale, float add, int act, float gain, int square_input, hipStream_t s) {
+    DGE_CHECK(B > 0 && I > 0 && O > 0, "linear: bad shape");
+    const long waves = (long)B * O;
+    hipLaunchKernelGGL(linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, ldx, w, bias, y, ldy, B, I, O,
+                       wscale, bscale, add, act, gain, square_input);
+    DGE_LAUNCH_CHECK("linear");
+    return 0;
+}
+
+extern "C" int dge_pixelnorm(const float* x, float* y, int B, int D, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(pixelnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, y, B, D, eps);
+    DGE_LAUNCH_CHECK("pixelnorm");
+    return 0;
+}
+
+extern "C" int dge_truncation(const float* w, const float* w_avg, float* wp, int B, int L, int D, float psi, int layers,
+                              int w_is_wp, hipStream_t s) {
+    const long n = (long)B * L * D;
+    const int apply = (psi < 1.0f && layers > 0) ? 1 : 0;
+    hipLaunchKernelGGL(truncation_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, w_avg, wp, B, L, D, psi,
+                       layers, w_is_wp, apply);
+    DGE_LAUNCH_CHECK("truncation");
+    return 0;
+}
+
+extern "C" int dge_torgb(const void* x, const float* wrgb, const float* style, const float* bias, const float* prev,
+                         float* img, int B, int H, int W, int cin, float wscale, int dtype, hipStream_t s) {
+    const int esz = dtype == DGE_BF16 ? 2 : 4;
+    DGE_CHECK(cin % (16 / esz) == 0, "torgb: Cin=%d not a multiple of %d", cin, 16 / esz);
+    const int hw = H * W;
+    int gx = (hw + 255) / 256; if (gx > 2048) gx = 2048;
+    const size_t shm = (size_t)3 * cin * sizeof(float);
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL((torgb_kernel<bf16_t, 3>), dim3(gx, B), dim3(256), shm, s, (const bf16_t*)x, wrgb, style, bias, prev, img, B, H, W, cin, wscale);
+    else
+        hipLaunchKernelGGL((torgb_kernel<float, 3>), dim3(gx, B), dim3(256), shm, s, (const float*)x, wrgb, style, bias, prev, img, B, H, W, cin, wscale);
+    DGE_LAUNCH_CHECK("torgb");
+    return 0;
+}
+
+extern "C" int dge_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int src_B, int dtype, hipStream_t s) {
+    const long n = (long)B * C * HW;
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (bf16_t*)dst, B, C, HW, src_B);
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (float*)dst, B, C, HW, src_B);
+    DGE_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int dge_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtype, hipStream_t s) {
+    const long n = (long)B * C * HW;
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)src, dst, B, C, HW);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)src, dst, B, C, HW);
+    DGE_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}

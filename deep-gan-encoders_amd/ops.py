@@ -1,0 +1,145 @@
+"""Tensor-level wrappers over the C ABI (include/dge_hip.h).  PyTorch supplies device memory
+and the stream; every computation happens in libdge_hip.so."""
+import ctypes as C
+import math
+
+import torch
+
+from ._lib import lib, check, ConvDesc, DgeError
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
+PACK_FWD, PACK_UPFOLD, PACK_DGRAD = 0, 1, 2
+
+
+def tdtype(dtype):
+    return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+def dtype_of(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise DgeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DgeError("tensor is not on the GPU: the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise DgeError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    if t is not None and t.dtype != torch.float32:
+        raise DgeError(f"expected float32, got {t.dtype}")
+    return _p(t)
+
+
+def packed_n(n):
+    return lib().dge_packed_n(int(n))
+
+
+def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
+    """w: [Cout,Cin,k,k] f32 (reference layout) -> packed [k*k, Npad, K] tensor of `dtype`."""
+    cout, cin, k, _ = w.shape
+    nvalid = 4 * cout if mode == PACK_UPFOLD else (cin if mode == PACK_DGRAD else cout)
+    kdim = cout if mode == PACK_DGRAD else cin
+    out = torch.empty((k * k, packed_n(nvalid), kdim), dtype=tdtype(dtype), device=w.device)
+    check(lib().dge_pack_conv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, k, mode, dtype, float(scale),
+                                     _stream()), "dge_pack_conv_weight")
+    return out
+
+
+def weight_sumsq(w, scale=1.0):
+    cout, cin, k, _ = w.shape
+    out = torch.empty((cout, cin), dtype=torch.float32, device=w.device)
+    check(lib().dge_weight_sumsq(_f32(w.detach().contiguous()), _p(out), cout, cin, k, float(scale), _stream()),
+          "dge_weight_sumsq")
+    return out
+
+
+def linear(x, w, bias=None, wscale=1.0, bscale=1.0, add=0.0, act=ACT_NONE, gain=1.0, square_input=False, out=None):
+    """x: [B, I] f32 view with unit inner stride (row stride arbitrary); w: [O, I]."""
+    B, I = x.shape
+    O = w.shape[0]
+    if x.stride(1) != 1:
+        raise DgeError("linear: inner stride must be 1")
+    if out is None:
+        out = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    if not x.is_cuda:
+        raise DgeError("tensor is not on the GPU: the HIP path has no CPU fallback")
+    check(lib().dge_linear(C.c_void_p(x.data_ptr()), x.stride(0), _f32(w), _f32(bias), C.c_void_p(out.data_ptr()),
+                           out.stride(0), B, I, O, float(wscale), float(bscale), float(add), act, float(gain),
+                           1 if square_input else 0, _stream()), "dge_linear")
+    return out
+
+
+def pixelnorm(x, eps=1e-8):
+    y = torch.empty_like(x)
+    check(lib().dge_pixelnorm(_f32(x), _p(y), x.shape[0], x.shape[1], eps, _stream()), "dge_pixelnorm")
+    return y
+
+
+def truncation(w, w_avg, num_layers, psi, layers):
+    w_is_wp = (w.ndim == 3)
+    B, D = w.shape[0], w.shape[-1]
+    wp = torch.empty((B, num_layers, D), dtype=torch.float32, device=w.device)
+    check(lib().dge_truncation(_f32(w.contiguous()), _f32(w_avg), _p(wp), B, num_layers, D, float(psi), int(layers),
+                               1 if w_is_wp else 0, _stream()), "dge_truncation")
+    return wp
+
+
+def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
+           bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
+           out=None):
+    """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout]."""
+    B, H, W, Cin = x.shape
+    dt = dtype_of(x)
+    OH, OW = (2 * H, 2 * W) if up else (H, W)
+    if out is None:
+        out = torch.empty((B, OH, OW, cout), dtype=x.dtype, device=x.device)
+    d = ConvDesc()
+    d.x, d.w_packed, d.y, d.addend = _p(x), _p(w_packed), _p(out), _p(addend)
+    d.in_scale, d.in_shift, d.out_scale = _f32(in_scale), _f32(in_shift), _f32(out_scale)
+    d.bias, d.noise, d.noise_w, d.stats = _f32(bias), _f32(noise), _f32(noise_w), _f32(stats)
+    d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
+    d.ksize, d.up = ksize, 1 if up else 0
+    d.noise_batch = 1 if noise is None else noise.shape[0]
+    d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
+    d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt
+    if w_packed.dtype != x.dtype:
+        raise DgeError("conv2d: packed weight dtype differs from activation dtype")
+    check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
+    return out
+
+
+def torgb(x, wrgb, style, bias, prev, wscale):
+    B, H, W, Cin = x.shape
+    img = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    check(lib().dge_torgb(_p(x), _f32(wrgb), _f32(style), _f32(bias), _f32(prev), _p(img), B, H, W, Cin, float(wscale),
+                          dtype_of(x), _stream()), "dge_torgb")
+    return img
+
+
+def nchw_to_nhwc(src, B, dtype):
+    """src: [sB, C, H, W] f32 with sB in {1, B} -> [B, H, W, C] of dtype."""
+    sB, Cc, H, W = src.shape
+    dst = torch.empty((B, H, W, Cc), dtype=tdtype(dtype), device=src.device)
+    check(lib().dge_nchw_to_nhwc(_f32(src.contiguous()), _p(dst), B, Cc, H * W, sB, dtype, _stream()), "dge_nchw_to_nhwc")
+    return dst
+
+
+def nhwc_to_nchw(src):
+    B, H, W, Cc = src.shape
+    dst = torch.empty((B, Cc, H, W), dtype=torch.float32, device=src.device)
+    check(lib().dge_nhwc_to_nchw(_p(src), _p(dst), B, Cc, H * W, dtype_of(src), _stream()), "dge_nhwc_to_nchw")
+    return dst

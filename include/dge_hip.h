@@ -1,0 +1,102 @@
+/* dge_hip.h - C ABI of libdge_hip.so: the MI355X (gfx950) kernels behind the E_align hot path
+ * of disanda/Deep-GAN-Encoders.
+ *
+ * The reference has no FFI: its hot path sits behind torch.nn.Module objects that call
+ * torch.nn.functional ops.  Each entry point below replaces the op sequence of
+ * the cited reference lines (paths relative to the reference root).  The Python modules in
+ * deep-gan-encoders_amd/ keep the reference's class names / forward signatures / state_dict keys
+ * and call these functions through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless named host_*.  No allocation happens inside;
+ *     outputs and scratch are caller provided.  No global mutable state except the last-error
+ *     string (thread local).  Every call is asynchronous on `stream`.
+ *   - Activations: NHWC, element type selected by `dtype` (DGE_F32 = 0 exact-f32 parity path,
+ *     DGE_BF16 = 1 bf16 storage with f32 accumulation).  Images and latents: NCHW / row-major f32
+ *     exactly as the reference's tensors.
+ *   - Return 0 on success, <0 on error (-1 invalid argument / unsupported shape, -3 launch
+ *     failure); dge_last_error() returns the message.
+ */
+#ifndef DGE_HIP_H
+#define DGE_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* dge_stream_t;   /* == hipStream_t */
+
+#define DGE_DTYPE_F32 0
+#define DGE_DTYPE_BF16 1
+#define DGE_ACT_LINEAR 0
+#define DGE_ACT_LRELU02 1
+#define DGE_ACT_RELU_ 2
+#define DGE_LIN_RSQRT 3
+#define DGE_PACK_FWD 0      /* [tap][Cout][Cin]                                   */
+#define DGE_PACK_UPFOLD 1   /* [tap][4*Cout][Cin]: conv_transpose(s2)+FIR folded  */
+#define DGE_PACK_DGRAD 2    /* [tap][Cin][Cout], taps flipped                     */
+
+const char* dge_last_error(void);
+int dge_version(void);
+
+/* One fused convolution launch.  Replaces, depending on the fields set:
+ *   - ModulateConvBlock.forward, model/stylegan2_generator.py:855-922 (style modulation =
+ *     in_scale, demodulation = out_scale, noise :911-916, bias :918-920, lrelu*sqrt2 :921;
+ *     `up` = conv_transpose2d stride 2 + filter :879-896 via DGE_PACK_UPFOLD weights);
+ *   - BEBlock convs, model/E/E.py:58-62,69-74,81-84 (instance norm apply = in_scale/in_shift,
+ *     noise_weight/bias/leaky_relu epilogue, residual blend via addend, statistics of the
+ *     output for the next mean/std :64-65 via `stats`). */
+typedef struct dge_conv_desc {
+    const void* x;            /* [B,H,W,Cin]                       */
+    const void* w_packed;     /* from dge_pack_conv_weight          */
+    void* y;                  /* [B,OH,OW,Cout], OH = up ? 2H : H   */
+    const void* addend;       /* optional, same shape as y          */
+    const float* in_scale;    /* optional [B,Cin]                   */
+    const float* in_shift;    /* optional [B,Cin]                   */
+    const float* out_scale;   /* optional [B,Cout]                  */
+    const float* bias;        /* optional [Cout]                    */
+    const float* noise;       /* optional [noise_batch,OH,OW]       */
+    const float* noise_w;     /* [Cout] or [1]                      */
+    float* stats;             /* optional [B,Cout,2], pre-zeroed    */
+    int B, H, W, Cin, Cout;
+    int ksize;                /* 1 or 3 (stride 1, pad ksize/2)     */
+    int up;                   /* 0 / 1                              */
+    int noise_batch;          /* 1 = shared noise plane, else B     */
+    int noise_w_per_channel;  /* 0 scalar strength, 1 per channel   */
+    int act;                  /* DGE_ACT_*                          */
+    float bias_scale, gain, add_scale;
+    int dtype;
+} dge_conv_desc;
+int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
+
+/* Weight preparation (once per weight update).  w_oihw: [Cout][Cin][k][k] f32 as stored by the
+ * reference (model/stylegan2_generator.py:814-819; model/utils/lreq.py:107-110).  `out` holds
+ * k*k * dge_packed_n(N) * K elements of `dtype` (N,K per mode above). */
+int dge_packed_n(int n_valid);
+int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
+                         float scale, dge_stream_t stream);
+/* wsq[o][i] = scale^2 * sum_taps W^2 : the demodulation norm of :867-870 for the shared-weight form */
+int dge_weight_sumsq(const float* w_oihw, float* wsq, int cout, int cin, int ksize, float scale, dge_stream_t stream);
+
+/* y[b][o] = act((sum_i f(x[b][i]) W[o][i])*wscale + bias[o]*bscale + add)*gain, f = id or square.
+ * DenseBlock.forward :990-996 (mapping :267-270, style :825-829) and ln.Linear (lreq.py:69-75);
+ * with square_input=1, act=DGE_LIN_RSQRT it evaluates d[b][o] = rsqrt(s^2 . wsq + eps) (:867-870). */
+int dge_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int I, int O,
+               float wscale, float bscale, float add, int act, float gain, int square_input, dge_stream_t stream);
+int dge_pixelnorm(const float* x, float* y, int B, int D, float eps, dge_stream_t stream);          /* :550-553 */
+int dge_truncation(const float* w, const float* w_avg, float* wp, int B, int L, int D, float psi, int layers,
+                   int w_is_wp, dge_stream_t stream);                                                /* :311-333 */
+
+/* toRGB (1x1 modulated conv, no demod, linear) + bias + 2x FIR-upsampled previous image:
+ * SynthesisModule.forward :515-522, ModulateConvBlock k=1 :465-474, UpsamplingLayer :603-615.
+ * x [B,H,W,Cin] dtype; wrgb [3][Cin] f32; style [B,Cin]; prev [B,3,H/2,W/2] f32 or NULL; img [B,3,H,W] f32. */
+int dge_torgb(const void* x, const float* wrgb, const float* style, const float* bias, const float* prev, float* img,
+              int B, int H, int W, int cin, float wscale, int dtype, dge_stream_t stream);
+
+int dge_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int src_B, int dtype, dge_stream_t stream);
+int dge_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtype, dge_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

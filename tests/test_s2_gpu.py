@@ -1,0 +1,128 @@
+"""GPU parity of the StyleGAN2 HIP path (through the C ABI) against the golden vectors of the
+reference and against the oracle.  Tolerances: f32 path 2e-4 of the tensor's max magnitude
+(exact-f32 MFMA, differences are summation order only); bf16 path 6e-2 at the image / 3e-2 per
+layer (bf16 storage of activations and weights, f32 accumulation)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden
+from tests.golden import recipe as R
+from tests.helpers import s2_shapes, modconv_shapes
+from oracle import ref_torch as O
+
+pytestmark = pytest.mark.gpu
+TOL = {"f32": 2e-4, "bf16": 3e-2}
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu()
+    b = torch.as_tensor(np.asarray(b)).float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def to_nhwc(x, cd):
+    t = x.permute(0, 2, 3, 1).contiguous().cuda()
+    return t.bfloat16() if cd == "bf16" else t
+
+
+def from_nhwc(y):
+    return y.float().permute(0, 3, 1, 2).cpu()
+
+
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_modconv_blocks_vs_reference_golden(cd):
+    from dge_amd.stylegan2_generator import ModulateConvBlock
+    g = golden("s2_blocks.npz")
+    for ci in range(6):
+        cin, cout, res, up, k = [int(v) for v in g[f"c{ci}_cfg"]]
+        torgb = (k == 1)
+        blk = ModulateConvBlock(cin, cout, res, 512, kernel_size=k, scale_factor=2 if up else 1,
+                                demodulate=not torgb, add_noise=not torgb,
+                                activation_type="linear" if torgb else "lrelu").cuda()
+        sd = R.fill_s2(modconv_shapes(cin, cout, res, k, noise=not torgb, up=bool(up)), seed=100 + ci)
+        blk.load_state_dict(sd)
+        rin = res // 2 if up else res
+        x = R.randn(f"mc{ci}.x", (2, cin, rin, rin), 7)
+        w = R.randn(f"mc{ci}.w", (2, 512), 7).cuda()
+        with torch.no_grad():
+            y, s = blk(to_nhwc(x, cd), w)
+        assert relerr(s, g[f"c{ci}_style"]) < 1e-5
+        y = y.cpu() if torgb else from_nhwc(y)
+        e = relerr(y, g[f"c{ci}_y"])
+        assert e < TOL[cd], f"case {ci} ({cin}->{cout} res {res} up {up} k {k}) {cd}: {e:.3e}"
+
+
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_synthesis_vs_reference_golden(cd):
+    import dge_amd
+    g = golden("s2_small.npz")
+    P = R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11)
+    G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype=cd).cuda()
+    G.load_state_dict(P)
+    G.eval()
+    wp = R.randn("s2.wp", (2, 10, 512), 5).cuda()
+    with torch.no_grad():
+        r = G.synthesis(wp)
+    assert relerr(r["style00"], g["syn_style00"]) < 1e-5
+    assert relerr(r["output_style4"], g["syn_output_style4"]) < 1e-5
+    e = relerr(r["image"], g["syn_image"])
+    assert e < (2e-4 if cd == "f32" else 6e-2), e
+    # full forward in eval mode: mapping + truncation + synthesis
+    z = R.randn("s2.z", (2, 512), 5).cuda()
+    with torch.no_grad():
+        r = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+    assert relerr(r["w"], g["eval_w"]) < 1e-5
+    assert relerr(r["wp"], g["eval_wp"]) < 1e-5
+    assert relerr(r["image"], g["eval_image"]) < (2e-4 if cd == "f32" else 6e-2)
+
+
+def test_train_mode_quirk_q1_matches_reference():
+    """G is never .eval()'d in E_align_s2.py: w_avg EMA + style mixing stay active."""
+    import dge_amd
+    g = golden("s2_small.npz")
+    P = R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11)
+    G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="f32").cuda()
+    G.load_state_dict(P)
+    G.train()
+    z = R.randn("s2.z", (2, 512), 5).cuda()
+    new_z = R.randn("s2.new_z", (2, 512), 5).cuda()
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: new_z.clone()
+    try:
+        for it, tag in ((3, "a"), (4, "b")):
+            np.random.seed(it)
+            with torch.no_grad():
+                r = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+            assert relerr(G.truncation.w_avg, g[f"train_{tag}_w_avg_after"]) < 1e-5
+            assert relerr(r["wp"], g[f"train_{tag}_wp"]) < 1e-5
+            assert relerr(r["image"], g[f"train_{tag}_image"]) < 2e-4
+    finally:
+        torch.randn_like = orig
+
+
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_conv_vs_oracle_random_shapes(cd):
+    """Plain fused conv (encoder-style epilogue) against the oracle on ragged sizes."""
+    import torch.nn.functional as F
+    from dge_amd import ops
+    dt = ops.BF16 if cd == "bf16" else ops.F32
+    for (B, cin, cout, H, W, k) in [(1, 16, 16, 20, 12, 3), (2, 32, 64, 33, 17, 3), (1, 64, 32, 16, 16, 1),
+                                    (3, 128, 128, 5, 7, 3), (1, 16, 32, 64, 64, 3)]:
+        x = R.randn("cv.x", (B, cin, H, W), 1)
+        w = R.randn("cv.w", (cout, cin, k, k), 1, 1.0 / (cin * k * k) ** 0.5)
+        bias = R.randn("cv.b", (cout,), 1, 0.3)
+        nw = R.randn("cv.nw", (cout,), 1, 0.3)
+        noise = R.randn("cv.n", (B, 1, H, W), 1)
+        isc = R.randn("cv.isc", (B, cin), 1, 0.3, 1.0)
+        ish = R.randn("cv.ish", (B, cin), 1, 0.3)
+        xin = x * isc[:, :, None, None] + ish[:, :, None, None]
+        ref = F.leaky_relu(F.conv2d(xin, w, padding=k // 2) + nw.view(1, -1, 1, 1) * noise + bias.view(1, -1, 1, 1), 0.2)
+        stats = torch.zeros(B, cout, 2, device="cuda")
+        y = ops.conv2d(to_nhwc(x, cd), ops.pack_conv_weight(w.cuda(), ops.PACK_FWD, dt), cout, k,
+                       in_scale=isc.cuda(), in_shift=ish.cuda(), bias=bias.cuda(), noise=noise.view(B, H, W).cuda(),
+                       noise_w=nw.cuda(), act=ops.ACT_LRELU, stats=stats)
+        e = relerr(from_nhwc(y), ref)
+        assert e < TOL[cd], ((B, cin, cout, H, W, k), e)
+        s_ref = torch.stack([ref.sum(dim=(2, 3)), (ref * ref).sum(dim=(2, 3))], dim=2)
+        assert relerr(stats, s_ref) < (1e-4 if cd == "f32" else 3e-2)
