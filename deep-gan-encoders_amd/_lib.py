@@ -35,6 +35,9 @@ SIGNATURES = {
     "dge_torgb": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dge_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dge_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _P],
+    "dge_fromrgb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dge_stats_finalize": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "dge_blend": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_version": [],
 }
 

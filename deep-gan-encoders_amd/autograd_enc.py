@@ -1,0 +1,105 @@
+"""Encoder forward / backward pipelines over the HIP ops, exposed as one autograd.Function
+(PyTorch only routes the gradient tensors; every kernel is in libdge_hip.so)."""
+import torch
+
+from . import ops
+from .stylegan2_generator import _dt
+
+
+def _packed(cache, conv, dtype, mode):
+    """Packed copy of a conv weight, rebuilt when the parameter was updated in place."""
+    w = conv.weight
+    key = (id(w), mode, dtype)
+    ver = (w._version, w.data_ptr())
+    hit = cache.get(key)
+    if hit is None or hit[0] != ver:
+        hit = (ver, ops.pack_conv_weight(w, mode, dtype, 1.0))
+        cache[key] = hit
+    return hit[1]
+
+
+def draw_noises(E, B, R, device):
+    out = []
+    for j in range(E.layer_count):
+        r = R >> j
+        out.append(torch.randn(B, 1, r, r, device=device))
+        if j != E.layer_count - 1:
+            out.append(torch.randn(B, 1, r, r, device=device))
+    return out
+
+
+def encoder_forward(E, img, noises=None, save=False):
+    """BE.forward (reference model/E/E.py:122-136) + BEBlock.forward (:50-85)."""
+    dt = _dt(E.compute_dtype)
+    dev = img.device
+    B, _, R, _ = img.shape
+    if noises is None:
+        noises = draw_noises(E, B, R, dev)
+    cache = E.__dict__.setdefault("_pack_cache", {})
+    zeros = lambda c: torch.zeros((B, c, 2), dtype=torch.float32, device=dev)
+    fr = E.FromRGB.from_rgb
+    stats = zeros(E.startf)
+    x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats)
+    saved = {"img": img, "x0": x, "blocks": []} if save else None
+    ws, ni = [], 0
+    L = E.layer_count
+    for j, blk in enumerate(E.decode_block):
+        Cc, C2 = blk.inputs, blk.outputs
+        H = R >> j
+        last = not blk.has_last_conv
+        musig1, sc1, sh1 = ops.stats_finalize(stats, H * H)
+        w1 = ops.linear(musig1, blk.inver_mod1.weight.detach(), blk.inver_mod1.bias.detach())
+        n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
+        st1 = zeros(Cc)
+        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
+                        noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
+                        act=ops.ACT_LRELU, stats=st1)
+        musig2, sc2, sh2 = ops.stats_finalize(st1, H * H)
+        w2 = ops.linear(musig2, blk.inver_mod2.weight.detach(), blk.inver_mod2.bias.detach())
+        rec = dict(x=x, musig1=musig1, sc1=sc1, sh1=sh1, n1=n1, x1=x1, musig2=musig2, sc2=sc2, sh2=sh2) if save else None
+        has3 = Cc != C2
+        nstats = zeros(C2) if not last else None
+        if not last:
+            n2 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
+            a2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=sc2, in_shift=sh2, noise=n2,
+                            noise_w=blk.noise_weight_2.detach().reshape(-1), bias=blk.bias_2.detach().reshape(-1),
+                            act=ops.ACT_LRELU)
+            if has3:
+                x2 = ops.blend(a2, pool=True)
+                xp = ops.blend(x, pool=True)
+                out = ops.conv2d(xp, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(),
+                                 gain=0.889, addend=x2, add_scale=0.111, stats=nstats)
+            else:
+                xp = ops.blend(x, pool=True, alpha=0.889)
+                out = ops.blend(a2, z=xp, pool=True, alpha=0.111, beta=1.0, stats=nstats)
+            if save:
+                rec.update(n2=n2, a2=a2, xp=xp if has3 else None)
+        else:
+            if has3:
+                y2 = ops.blend(x1, sc=sc2, sh=sh2)
+                out = ops.conv2d(x, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(),
+                                 gain=0.889, addend=y2, add_scale=0.111)
+            else:
+                out = ops.blend(x1, z=x, sc=sc2, sh=sh2, alpha=0.111, beta=0.889)
+        if save:
+            saved["blocks"].append(rec)
+        ws = [w2, w1] + ws          # E.py:130-134: later (deeper) blocks come first
+        x, stats = out, nstats
+    w = torch.stack(ws, dim=1)
+    return ops.nhwc_to_nchw(x), w, saved
+
+
+class EncoderFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, E, img, noises, *params):
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        xo, w, saved = encoder_forward(E, img.detach(), noises, save=need)
+        ctx.E, ctx.saved_acts = E, saved
+        ctx.mark_non_differentiable(xo)
+        return xo, w
+
+    @staticmethod
+    def backward(ctx, g_x, g_w):
+        from .autograd_enc_bwd import encoder_backward
+        grads = encoder_backward(ctx.E, ctx.saved_acts, g_w.contiguous())
+        return (None, None, None) + tuple(grads)

@@ -1,0 +1,178 @@
+// Encoder (E.BE) support kernels: FromRGB, instance-norm statistics, pooling / residual blends.
+// All are HBM-bound streaming kernels over NHWC tensors: 16-byte accesses per lane, per-(b,c)
+// statistics accumulated in registers -> LDS -> one atomic per channel per workgroup.
+// Reference: model/E/E.py:50-85 (BEBlock.forward), model/utils/net.py:231-240 (FromRGB).
+#include "common.h"
+#include "../../include/dge_hip.h"
+
+// Per-thread partial (sum, sumsq) for EP channels -> LDS reduce over threads that own the same
+// channel chunk -> atomics into stats[b][c][2].  All 256 threads must call.
+template <int EP>
+__device__ __forceinline__ void block_stats_flush(float (&s)[EP], float (&q)[EP], int chunk, int cpt, int ppi,
+                                                  float* __restrict__ stats_b, int C, float* red) {
+    // red: [256][2*EP] floats
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int e = 0; e < EP; e++) { red[tid * 2 * EP + e] = s[e]; red[tid * 2 * EP + EP + e] = q[e]; }
+    __syncthreads();
+    // thread t < cpt*EP*2 reduces one (chunk, e, kind) over the ppi pixel slots
+    for (int item = tid; item < cpt * 2 * EP; item += 256) {
+        const int ch = item / (2 * EP), k = item % (2 * EP);
+        float a = 0.f;
+        for (int j = 0; j < ppi; j++) a += red[(j * cpt + ch) * 2 * EP + k];
+        const int c = ch * EP + (k % EP);
+        if (c < C) atomicAdd(stats_b + (size_t)c * 2 + (k / EP), a);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ FromRGB
+// y[b,p,o] = lrelu(sum_c img[b,c,p] W[o,c] + bias[o], 0.2)   img NCHW f32 -> y NHWC T, + stats
+template <typename T>
+__global__ __launch_bounds__(256) void fromrgb_kernel(const float* __restrict__ img, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, T* __restrict__ y,
+                                                       float* __restrict__ stats, int HW, int C) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * 2 * EP];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    float w0[EP], w1[EP], w2[EP], bb[EP], s[EP], q[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) {
+        const int o = chunk * EP + e;
+        w0[e] = W[o * 3 + 0]; w1[e] = W[o * 3 + 1]; w2[e] = W[o * 3 + 2]; bb[e] = bias[o];
+        s[e] = 0.f; q[e] = 0.f;
+    }
+    const float* ib = img + (size_t)b * 3 * HW;
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
+        const int p = p0 + slot;
+        if (slot < ppi && p < HW) {
+            const float r = ib[p], g = ib[HW + p], bl = ib[2 * HW + p];
+            float f[EP];
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                float v = r * w0[e] + g * w1[e] + bl * w2[e] + bb[e];
+                v = v > 0.f ? v : 0.2f * v;
+                f[e] = v; s[e] += v; q[e] += v * v;
+            }
+            *(uint4*)(y + ((size_t)b * HW + p) * C + chunk * EP) = pack16(f, (T*)nullptr);
+        }
+    }
+    if (stats) block_stats_flush<EP>(s, q, chunk, cpt, ppi, stats + (size_t)b * C * 2, C, red);
+}
+
+// ------------------------------------------------------------------ stats -> mean/std + IN affine
+// stats [B,C,2] (sum, sumsq) over npix pixels ->
+//   musig [B,2C] = [mean | sqrt(biased var)]          (E.py:51-53, no eps)
+//   sc [B,C] = rsqrt(var + eps), sh = -mean*sc         (InstanceNorm2d eps=1e-8, E.py:57)
+__global__ void stats_finalize_kernel(const float* __restrict__ stats, float* __restrict__ musig, float* __restrict__ sc,
+                                      float* __restrict__ sh, int B, int C, float inv_n, float eps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx % C;
+    const float m = stats[(size_t)idx * 2] * inv_n;
+    float v = stats[(size_t)idx * 2 + 1] * inv_n - m * m;
+    v = v > 0.f ? v : 0.f;
+    musig[(size_t)b * 2 * C + c] = m;
+    musig[(size_t)b * 2 * C + C + c] = sqrtf(v);
+    const float r = rsqrtf(v + eps);
+    sc[idx] = r; sh[idx] = -m * r;
+}
+
+// ------------------------------------------------------------------ pooling / blends
+// mode 0: y = alpha * f(x)                 + beta * z     (same resolution)
+// mode 1: y = alpha * avgpool2(f(x))       + beta * z     (y, z at half resolution)
+// f(x) = x*sc[b,c] + sh[b,c] when sc != null (instance-norm apply), else identity.
+// Optional per-(b,c) statistics of y.
+template <typename T>
+__global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y,
+                                                     const float* __restrict__ sc, const float* __restrict__ sh,
+                                                     float* __restrict__ stats, int OH, int OW, int C, int pool,
+                                                     float alpha, float beta) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * 2 * EP];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    const int OHW = OH * OW, IW = pool ? 2 * OW : OW, IHW = pool ? 4 * OHW : OHW;
+    float s[EP], q[EP], a[EP], d[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) {
+        s[e] = 0.f; q[e] = 0.f;
+        a[e] = sc ? sc[(size_t)b * C + chunk * EP + e] : 1.f;
+        d[e] = sh ? sh[(size_t)b * C + chunk * EP + e] : 0.f;
+    }
+    const T* xb = x + (size_t)b * IHW * C;
+    for (int p0 = blockIdx.x * ppi; p0 < OHW; p0 += gridDim.x * ppi) {
+        const int p = p0 + slot;
+        if (slot < ppi && p < OHW) {
+            float f[EP];
+            if (pool) {
+                const int oy = p / OW, ox = p % OW;
+                const T* base = xb + ((size_t)(2 * oy) * IW + 2 * ox) * C + chunk * EP;
+                float f0[EP], f1[EP], f2[EP], f3[EP];
+                unpack16(*(const uint4*)base, f0, (T*)nullptr);
+                unpack16(*(const uint4*)(base + C), f1, (T*)nullptr);
+                unpack16(*(const uint4*)(base + (size_t)IW * C), f2, (T*)nullptr);
+                unpack16(*(const uint4*)(base + (size_t)IW * C + C), f3, (T*)nullptr);
+#pragma unroll
+                for (int e = 0; e < EP; e++) f[e] = 0.25f * (f0[e] + f1[e] + f2[e] + f3[e]);
+            } else {
+                unpack16(*(const uint4*)(xb + (size_t)p * C + chunk * EP), f, (T*)nullptr);
+            }
+#pragma unroll
+            for (int e = 0; e < EP; e++) f[e] = alpha * (f[e] * a[e] + d[e]);
+            if (z) {
+                float g[EP];
+                unpack16(*(const uint4*)(z + ((size_t)b * OHW + p) * C + chunk * EP), g, (T*)nullptr);
+#pragma unroll
+                for (int e = 0; e < EP; e++) f[e] += beta * g[e];
+            }
+#pragma unroll
+            for (int e = 0; e < EP; e++) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            *(uint4*)(y + ((size_t)b * OHW + p) * C + chunk * EP) = pack16(f, (T*)nullptr);
+        }
+    }
+    if (stats) block_stats_flush<EP>(s, q, chunk, cpt, ppi, stats + (size_t)b * C * 2, C, red);
+}
+
+// =================================================================== C ABI
+static int grid_for(int hw, int ppi) {
+    int g = (hw + ppi - 1) / ppi;
+    return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+}
+
+extern "C" int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, float* stats, int B, int HW,
+                           int C, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "fromrgb: unsupported channel count %d", C);
+    const int ppi = 256 / (C / ep);
+    dim3 grid(grid_for(HW, ppi), B);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_kernel<bf16_t>, grid, dim3(256), 0, s, img, w, bias, (bf16_t*)y, stats, HW, C);
+    else hipLaunchKernelGGL(fromrgb_kernel<float>, grid, dim3(256), 0, s, img, w, bias, (float*)y, stats, HW, C);
+    DGE_LAUNCH_CHECK("fromrgb");
+    return 0;
+}
+
+extern "C" int dge_stats_finalize(const float* stats, float* musig, float* sc, float* sh, int B, int C, int npix, float eps,
+                                  hipStream_t s) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, stats, musig, sc, sh, B, C,
+                       1.0f / (float)npix, eps);
+    DGE_LAUNCH_CHECK("stats_finalize");
+    return 0;
+}
+
+extern "C" int dge_blend(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B,
+                         int OH, int OW, int C, int pool, float alpha, float beta, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "blend: unsupported channel count %d", C);
+    const int ppi = 256 / (C / ep);
+    dim3 grid(grid_for(OH * OW, ppi), B);
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(blend_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)z, (bf16_t*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta);
+    else
+        hipLaunchKernelGGL(blend_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)z, (float*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta);
+    DGE_LAUNCH_CHECK("blend");
+    return 0;
+}

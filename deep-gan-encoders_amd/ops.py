@@ -143,3 +143,32 @@ def nhwc_to_nchw(src):
     dst = torch.empty((B, Cc, H, W), dtype=torch.float32, device=src.device)
     check(lib().dge_nhwc_to_nchw(_p(src), _p(dst), B, Cc, H * W, dtype_of(src), _stream()), "dge_nhwc_to_nchw")
     return dst
+
+
+# ------------------------------------------------------------------ encoder streaming ops
+def fromrgb(img, w, bias, dtype, stats=None):
+    B, _, H, W = img.shape
+    Cc = w.shape[0]
+    y = torch.empty((B, H, W, Cc), dtype=tdtype(dtype), device=img.device)
+    check(lib().dge_fromrgb(_f32(img.contiguous()), _f32(w.reshape(Cc, 3)), _f32(bias), _p(y), _f32(stats), B, H * W, Cc,
+                            dtype, _stream()), "dge_fromrgb")
+    return y
+
+
+def stats_finalize(stats, npix, eps=1e-8):
+    B, Cc, _ = stats.shape
+    musig = torch.empty((B, 2 * Cc), dtype=torch.float32, device=stats.device)
+    sc = torch.empty((B, Cc), dtype=torch.float32, device=stats.device)
+    sh = torch.empty((B, Cc), dtype=torch.float32, device=stats.device)
+    check(lib().dge_stats_finalize(_f32(stats), _p(musig), _p(sc), _p(sh), B, Cc, int(npix), float(eps), _stream()),
+          "dge_stats_finalize")
+    return musig, sc, sh
+
+
+def blend(x, z=None, sc=None, sh=None, pool=False, alpha=1.0, beta=0.0, stats=None):
+    B, H, W, Cc = x.shape
+    OH, OW = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, OH, OW, Cc), dtype=x.dtype, device=x.device)
+    check(lib().dge_blend(_p(x), _p(z), _p(y), _f32(sc), _f32(sh), _f32(stats), B, OH, OW, Cc, 1 if pool else 0,
+                          float(alpha), float(beta), dtype_of(x), _stream()), "dge_blend")
+    return y

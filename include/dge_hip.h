@@ -96,6 +96,20 @@ int dge_torgb(const void* x, const float* wrgb, const float* style, const float*
 int dge_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int src_B, int dtype, dge_stream_t stream);
 int dge_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtype, dge_stream_t stream);
 
+/* ---- encoder E.BE (model/E/E.py) streaming kernels ---------------------------------------- */
+/* FromRGB: 1x1 conv 3->C + bias + leaky_relu(0.2), model/utils/net.py:231-240.  img NCHW f32,
+ * w [C][3], y NHWC dtype; optional per-(b,c) (sum, sumsq) of y into stats [B,C,2] (pre-zeroed). */
+int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, float* stats, int B, int HW, int C,
+                int dtype, dge_stream_t stream);
+/* (sum, sumsq) -> musig [B,2C] = [mean | biased std] (E.py:51-53,64-66) and the instance-norm
+ * affine sc = rsqrt(var+eps), sh = -mean*sc (nn.InstanceNorm2d eps=1e-8, E.py:57,68). */
+int dge_stats_finalize(const float* stats, float* musig, float* sc, float* sh, int B, int C, int npix, float eps,
+                       dge_stream_t stream);
+/* y = alpha * P(x*sc+sh) + beta * z with P = identity (pool=0) or avg_pool2d(2) (pool=1; y,z at
+ * OHxOW, x at 2OHx2OW); sc/sh/z/stats optional.  E.py:75-78,84 (downscale2d, residual blend). */
+int dge_blend(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B, int OH,
+              int OW, int C, int pool, float alpha, float beta, int dtype, dge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
