@@ -38,6 +38,13 @@ SIGNATURES = {
     "dge_fromrgb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dge_stats_finalize": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "dge_blend": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "dge_loss_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dge_crop_pool": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dge_ssim_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dge_ssim_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "dge_space_loss_finalize": [_P, _P, _P, _P, _F, _F, _I, _P],
+    "dge_space_loss_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "dge_axpy_scalar": [_P, _P, _P, C.c_long, _F, _I, _P],
     "dge_version": [],
 }
 

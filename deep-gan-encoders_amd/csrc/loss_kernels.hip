@@ -1,0 +1,250 @@
+// space_loss (reference training_utils.py:54-99) and SSIM (metric/pytorch_ssim.py:18-38) kernels:
+// single-pass fused reductions (MSE / cosine / mean / std / KL), crop + average pooling,
+// 11x11 Gaussian SSIM forward + analytic backward, and the fused image-space gradient.
+// Images are NCHW f32 like the reference's tensors; all kernels are HBM/L2-bound streaming.
+#include "common.h"
+#include "../../include/dge_hip.h"
+
+struct Crop { int H, W, y0, x0, h, w; };     // source plane H x W, window [y0,y0+h) x [x0,x0+w)
+
+__device__ __forceinline__ void block_atomic_sums(float* vals, int n, float* out, float* red) {
+    // vals: per-thread partials (n <= 8); red: [n][4] floats of LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = 0; i < n; i++) {
+        const float s = wave_sum(vals[i]);
+        if (lane == 0) red[i * 4 + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < n) atomicAdd(out + threadIdx.x, red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+}
+
+// sums[0]=sum (a-b)^2, [1]=a.b, [2]=a.a, [3]=b.b, [4]=sum a, [5]=sum b, [6]=sum softmax_c(a)*(log softmax_c(a) - log softmax_c(b))
+// a,b: [B,C,H,W] planes with a crop window; softmax is over the C axis (training_utils.py:67: implicit dim = 1
+// for 4-D inputs; the 3-D latent case is passed as B'=1, C'=B so that the implicit dim 0 is reproduced).
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ sums, int B, int C, Crop cr) {
+    __shared__ float red[7 * 4];
+    float v[7] = {0, 0, 0, 0, 0, 0, 0};
+    const long npix = (long)B * cr.h * cr.w;
+    const size_t plane = (size_t)cr.H * cr.W;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < npix; idx += gridDim.x * 256L) {
+        const int x = idx % cr.w; const long r = idx / cr.w; const int y = r % cr.h; const int bb = r / cr.h;
+        const size_t off = (size_t)bb * C * plane + (size_t)(cr.y0 + y) * cr.W + cr.x0 + x;
+        float ma = -INFINITY, mb = -INFINITY;
+        for (int c = 0; c < C; c++) {
+            const float av = a[off + c * plane], bv = b[off + c * plane];
+            const float d = av - bv;
+            v[0] += d * d; v[1] += av * bv; v[2] += av * av; v[3] += bv * bv; v[4] += av; v[5] += bv;
+            ma = fmaxf(ma, av); mb = fmaxf(mb, bv);
+        }
+        float sa = 0.f, sb = 0.f;
+        for (int c = 0; c < C; c++) { sa += __expf(a[off + c * plane] - ma); sb += __expf(b[off + c * plane] - mb); }
+        const float lsa = __logf(sa) + ma, lsb = __logf(sb) + mb;
+        for (int c = 0; c < C; c++) {
+            const float la = a[off + c * plane] - lsa, lb = b[off + c * plane] - lsb;
+            v[6] += __expf(la) * (la - lb);
+        }
+    }
+    block_atomic_sums(v, 7, sums, red);
+}
+
+// out[b,c,y,x] = mean over k x k of src[b,c,y0+ky.., x0+kx..]   (crop + repeated avg_pool2d(2), :81-84)
+__global__ void crop_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, int BC, Crop cr, int k) {
+    const int oh = cr.h / k, ow = cr.w / k;
+    const long n = (long)BC * oh * ow;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n) return;
+    const int x = idx % ow; const long r = idx / ow; const int y = r % oh; const int bc = r / oh;
+    const float* p = src + (size_t)bc * cr.H * cr.W + (size_t)(cr.y0 + y * k) * cr.W + cr.x0 + x * k;
+    float s = 0.f;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) s += p[(size_t)i * cr.W + j];
+    dst[idx] = s / (float)(k * k);
+}
+
+struct Gauss11 { float g[11]; };
+
+// SSIM forward on [BC, h, w] planes: ssim_sum += sum of the SSIM map; optional derivative maps
+// dmap[0] = dS/dmu2, dmap[1] = dS/dE[b^2], dmap[2] = dS/dE[ab]  (each [BC,h,w]) for the backward.
+__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ ssim_sum, float* __restrict__ dmap,
+                                                        int BC, int h, int w, Gauss11 G) {
+    __shared__ float ta[26][27], tb[26][27];
+    __shared__ float red[4];
+    const int bc = blockIdx.z, x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
+    const float* pa = a + (size_t)bc * h * w; const float* pb = b + (size_t)bc * h * w;
+    for (int i = threadIdx.x; i < 26 * 26; i += 256) {
+        const int ty = i / 26, tx = i % 26, gy = y0 + ty - 5, gx = x0 + tx - 5;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        ta[ty][tx] = in ? pa[(size_t)gy * w + gx] : 0.f;
+        tb[ty][tx] = in ? pb[(size_t)gy * w + gx] : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % 16, ly = threadIdx.x / 16, gx = x0 + lx, gy = y0 + ly;
+    float S = 0.f;
+    if (gx < w && gy < h) {
+        float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+        for (int i = 0; i < 11; i++)
+            for (int j = 0; j < 11; j++) {
+                const float wgt = G.g[i] * G.g[j];
+                const float av = ta[ly + i][lx + j], bv = tb[ly + i][lx + j];
+                mu1 += wgt * av; mu2 += wgt * bv; e11 += wgt * av * av; e22 += wgt * bv * bv; e12 += wgt * av * bv;
+            }
+        const float C1 = 1e-4f, C2 = 9e-4f;
+        const float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+        const float A1 = 2 * mu1 * mu2 + C1, A2 = 2 * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+        const float inv = 1.f / (B1 * B2);
+        S = A1 * A2 * inv;
+        if (dmap) {
+            const size_t n = (size_t)BC * h * w, o = (size_t)bc * h * w + (size_t)gy * w + gx;
+            dmap[o] = (2 * mu1 * A2 - 2 * mu1 * A1) * inv - S * (2 * mu2 / B1 - 2 * mu2 / B2);
+            dmap[n + o] = -S / B2;
+            dmap[2 * n + o] = 2 * A1 * inv;
+        }
+    }
+    S = wave_sum(S);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = S;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(ssim_sum, red[0] + red[1] + red[2] + red[3]);
+}
+
+// g[q] = scale * ( G*(dmu2) + 2 b[q] G*(dE22) + a[q] G*(dE12) )[q]      (loss = 1 - mean(S): scale = -1/N)
+__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ dmap, float* __restrict__ g,
+                                                        int BC, int h, int w, Gauss11 G, float scale, int accumulate) {
+    __shared__ float t0[26][27], t1[26][27], t2[26][27];
+    const int bc = blockIdx.z, x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;
+    const size_t n = (size_t)BC * h * w, po = (size_t)bc * h * w;
+    for (int i = threadIdx.x; i < 26 * 26; i += 256) {
+        const int ty = i / 26, tx = i % 26, gy = y0 + ty - 5, gx = x0 + tx - 5;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;
+        const size_t o = po + (size_t)gy * w + gx;
+        t0[ty][tx] = in ? dmap[o] : 0.f; t1[ty][tx] = in ? dmap[n + o] : 0.f; t2[ty][tx] = in ? dmap[2 * n + o] : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % 16, ly = threadIdx.x / 16, gx = x0 + lx, gy = y0 + ly;
+    if (gx >= w || gy >= h) return;
+    float f0 = 0, f1 = 0, f2 = 0;
+    for (int i = 0; i < 11; i++)
+        for (int j = 0; j < 11; j++) {
+            const float wgt = G.g[i] * G.g[j];
+            f0 += wgt * t0[ly + i][lx + j]; f1 += wgt * t1[ly + i][lx + j]; f2 += wgt * t2[ly + i][lx + j];
+        }
+    const size_t o = po + (size_t)gy * w + gx;
+    const float v = scale * (f0 + 2.f * b[o] * f1 + a[o] * f2);
+    g[o] = accumulate ? g[o] + v : v;
+}
+
+// loss/info on device.  sums (loss_reduce), ssim_sum, lpips (mean over batch, may be null).
+// out[0] = 5*mse + 3*cos + ssim_l + 2*lpips (:97); out[1..7] = mse, mse_mean, mse_std, kl, cos, ssim_l, lpips
+__global__ void space_loss_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ ssim_sum,
+                                           const float* __restrict__ lpips, float* __restrict__ out, float n, float n_pooled,
+                                           int image_space) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float mse = sums[0] / n;
+    const float cosv = 1.f - sums[1] / (sqrtf(sums[2]) * sqrtf(sums[3]));
+    const float ma = sums[4] / n, mb = sums[5] / n;
+    const float va = fmaxf((sums[2] - n * ma * ma) / (n - 1.f), 0.f), vb = fmaxf((sums[3] - n * mb * mb) / (n - 1.f), 0.f);
+    const float dm = ma - mb, ds = sqrtf(va) - sqrtf(vb);
+    float kl = sums[6] / n;
+    if (isnan(kl)) kl = 0.f;
+    if (isinf(kl)) kl = 1.f;
+    const float ssim_l = image_space ? 1.f - ssim_sum[0] / n_pooled : 0.f;
+    const float lp = (image_space && lpips) ? lpips[0] : 0.f;
+    out[0] = 5.f * mse + 3.f * cosv + ssim_l + 2.f * lp;
+    out[1] = mse; out[2] = dm * dm; out[3] = ds * ds; out[4] = kl; out[5] = cosv; out[6] = ssim_l; out[7] = lp;
+}
+
+// d(5*mse + 3*cos)/db at full resolution + un-pooled gradient of the pooled terms:
+// g[b,c,y0+y,x0+x] (+)= wgt * ( 10 (b-a)/n + 3 (-a/(|a||b|) + (a.b) b/(|a||b|^3)) + gp[b,c,y/k,x/k]/k^2 )
+__global__ void space_loss_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                      const float* __restrict__ sums, const float* __restrict__ gp, float* __restrict__ g,
+                                      int BC, Crop cr, int k, float n, float wgt, int accumulate) {
+    const long tot = (long)BC * cr.h * cr.w;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= tot) return;
+    const int x = idx % cr.w; const long r = idx / cr.w; const int y = r % cr.h; const int bc = r / cr.h;
+    const size_t off = (size_t)bc * cr.H * cr.W + (size_t)(cr.y0 + y) * cr.W + cr.x0 + x;
+    const float na = sqrtf(sums[2]), nb = sqrtf(sums[3]);
+    const float av = a[off], bv = b[off];
+    float v = 10.f * (bv - av) / n + 3.f * (-av / (na * nb) + sums[1] * bv / (na * nb * nb * nb));
+    if (gp) {
+        const int oh = cr.h / k, ow = cr.w / k;
+        if (y / k < oh && x / k < ow) v += gp[((size_t)bc * oh + y / k) * ow + x / k] / (float)(k * k);
+    }
+    v *= wgt;
+    g[off] = accumulate ? g[off] + v : v;
+}
+
+// y = (accumulate ? y : 0) + x * scalar[0]      (chain-rule scaling by a device scalar)
+__global__ void axpy_scalar_kernel(const float* __restrict__ x, const float* __restrict__ scalar, float* __restrict__ y,
+                                   long n, float extra, int accumulate) {
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n) return;
+    const float v = x[idx] * (scalar ? scalar[0] : 1.f) * extra;
+    y[idx] = accumulate ? y[idx] + v : v;
+}
+
+// =================================================================== C ABI
+static Gauss11 gauss11() {
+    Gauss11 G; float s = 0.f;
+    for (int i = 0; i < 11; i++) { G.g[i] = expf(-(float)((i - 5) * (i - 5)) / (2.f * 1.5f * 1.5f)); s += G.g[i]; }
+    for (int i = 0; i < 11; i++) G.g[i] /= s;
+    return G;
+}
+static Crop mk(int H, int W, int y0, int x0, int h, int w) { Crop c = {H, W, y0, x0, h, w}; return c; }
+
+extern "C" int dge_loss_reduce(const float* a, const float* b, float* sums7, int B, int C, int H, int W, int y0, int x0,
+                               int h, int w, hipStream_t s) {
+    DGE_CHECK(y0 >= 0 && x0 >= 0 && y0 + h <= H && x0 + w <= W && h > 0 && w > 0, "loss_reduce: bad crop");
+    long npix = (long)B * h * w;
+    int grid = (int)((npix + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, s, a, b, sums7, B, C, mk(H, W, y0, x0, h, w));
+    DGE_LAUNCH_CHECK("loss_reduce");
+    return 0;
+}
+
+extern "C" int dge_crop_pool(const float* src, float* dst, int BC, int H, int W, int y0, int x0, int h, int w, int k,
+                             hipStream_t s) {
+    DGE_CHECK(k >= 1 && h % k == 0 && w % k == 0, "crop_pool: %dx%d not divisible by %d", h, w, k);
+    const long n = (long)BC * (h / k) * (w / k);
+    hipLaunchKernelGGL(crop_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, BC, mk(H, W, y0, x0, h, w), k);
+    DGE_LAUNCH_CHECK("crop_pool");
+    return 0;
+}
+
+extern "C" int dge_ssim_fwd(const float* a, const float* b, float* ssim_sum, float* dmap, int BC, int h, int w, hipStream_t s) {
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((w + 15) / 16, (h + 15) / 16, BC), dim3(256), 0, s, a, b, ssim_sum, dmap, BC, h, w, gauss11());
+    DGE_LAUNCH_CHECK("ssim_fwd");
+    return 0;
+}
+
+extern "C" int dge_ssim_bwd(const float* a, const float* b, const float* dmap, float* g, int BC, int h, int w, float scale,
+                            int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((w + 15) / 16, (h + 15) / 16, BC), dim3(256), 0, s, a, b, dmap, g, BC, h, w, gauss11(), scale, accumulate);
+    DGE_LAUNCH_CHECK("ssim_bwd");
+    return 0;
+}
+
+extern "C" int dge_space_loss_finalize(const float* sums7, const float* ssim_sum, const float* lpips, float* out8, float n,
+                                       float n_pooled, int image_space, hipStream_t s) {
+    hipLaunchKernelGGL(space_loss_finalize_kernel, dim3(1), dim3(64), 0, s, sums7, ssim_sum, lpips, out8, n, n_pooled, image_space);
+    DGE_LAUNCH_CHECK("space_loss_finalize");
+    return 0;
+}
+
+extern "C" int dge_space_loss_bwd(const float* a, const float* b, const float* sums7, const float* g_pooled, float* g,
+                                  int BC, int H, int W, int y0, int x0, int h, int w, int k, float n, float weight,
+                                  int accumulate, hipStream_t s) {
+    const long tot = (long)BC * h * w;
+    hipLaunchKernelGGL(space_loss_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, b, sums7, g_pooled, g, BC,
+                       mk(H, W, y0, x0, h, w), k, n, weight, accumulate);
+    DGE_LAUNCH_CHECK("space_loss_bwd");
+    return 0;
+}
+
+extern "C" int dge_axpy_scalar(const float* x, const float* scalar, float* y, long n, float extra, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(axpy_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, scalar, y, n, extra, accumulate);
+    DGE_LAUNCH_CHECK("axpy_scalar");
+    return 0;
+}

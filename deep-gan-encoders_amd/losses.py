@@ -1,0 +1,118 @@
+"""space_loss (reference training_utils.py:54-99) and the three-scale image loss of
+E_align_s2.py:185-203 on the HIP kernels, as autograd Functions whose forward also produces the
+analytic gradient w.r.t. the second argument (the only one that carries grad in E_align)."""
+import torch
+
+from . import ops
+from ._lib import lib, check
+from .ops import _f32, _p, _stream
+
+
+def _pool_factor(h):
+    k = 1
+    while h > 256:          # training_utils.py:81 tests shape[2] only
+        h //= 2
+        k *= 2
+    return k
+
+
+def attention_windows(H, W):
+    """(y0, x0, h, w) of the full image, AT1 and AT2 (E_align_s2.py:188-199)."""
+    oy, ox = H // 8 + H // 32, W // 8 + W // 32
+    return [(0, 0, H, W), (0, W // 8, H, W - 2 * (W // 8)), (oy, ox, H - 2 * oy, W - 2 * ox)]
+
+
+def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accumulate):
+    """One space_loss evaluation on a window of a,b [B,C,H,W].  Returns out8 (device) and, when
+    g_out is given, adds weight * dloss/db into it."""
+    B, Cc, H, W = a.shape
+    y0, x0, h, w = win
+    dev = a.device
+    L = lib()
+    sums = torch.zeros(8, dtype=torch.float32, device=dev)
+    check(L.dge_loss_reduce(_f32(a), _f32(b), _p(sums), B, Cc, H, W, y0, x0, h, w, _stream()), "dge_loss_reduce")
+    n = float(B * Cc * h * w)
+    out8 = torch.empty(8, dtype=torch.float32, device=dev)
+    gp, k, npool = None, 1, 1.0
+    ssum = lp = None
+    if image_space:
+        k = _pool_factor(h)
+        hp, wp = h // k, w // k
+        ap = torch.empty((B, Cc, hp, wp), dtype=torch.float32, device=dev)
+        bp = torch.empty_like(ap)
+        check(L.dge_crop_pool(_f32(a), _p(ap), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
+        check(L.dge_crop_pool(_f32(b), _p(bp), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
+        npool = float(B * Cc * hp * wp)
+        ssum = torch.zeros(1, dtype=torch.float32, device=dev)
+        dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if g_out is not None else None
+        check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(ssum), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
+        if g_out is not None:
+            gp = torch.empty_like(bp)
+            check(L.dge_ssim_bwd(_p(ap), _p(bp), _p(dmap), _p(gp), B * Cc, hp, wp, -1.0 / npool, 0, _stream()), "dge_ssim_bwd")
+        if lpips_model is not None:
+            lp, g_lp = lpips_model.value_and_grad(ap, bp, need_grad=g_out is not None)   # mean over batch, d/dbp
+            if g_out is not None:
+                check(L.dge_axpy_scalar(_p(g_lp), None, _p(gp), gp.numel(), 2.0, 1, _stream()), "dge_axpy_scalar")
+    check(L.dge_space_loss_finalize(_p(sums), _p(ssum), _p(lp), _p(out8), n, npool, 1 if image_space else 0, _stream()),
+          "dge_space_loss_finalize")
+    if g_out is not None:
+        check(L.dge_space_loss_bwd(_f32(a), _f32(b), _p(sums), _p(gp), _p(g_out), B * Cc, H, W, y0, x0, h, w, k, n,
+                                   float(weight), 1 if accumulate else 0, _stream()), "dge_space_loss_bwd")
+    return out8
+
+
+class _ScaledGrad(torch.autograd.Function):
+    """loss tensor whose gradient w.r.t. `b` was computed analytically in the forward."""
+
+    @staticmethod
+    def forward(ctx, b, loss, g):
+        ctx.save_for_backward(g)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        (g,) = ctx.saved_tensors
+        out = torch.empty_like(g)
+        check(lib().dge_axpy_scalar(_p(g), _p(go.contiguous().float()), _p(out), g.numel(), 1.0, 0, _stream()), "dge_axpy_scalar")
+        return out, None, None
+
+
+def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0)):
+    """loss_tsa = loss_imgs + 5*loss_medium + 9*loss_small (E_align_s2.py:185-203).
+    Returns (loss [] on device, info [3,8] on device: rows full/AT1/AT2, columns
+    loss, mse, mse_mean, mse_std, kl, cos, ssim, lpips).  No host synchronisation."""
+    a = imgs1.detach().float().contiguous()
+    b = imgs2.detach().float().contiguous()
+    need = imgs2.requires_grad and torch.is_grad_enabled()
+    g = torch.zeros_like(b) if need else None
+    infos = []
+    for i, win in enumerate(attention_windows(a.shape[2], a.shape[3])):
+        infos.append(_space_loss_window(a, b, win, True, lpips_model, weights[i], g, accumulate=True))
+    info = torch.stack(infos)
+    wv = torch.tensor(weights, dtype=torch.float32, device=a.device)
+    loss = (info[:, 0] * wv).sum()
+    if need:
+        loss = _ScaledGrad.apply(imgs2, loss, g)
+    return loss, info
+
+
+def space_loss(imgs1, imgs2, image_space=True, lpips_model=None):
+    """Drop-in for training_utils.space_loss; returns (loss tensor, info tensor[8] on device)
+    instead of Python floats (the reference's 7 .item() syncs per call are deferred)."""
+    a = imgs1.detach().float().contiguous()
+    b = imgs2.detach().float().contiguous()
+    need = imgs2.requires_grad and torch.is_grad_enabled()
+    g = torch.empty_like(b) if need else None
+    if image_space:
+        B, Cc, H, W = a.shape
+        out8 = _space_loss_window(a, b, (0, 0, H, W), True, lpips_model, 1.0, g, accumulate=False)
+    else:
+        # 3-D latents: the implicit softmax dim is 0 (the batch) -> planes = batch (training_utils.py:67)
+        Bt = a.shape[0]
+        n_in = a.numel() // Bt
+        out8 = _space_loss_window(a.view(1, Bt, 1, n_in), b.view(1, Bt, 1, n_in), (0, 0, 1, n_in), False, None, 1.0,
+                                  g.view(1, Bt, 1, n_in) if need else None, accumulate=False)
+    loss = out8[0]
+    if need:
+        loss = _ScaledGrad.apply(imgs2, loss, g)
+    return loss, out8

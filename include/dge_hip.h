@@ -110,6 +110,27 @@ int dge_stats_finalize(const float* stats, float* musig, float* sc, float* sh, i
 int dge_blend(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B, int OH,
               int OW, int C, int pool, float alpha, float beta, int dtype, dge_stream_t stream);
 
+/* ---- space_loss (training_utils.py:54-99) and SSIM (metric/pytorch_ssim.py:18-38) ---------- */
+/* One pass over a crop window of a,b [B,C,H,W] f32: sums7 (pre-zeroed) += { sum (a-b)^2, a.b, a.a, b.b, sum a, sum b,
+ * sum softmax_C(a)*(log softmax_C(a)-log softmax_C(b)) }  -> mse :63, mean/std terms :64-65, KL :67-71, cosine :73-75. */
+int dge_loss_reduce(const float* a, const float* b, float* sums7, int B, int C, int H, int W, int y0, int x0, int h, int w,
+                    dge_stream_t stream);
+/* crop + k x k mean (the `while H > 256: avg_pool2d(2)` loop of :81-84 collapsed) on BC planes */
+int dge_crop_pool(const float* src, float* dst, int BC, int H, int W, int y0, int x0, int h, int w, int k, dge_stream_t stream);
+/* ssim_sum (pre-zeroed) += sum of the SSIM map of a,b [BC,h,w]; dmap (optional, [3][BC][h][w]) receives dS/dmu2,
+ * dS/dE[b^2], dS/dE[ab] for dge_ssim_bwd, which writes g = scale * dSum/db. */
+int dge_ssim_fwd(const float* a, const float* b, float* ssim_sum, float* dmap, int BC, int h, int w, dge_stream_t stream);
+int dge_ssim_bwd(const float* a, const float* b, const float* dmap, float* g, int BC, int h, int w, float scale,
+                 int accumulate, dge_stream_t stream);
+/* out8 = { 5*mse + 3*cos + (1-ssim) + 2*lpips (:97), mse, mse(mean), mse(std), kl, cos, 1-ssim, lpips } on device */
+int dge_space_loss_finalize(const float* sums7, const float* ssim_sum, const float* lpips, float* out8, float n,
+                            float n_pooled, int image_space, dge_stream_t stream);
+/* g[window] (+)= weight * d(5*mse + 3*cos)/db + weight * unpool_k(g_pooled)   (g_pooled optional) */
+int dge_space_loss_bwd(const float* a, const float* b, const float* sums7, const float* g_pooled, float* g, int BC, int H,
+                       int W, int y0, int x0, int h, int w, int k, float n, float weight, int accumulate, dge_stream_t stream);
+/* y (+)= x * scalar[0] * extra  (scalar may be NULL) */
+int dge_axpy_scalar(const float* x, const float* scalar, float* y, long n, float extra, int accumulate, dge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
