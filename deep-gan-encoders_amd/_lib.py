@@ -12,11 +12,11 @@ class DgeError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [
-        ("x", C.c_void_p), ("w_packed", C.c_void_p), ("y", C.c_void_p), ("addend", C.c_void_p),
+        ("x", C.c_void_p), ("w_packed", C.c_void_p), ("y", C.c_void_p), ("addend", C.c_void_p), ("dot_src", C.c_void_p),
         ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("out_scale", C.c_void_p),
         ("bias", C.c_void_p), ("noise", C.c_void_p), ("noise_w", C.c_void_p), ("stats", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
-        ("ksize", C.c_int), ("up", C.c_int), ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int),
+        ("ksize", C.c_int), ("up", C.c_int), ("in_s2d", C.c_int), ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int),
         ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float), ("add_scale", C.c_float),
         ("dtype", C.c_int),
     ]
@@ -45,6 +45,12 @@ SIGNATURES = {
     "dge_space_loss_finalize": [_P, _P, _P, _P, _F, _F, _I, _P],
     "dge_space_loss_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_axpy_scalar": [_P, _P, _P, C.c_long, _F, _I, _P],
+    "dge_lreq_adam_multi": [_I, _P, _P, _P, _P, _P, _F, _F, _P, _P],
+    "dge_modconv_bwd_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "dge_demod_bwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "dge_linear_t": [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dge_torgb_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "dge_up2_bwd": [_P, _P, _I, _I, _I, _P],
     "dge_version": [],
 }
 

@@ -92,7 +92,7 @@ def encoder_forward(E, img, noises=None, save=False):
 class EncoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, E, img, noises, *params):
-        need = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        need = any(ctx.needs_input_grad[3:])
         xo, w, saved = encoder_forward(E, img.detach(), noises, save=need)
         ctx.E, ctx.saved_acts = E, saved
         ctx.mark_non_differentiable(xo)

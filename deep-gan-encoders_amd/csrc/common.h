@@ -63,6 +63,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Per-channel block reduction for NHWC streaming kernels.  Thread t owns channel chunk (t % cpt)
+// (EP channels) of pixel slot (t / cpt); each thread holds NS partial sums per channel.  The
+// sums of all pixel slots are combined in LDS and added atomically to out[c*NS + k].
+// `red` must hold 256*NS*EP floats; all 256 threads must call.
+template <int EP, int NS>
+__device__ __forceinline__ void block_chan_flush(float (&s)[NS][EP], int cpt, int ppi, float* __restrict__ out_b, int C,
+                                                 float* red) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < EP; e++) red[tid * NS * EP + k * EP + e] = s[k][e];
+    __syncthreads();
+    for (int item = tid; item < cpt * NS * EP; item += 256) {
+        const int ch = item / (NS * EP), r = item % (NS * EP);
+        float a = 0.f;
+        for (int j = 0; j < ppi; j++) a += red[(j * cpt + ch) * NS * EP + r];
+        const int c = ch * EP + (r % EP);
+        if (c < C) atomicAdd(out_b + (size_t)c * NS + (r / EP), a);
+    }
+    __syncthreads();
+}
+
 // error plumbing shared by the C ABI translation units
 void dge_set_error(const char* fmt, ...);
 #define DGE_CHECK(cond, ...) do { if (!(cond)) { dge_set_error(__VA_ARGS__); return -1; } } while (0)

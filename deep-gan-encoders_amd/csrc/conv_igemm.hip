@@ -151,6 +151,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    if (p.in_s2d) {       // logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid
+                        const int cphys = p.Cin >> 2, ph = cbase / cphys, cb = cbase - ph * cphys;
+                        v = *(const uint4*)(X + ((size_t)(b * 2 * p.H + 2 * gy + (ph >> 1)) * (2 * p.W) + 2 * gx + (ph & 1)) * cphys + cb + c * EP16);
+                    } else
                     v = *(const uint4*)(X + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cin + cbase + c * EP16);
                     if (affine) {
                         float f[EP16];
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const int OH = p.up ? 2 * p.H : p.H, OW = p.up ? 2 * p.W : p.W;
     T* __restrict__ Y = (T*)p.y;
     const T* __restrict__ ADD = (const T*)p.addend;
+    const T* __restrict__ DOT = (const T*)p.dot_src;
     constexpr int CPR = 32 / EP16;              // 16-byte chunks per 32-channel row
     constexpr int PPP = 64 / CPR;               // pixels per read-back pass
 #pragma unroll
@@ -216,13 +221,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 const int gy = y0 + m / TW, gx = x0 + m % TW;
                 const bool pvalid = gy < p.H && gx < p.W;
                 const int oy = p.up ? 2 * gy + py : gy, ox = p.up ? 2 * gx + px : gx;
+                if (DOT) {            // reductions of the raw accumulator (data-gradient statistics)
+                    if (pvalid && ovalid) {
+                        const float dv = Elem<T>::ld(DOT + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o);
+                        ssum += acc[i][j][r] * dv; ssq += acc[i][j][r];
+                    }
+                }
                 float v = acc[i][j][r] * osc;
                 if (p.noise && pvalid) v += nw * p.noise[(size_t)b * p.noise_bstride + (size_t)oy * OW + ox];
                 v += bia;
                 v = act_apply(v, p.act) * p.gain;
                 if (ADD && pvalid && ovalid)
                     v += p.add_scale * Elem<T>::ld(ADD + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o);
-                if (pvalid) { ssum += v; ssq += v * v; }
+                if (pvalid && !DOT) { ssum += v; ssq += v * v; }
                 Elem<T>::st((T*)(est + ml * C::ESTR) + (lane & 31), v);
             }
             __builtin_amdgcn_wave_barrier();
@@ -278,7 +289,7 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
     constexpr int E = (int)sizeof(T);
     constexpr int K0 = 128 / E, K1 = 64 / E, K2 = 32 / E;
     const int bn = dge_conv_ntile(p.Ntot);
-    const int kc = kchunk(p.Cin, E);
+    const int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
     const bool small = (p.H <= 8 && p.W <= 8) || ((long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn) < 256L * 256);
 #define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
     if (small) {           // 8x8 pixel tiles: more workgroups for the low-resolution layers

@@ -7,6 +7,7 @@ struct ConvParams {
     const void* w;            // packed [KS*KS][Ntot][Cin] T  (dge_pack_conv_weight)
     void* y;                  // [B,OH,OW,Cout] T   (OH = 2H in up mode)
     const void* addend;       // optional [B,OH,OW,Cout] T, y += add_scale*addend
+    const void* dot_src;      // optional [B,OH,OW,Cout] T: stats = (sum acc*dot_src, sum acc) of the raw accumulator
     const float* in_scale;    // optional [B,Cin]
     const float* in_shift;    // optional [B,Cin]
     const float* out_scale;   // optional [B,Cout]
@@ -18,6 +19,7 @@ struct ConvParams {
     int Ntot;                 // packed N (padded to the N tile); = 4*Cout (+pad) in up mode
     int Ntot_valid;           // unpadded N
     int up;                   // 1: depth-to-space x2 store of the 4 folded phases
+    int in_s2d;               // 1: x is [B,2H,2W,Cin/4], read space-to-depth (adjoint of `up`)
     int noise_bstride;        // 0 (shared noise) or OH*OW
     int noise_w_stride;       // 0 or 1
     int act;

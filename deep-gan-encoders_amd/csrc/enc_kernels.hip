@@ -5,27 +5,6 @@
 #include "common.h"
 #include "../../include/dge_hip.h"
 
-// Per-thread partial (sum, sumsq) for EP channels -> LDS reduce over threads that own the same
-// channel chunk -> atomics into stats[b][c][2].  All 256 threads must call.
-template <int EP>
-__device__ __forceinline__ void block_stats_flush(float (&s)[EP], float (&q)[EP], int chunk, int cpt, int ppi,
-                                                  float* __restrict__ stats_b, int C, float* red) {
-    // red: [256][2*EP] floats
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int e = 0; e < EP; e++) { red[tid * 2 * EP + e] = s[e]; red[tid * 2 * EP + EP + e] = q[e]; }
-    __syncthreads();
-    // thread t < cpt*EP*2 reduces one (chunk, e, kind) over the ppi pixel slots
-    for (int item = tid; item < cpt * 2 * EP; item += 256) {
-        const int ch = item / (2 * EP), k = item % (2 * EP);
-        float a = 0.f;
-        for (int j = 0; j < ppi; j++) a += red[(j * cpt + ch) * 2 * EP + k];
-        const int c = ch * EP + (k % EP);
-        if (c < C) atomicAdd(stats_b + (size_t)c * 2 + (k / EP), a);
-    }
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------ FromRGB
 // y[b,p,o] = lrelu(sum_c img[b,c,p] W[o,c] + bias[o], 0.2)   img NCHW f32 -> y NHWC T, + stats
 template <typename T>
@@ -37,12 +16,12 @@ __global__ __launch_bounds__(256) void fromrgb_kernel(const float* __restrict__ 
     const int b = blockIdx.y;
     const int cpt = C / EP, ppi = 256 / cpt;
     const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
-    float w0[EP], w1[EP], w2[EP], bb[EP], s[EP], q[EP];
+    float w0[EP], w1[EP], w2[EP], bb[EP], sq[2][EP];
 #pragma unroll
     for (int e = 0; e < EP; e++) {
         const int o = chunk * EP + e;
         w0[e] = W[o * 3 + 0]; w1[e] = W[o * 3 + 1]; w2[e] = W[o * 3 + 2]; bb[e] = bias[o];
-        s[e] = 0.f; q[e] = 0.f;
+        sq[0][e] = 0.f; sq[1][e] = 0.f;
     }
     const float* ib = img + (size_t)b * 3 * HW;
     for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
@@ -54,12 +33,12 @@ __global__ __launch_bounds__(256) void fromrgb_kernel(const float* __restrict__ 
             for (int e = 0; e < EP; e++) {
                 float v = r * w0[e] + g * w1[e] + bl * w2[e] + bb[e];
                 v = v > 0.f ? v : 0.2f * v;
-                f[e] = v; s[e] += v; q[e] += v * v;
+                f[e] = v; sq[0][e] += v; sq[1][e] += v * v;
             }
             *(uint4*)(y + ((size_t)b * HW + p) * C + chunk * EP) = pack16(f, (T*)nullptr);
         }
     }
-    if (stats) block_stats_flush<EP>(s, q, chunk, cpt, ppi, stats + (size_t)b * C * 2, C, red);
+    if (stats) block_chan_flush<EP, 2>(sq, cpt, ppi, stats + (size_t)b * C * 2, C, red);
 }
 
 // ------------------------------------------------------------------ stats -> mean/std + IN affine
@@ -96,10 +75,10 @@ __global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ x, con
     const int cpt = C / EP, ppi = 256 / cpt;
     const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
     const int OHW = OH * OW, IW = pool ? 2 * OW : OW, IHW = pool ? 4 * OHW : OHW;
-    float s[EP], q[EP], a[EP], d[EP];
+    float sq[2][EP], a[EP], d[EP];
 #pragma unroll
     for (int e = 0; e < EP; e++) {
-        s[e] = 0.f; q[e] = 0.f;
+        sq[0][e] = 0.f; sq[1][e] = 0.f;
         a[e] = sc ? sc[(size_t)b * C + chunk * EP + e] : 1.f;
         d[e] = sh ? sh[(size_t)b * C + chunk * EP + e] : 0.f;
     }
@@ -130,11 +109,11 @@ __global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ x, con
                 for (int e = 0; e < EP; e++) f[e] += beta * g[e];
             }
 #pragma unroll
-            for (int e = 0; e < EP; e++) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+            for (int e = 0; e < EP; e++) { sq[0][e] += f[e]; sq[1][e] += f[e] * f[e]; }
             *(uint4*)(y + ((size_t)b * OHW + p) * C + chunk * EP) = pack16(f, (T*)nullptr);
         }
     }
-    if (stats) block_stats_flush<EP>(s, q, chunk, cpt, ppi, stats + (size_t)b * C * 2, C, red);
+    if (stats) block_chan_flush<EP, 2>(sq, cpt, ppi, stats + (size_t)b * C * 2, C, red);
 }
 
 // =================================================================== C ABI

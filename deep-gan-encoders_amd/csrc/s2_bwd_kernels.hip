@@ -1,0 +1,180 @@
+// Data-gradient path of the StyleGAN2 synthesis network w.r.t. the latent codes wp
+// (the only gradient the encoder needs: E_align_s2.py:160,204 - G's weights receive no update).
+// The heavy part (conv data gradients) reuses conv_igemm with DGE_PACK_DGRAD /
+// DGE_PACK_UPFOLD_DGRAD weights; the kernels here are the HBM-bound glue around it.
+#include "common.h"
+#include "../../include/dge_hip.h"
+
+// Forward (stylegan2_generator.py:905-921): z = yraw*d + noise*ns + bias ; x = lrelu(z)*gain.
+// Given g_x: g_z = g_x*gain*lrelu'(x) ; g_y = g_z*d[b,c] (gradient w.r.t. yraw, fed to the dgrad conv)
+// R[b,c,:] += { sum g_z*z, sum g_z*noise, sum g_z }   (for the demodulation gradient)
+template <typename T>
+__global__ __launch_bounds__(256) void modconv_bwd_prep_kernel(const T* __restrict__ gx, const T* __restrict__ x,
+                                                                const float* __restrict__ d, const float* __restrict__ noise,
+                                                                T* __restrict__ gy, float* __restrict__ R, int HW, int C,
+                                                                int noise_bstride, float gain) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * 3 * EP];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    float s[3][EP], dd[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) { s[0][e] = s[1][e] = s[2][e] = 0.f; dd[e] = d ? d[(size_t)b * C + chunk * EP + e] : 1.f; }
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
+        const int p = p0 + slot;
+        if (slot < ppi && p < HW) {
+            const size_t o = ((size_t)b * HW + p) * C + chunk * EP;
+            float g[EP], xv[EP];
+            unpack16(*(const uint4*)(gx + o), g, (T*)nullptr);
+            unpack16(*(const uint4*)(x + o), xv, (T*)nullptr);
+            const float nz = noise ? noise[(size_t)b * noise_bstride + p] : 0.f;
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                const bool pos = xv[e] > 0.f;
+                const float gz = g[e] * gain * (pos ? 1.f : 0.2f);
+                const float z = pos ? xv[e] / gain : xv[e] / (0.2f * gain);
+                s[0][e] += gz * z; s[1][e] += gz * nz; s[2][e] += gz;
+                g[e] = gz * dd[e];
+            }
+            *(uint4*)(gy + o) = pack16(g, (T*)nullptr);
+        }
+    }
+    if (R) block_chan_flush<EP, 3>(s, cpt, ppi, R + (size_t)b * C * 3, C, red);
+}
+
+// t[b,o] = -(R0 - ns*R1 - bias[o]*bscale*R2) * d[b,o]^2   (= g_d * dd/du up to the 2 s_i wsq factor)
+__global__ void demod_bwd_kernel(const float* __restrict__ R, const float* __restrict__ d, const float* __restrict__ bias,
+                                 const float* __restrict__ ns, float* __restrict__ t, int B, int C, float bscale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int o = idx % C;
+    const float dv = d[idx];
+    t[idx] = -(R[(size_t)idx * 3] - (ns ? ns[0] : 0.f) * R[(size_t)idx * 3 + 1] - bias[o] * bscale * R[(size_t)idx * 3 + 2]) * dv * dv;
+}
+
+// y[b*ldy + k*incy] (+)= scale * mul[b,k] * sum_o x[b*ldx + o*incx] * W[o,k]
+__global__ void linear_t_kernel(const float* __restrict__ x, int ldx, int incx, const float* __restrict__ W,
+                                const float* __restrict__ mul, float* __restrict__ y, int ldy, int incy, int B, int O, int K,
+                                float scale, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * K) return;
+    const int b = idx / K, k = idx % K;
+    float s = 0.f;
+    for (int o = 0; o < O; o++) s += x[(size_t)b * ldx + (size_t)o * incx] * W[(size_t)o * K + k];
+    s *= scale;
+    if (mul) s *= mul[(size_t)b * K + k];
+    float* yp = y + (size_t)b * ldy + (size_t)k * incy;
+    *yp = accumulate ? *yp + s : s;
+}
+
+// toRGB backward: t_i = wscale * sum_c g[b,c,p] Wrgb[c,i];  gx[b,p,i] = t_i * s[b,i];  gs[b,i] += sum_p t_i x[b,p,i]
+template <typename T>
+__global__ __launch_bounds__(256) void torgb_bwd_kernel(const float* __restrict__ gimg, const T* __restrict__ x,
+                                                         const float* __restrict__ wrgb, const float* __restrict__ sty,
+                                                         T* __restrict__ gx, float* __restrict__ gs, int HW, int C, float wscale) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * EP];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    float w0[EP], w1[EP], w2[EP], sv[EP], s[1][EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) {
+        const int i = chunk * EP + e;
+        w0[e] = wrgb[i] * wscale; w1[e] = wrgb[C + i] * wscale; w2[e] = wrgb[2 * C + i] * wscale;
+        sv[e] = sty[(size_t)b * C + i]; s[0][e] = 0.f;
+    }
+    const float* gb = gimg + (size_t)b * 3 * HW;
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
+        const int p = p0 + slot;
+        if (slot < ppi && p < HW) {
+            const float g0 = gb[p], g1 = gb[HW + p], g2 = gb[2 * HW + p];
+            const size_t o = ((size_t)b * HW + p) * C + chunk * EP;
+            float xv[EP], out[EP];
+            unpack16(*(const uint4*)(x + o), xv, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                const float t = g0 * w0[e] + g1 * w1[e] + g2 * w2[e];
+                s[0][e] += t * xv[e];
+                out[e] = t * sv[e];
+            }
+            *(uint4*)(gx + o) = pack16(out, (T*)nullptr);
+        }
+    }
+    block_chan_flush<EP, 1>(s, cpt, ppi, gs + (size_t)b * C, C, red);
+}
+
+// adjoint of the skip-branch 2x FIR upsample (UpsamplingLayer scale 2, :603-615):
+// gprev[m,n] = sum_{a,b in {-1,0,1,2}} w(a) w(b) g[2m+a, 2n+b],  w = {.25,.75,.75,.25}
+__global__ void up2_bwd_kernel(const float* __restrict__ g, float* __restrict__ gprev, int BC, int h, int w) {
+    const long n = (long)BC * h * w;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n) return;
+    const int x = idx % w; const long r = idx / w; const int y = r % h; const int bc = r / h;
+    const float wt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    const float* gp = g + (size_t)bc * 4 * h * w;
+    const int H2 = 2 * h, W2 = 2 * w;
+    float s = 0.f;
+    for (int a = 0; a < 4; a++) {
+        const int yy = 2 * y + a - 1;
+        if (yy < 0 || yy >= H2) continue;
+        for (int bq = 0; bq < 4; bq++) {
+            const int xx = 2 * x + bq - 1;
+            if (xx < 0 || xx >= W2) continue;
+            s += wt[a] * wt[bq] * gp[(size_t)yy * W2 + xx];
+        }
+    }
+    gprev[idx] = s;
+}
+
+// =================================================================== C ABI
+static int sgrid(int hw, int ppi) { int g = (hw + ppi - 1) / ppi; return g > 1024 ? 1024 : (g < 1 ? 1 : g); }
+
+extern "C" int dge_modconv_bwd_prep(const void* gx, const void* x, const float* d, const float* noise, void* gy, float* R,
+                                    int B, int HW, int C, int noise_batch, float gain, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "modconv_bwd_prep: unsupported channel count %d", C);
+    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    const int nbs = noise_batch > 1 ? HW : 0;
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(modconv_bwd_prep_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gx, (const bf16_t*)x, d, noise, (bf16_t*)gy, R, HW, C, nbs, gain);
+    else
+        hipLaunchKernelGGL(modconv_bwd_prep_kernel<float>, grid, dim3(256), 0, s, (const float*)gx, (const float*)x, d, noise, (float*)gy, R, HW, C, nbs, gain);
+    DGE_LAUNCH_CHECK("modconv_bwd_prep");
+    return 0;
+}
+
+extern "C" int dge_demod_bwd(const float* R, const float* d, const float* bias, const float* noise_strength, float* t, int B,
+                             int C, float bscale, hipStream_t s) {
+    hipLaunchKernelGGL(demod_bwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, R, d, bias, noise_strength, t, B, C, bscale);
+    DGE_LAUNCH_CHECK("demod_bwd");
+    return 0;
+}
+
+extern "C" int dge_linear_t(const float* x, int ldx, int incx, const float* w, const float* mul, float* y, int ldy, int incy,
+                            int B, int O, int K, float scale, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(linear_t_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, x, ldx, incx, w, mul, y, ldy, incy, B, O, K, scale, accumulate);
+    DGE_LAUNCH_CHECK("linear_t");
+    return 0;
+}
+
+extern "C" int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb, const float* style, void* gx, float* gs,
+                             int B, int HW, int C, float wscale, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "torgb_bwd: unsupported channel count %d", C);
+    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(torgb_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, gimg, (const bf16_t*)x, wrgb, style, (bf16_t*)gx, gs, HW, C, wscale);
+    else
+        hipLaunchKernelGGL(torgb_bwd_kernel<float>, grid, dim3(256), 0, s, gimg, (const float*)x, wrgb, style, (float*)gx, gs, HW, C, wscale);
+    DGE_LAUNCH_CHECK("torgb_bwd");
+    return 0;
+}
+
+extern "C" int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, hipStream_t s) {
+    const long n = (long)BC * h * w;
+    hipLaunchKernelGGL(up2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, gprev, BC, h, w);
+    DGE_LAUNCH_CHECK("up2_bwd");
+    return 0;
+}

@@ -12,11 +12,30 @@
 //         (conv_transpose2d stride 2 with the flipped kernel followed by the 4x4 FIR,
 //          stylegan2_generator.py:879-896 + :802-807, folded per output phase)
 // mode 2: data-gradient conv    out[tap][i][o]      = scale * W[o][i][KS*KS-1-tap]   (N = Cin, K = Cout)
+// mode 3: data-gradient of 1    out[tap][i][ph*Cout+o] = mode-1 weight of (ph, 8-tap, o, i)  (N = Cin, K = 4*Cout)
+// folded (transposed conv stride 2, flipped 3x3) * (4x4 FIR) weight of output phase `ph`, input tap (dy,dx)
+__device__ __forceinline__ float upfold_weight(const float* __restrict__ w, int o, int i, int Cin, int ph, int tap) {
+    const int py = ph >> 1, px = ph & 1;
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};      // outer(k1,k1) = FIR/64*4
+    float v = 0.f;
+    for (int ty = 0; ty < 4; ty++) {
+        const int wy = 3 - py - ty + 2 * dy;
+        if (wy < 0 || wy > 2) continue;
+        for (int tx = 0; tx < 4; tx++) {
+            const int wx = 3 - px - tx + 2 * dx;
+            if (wx < 0 || wx > 2) continue;
+            v += k1[ty] * k1[tx] * w[((size_t)o * Cin + i) * 9 + wy * 3 + wx];
+        }
+    }
+    return v;
+}
+
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KS,
                                    int Ntot, int mode, float scale) {
     const int ntap = KS * KS;
-    const int Kdim = (mode == 2) ? Cout : Cin;
+    const int Kdim = (mode == 2) ? Cout : (mode == 3 ? 4 * Cout : Cin);
     const long total = (long)ntap * Ntot * Kdim;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int k = idx % Kdim;
@@ -27,22 +46,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             if (n < Cout) v = w[((size_t)n * Cin + k) * ntap + tap];
         } else if (mode == 2) {
             if (n < Cin) v = w[((size_t)k * Cin + n) * ntap + (ntap - 1 - tap)];
+        } else if (mode == 1) {
+            if (n < 4 * Cout) v = upfold_weight(w, n % Cout, k, Cin, n / Cout, tap);
         } else {
-            if (n < 4 * Cout) {
-                const int ph = n / Cout, o = n % Cout;
-                const int py = ph >> 1, px = ph & 1;
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};      // outer(k1,k1) = FIR/64*4
-                for (int ty = 0; ty < 4; ty++) {
-                    const int wy = 3 - py - ty + 2 * dy;
-                    if (wy < 0 || wy > 2) continue;
-                    for (int tx = 0; tx < 4; tx++) {
-                        const int wx = 3 - px - tx + 2 * dx;
-                        if (wx < 0 || wx > 2) continue;
-                        v += k1[ty] * k1[tx] * w[((size_t)o * Cin + k) * 9 + wy * 3 + wx];
-                    }
-                }
-            }
+            if (n < Cin) v = upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap);
         }
         Elem<T>::st(out + idx, v * scale);
     }
@@ -178,11 +185,11 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
 
 extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
                                     float scale, hipStream_t s) {
-    DGE_CHECK(mode >= 0 && mode <= 2, "pack: bad mode %d", mode);
-    DGE_CHECK(mode != 1 || ksize == 3, "pack: up fold needs a 3x3 kernel");
-    const int nvalid = mode == 1 ? 4 * cout : (mode == 2 ? cin : cout);
+    DGE_CHECK(mode >= 0 && mode <= 3, "pack: bad mode %d", mode);
+    DGE_CHECK((mode != 1 && mode != 3) || ksize == 3, "pack: up fold needs a 3x3 kernel");
+    const int nvalid = mode == 1 ? 4 * cout : (mode >= 2 ? cin : cout);
     const int ntot = dge_packed_n(nvalid);
-    const int kdim = mode == 2 ? cout : cin;
+    const int kdim = mode == 2 ? cout : (mode == 3 ? 4 * cout : cin);
     const long total = (long)ksize * ksize * ntot * kdim;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == DGE_BF16)

@@ -9,7 +9,7 @@ from ._lib import lib, check, ConvDesc, DgeError
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
-PACK_FWD, PACK_UPFOLD, PACK_DGRAD = 0, 1, 2
+PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD = 0, 1, 2, 3
 
 
 def tdtype(dtype):
@@ -51,8 +51,8 @@ def packed_n(n):
 def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
     """w: [Cout,Cin,k,k] f32 (reference layout) -> packed [k*k, Npad, K] tensor of `dtype`."""
     cout, cin, k, _ = w.shape
-    nvalid = 4 * cout if mode == PACK_UPFOLD else (cin if mode == PACK_DGRAD else cout)
-    kdim = cout if mode == PACK_DGRAD else cin
+    nvalid = 4 * cout if mode == PACK_UPFOLD else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD) else cout)
+    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode == PACK_UPFOLD_DGRAD else cin)
     out = torch.empty((k * k, packed_n(nvalid), kdim), dtype=tdtype(dtype), device=w.device)
     check(lib().dge_pack_conv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, k, mode, dtype, float(scale),
                                      _stream()), "dge_pack_conv_weight")
@@ -100,19 +100,21 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None):
+           out=None, in_s2d=False, dot_src=None):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout]."""
     B, H, W, Cin = x.shape
+    if in_s2d:            # x is the fine grid [B,2H,2W,C]; logical input is [B,H,W,4C]
+        H, W, Cin = H // 2, W // 2, Cin * 4
     dt = dtype_of(x)
     OH, OW = (2 * H, 2 * W) if up else (H, W)
     if out is None:
         out = torch.empty((B, OH, OW, cout), dtype=x.dtype, device=x.device)
     d = ConvDesc()
-    d.x, d.w_packed, d.y, d.addend = _p(x), _p(w_packed), _p(out), _p(addend)
+    d.x, d.w_packed, d.y, d.addend, d.dot_src = _p(x), _p(w_packed), _p(out), _p(addend), _p(dot_src)
     d.in_scale, d.in_shift, d.out_scale = _f32(in_scale), _f32(in_shift), _f32(out_scale)
     d.bias, d.noise, d.noise_w, d.stats = _f32(bias), _f32(noise), _f32(noise_w), _f32(stats)
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
-    d.ksize, d.up = ksize, 1 if up else 0
+    d.ksize, d.up, d.in_s2d = ksize, 1 if up else 0, 1 if in_s2d else 0
     d.noise_batch = 1 if noise is None else noise.shape[0]
     d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
     d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt
@@ -172,3 +174,50 @@ def blend(x, z=None, sc=None, sh=None, pool=False, alpha=1.0, beta=0.0, stats=No
     check(lib().dge_blend(_p(x), _p(z), _p(y), _f32(sc), _f32(sh), _f32(stats), B, OH, OW, Cc, 1 if pool else 0,
                           float(alpha), float(beta), dtype_of(x), _stream()), "dge_blend")
     return y
+
+
+# ------------------------------------------------------------------ StyleGAN2 backward ops
+def modconv_bwd_prep(gx, x, d, noise, gain, R=None):
+    B, H, W, Cc = x.shape
+    gy = torch.empty_like(x)
+    check(lib().dge_modconv_bwd_prep(_p(gx), _p(x), _f32(d), _f32(noise), _p(gy), _f32(R), B, H * W, Cc,
+                                     1 if noise is None else noise.shape[0], float(gain), dtype_of(x), _stream()),
+          "dge_modconv_bwd_prep")
+    return gy
+
+
+def demod_bwd(R, d, bias, noise_strength, bscale=1.0):
+    B, Cc = d.shape
+    t = torch.empty_like(d)
+    check(lib().dge_demod_bwd(_f32(R), _f32(d), _f32(bias), _f32(noise_strength), _p(t), B, Cc, float(bscale), _stream()),
+          "dge_demod_bwd")
+    return t
+
+
+def linear_t(x, w, y, mul=None, scale=1.0, accumulate=False, incx=1, incy=1, ldx=None, ldy=None, B=None, O=None):
+    """y[b, k*incy] (+)= scale * mul[b,k] * sum_o x[b, o*incx] * w[o, k].  x / y are given as tensors whose
+    data_ptr is element (0,0); row strides default to tensor strides."""
+    O_, K = w.shape
+    B = x.shape[0] if B is None else B
+    O = O_ if O is None else O
+    ldx = x.stride(0) if ldx is None else ldx
+    ldy = y.stride(0) if ldy is None else ldy
+    check(lib().dge_linear_t(C.c_void_p(x.data_ptr()), ldx, incx, _f32(w), _f32(mul), C.c_void_p(y.data_ptr()), ldy, incy,
+                             B, O, K, float(scale), 1 if accumulate else 0, _stream()), "dge_linear_t")
+    return y
+
+
+def torgb_bwd(gimg, x, wrgb, style, wscale):
+    B, H, W, Cc = x.shape
+    gx = torch.empty_like(x)
+    gs = torch.zeros((B, Cc), dtype=torch.float32, device=x.device)
+    check(lib().dge_torgb_bwd(_f32(gimg), _p(x), _f32(wrgb), _f32(style), _p(gx), _p(gs), B, H * W, Cc, float(wscale),
+                              dtype_of(x), _stream()), "dge_torgb_bwd")
+    return gx, gs
+
+
+def up2_bwd(g):
+    B, Cc, H, W = g.shape
+    out = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.float32, device=g.device)
+    check(lib().dge_up2_bwd(_f32(g), _p(out), B * Cc, H // 2, W // 2, _stream()), "dge_up2_bwd")
+    return out

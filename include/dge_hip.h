@@ -35,6 +35,7 @@ typedef struct ihipStream_t* dge_stream_t;   /* == hipStream_t */
 #define DGE_PACK_FWD 0      /* [tap][Cout][Cin]                                   */
 #define DGE_PACK_UPFOLD 1   /* [tap][4*Cout][Cin]: conv_transpose(s2)+FIR folded  */
 #define DGE_PACK_DGRAD 2    /* [tap][Cin][Cout], taps flipped                     */
+#define DGE_PACK_UPFOLD_DGRAD 3 /* [tap][Cin][4*Cout]: adjoint of DGE_PACK_UPFOLD  */
 
 const char* dge_last_error(void);
 int dge_version(void);
@@ -51,6 +52,7 @@ typedef struct dge_conv_desc {
     const void* w_packed;     /* from dge_pack_conv_weight          */
     void* y;                  /* [B,OH,OW,Cout], OH = up ? 2H : H   */
     const void* addend;       /* optional, same shape as y          */
+    const void* dot_src;      /* optional, same shape as y: stats = (sum acc*dot_src, sum acc) of the raw conv result */
     const float* in_scale;    /* optional [B,Cin]                   */
     const float* in_shift;    /* optional [B,Cin]                   */
     const float* out_scale;   /* optional [B,Cout]                  */
@@ -61,6 +63,7 @@ typedef struct dge_conv_desc {
     int B, H, W, Cin, Cout;
     int ksize;                /* 1 or 3 (stride 1, pad ksize/2)     */
     int up;                   /* 0 / 1                              */
+    int in_s2d;               /* 1: x is [B,2H,2W,Cin/4] read space-to-depth (adjoint of up; DGE_PACK_UPFOLD_DGRAD) */
     int noise_batch;          /* 1 = shared noise plane, else B     */
     int noise_w_per_channel;  /* 0 scalar strength, 1 per channel   */
     int act;                  /* DGE_ACT_*                          */
@@ -130,6 +133,31 @@ int dge_space_loss_bwd(const float* a, const float* b, const float* sums7, const
                        int W, int y0, int x0, int h, int w, int k, float n, float weight, int accumulate, dge_stream_t stream);
 /* y (+)= x * scalar[0] * extra  (scalar may be NULL) */
 int dge_axpy_scalar(const float* x, const float* scalar, float* y, long n, float extra, int accumulate, dge_stream_t stream);
+
+/* ---- LREQAdam.step, model/utils/custom_adam.py:24-76, all tensors in one launch ------------ */
+/* host_* are HOST arrays of `ntensors` device pointers / sizes / per-tensor step sizes
+ * (= lr * sqrt(1 - beta2^t) * lr_equalization_coef, :62-72).  gscale: optional device scalar the
+ * gradients are multiplied by first (e.g. 1/world_size after an all-reduce-sum). */
+int dge_lreq_adam_multi(int ntensors, float* const* host_p, const float* const* host_g, float* const* host_v,
+                        const long* host_n, const float* host_step, float beta2, float eps, const float* gscale,
+                        dge_stream_t stream);
+
+/* ---- data gradient of the StyleGAN2 synthesis network w.r.t. wp (E_align_s2.py:160,204) ---- */
+/* Backward through noise/bias/lrelu*gain/demodulation of ModulateConvBlock (:905-921):
+ * gy = gx*gain*lrelu'(x)*d[b,c];  R[b,c,:] (pre-zeroed) += { sum g_z*z, sum g_z*noise, sum g_z }. */
+int dge_modconv_bwd_prep(const void* gx, const void* x, const float* d, const float* noise, void* gy, float* R, int B,
+                         int HW, int C, int noise_batch, float gain, int dtype, dge_stream_t stream);
+/* t[b,o] = -(R0 - ns*R1 - bias[o]*bscale*R2) * d^2 : demodulation gradient factor (:867-870) */
+int dge_demod_bwd(const float* R, const float* d, const float* bias, const float* noise_strength, float* t, int B, int C,
+                  float bscale, dge_stream_t stream);
+/* y[b*ldy + k*incy] (+)= scale * mul[b,k] * sum_o x[b*ldx + o*incx] * W[o,k]   (transposed dense layer) */
+int dge_linear_t(const float* x, int ldx, int incx, const float* w, const float* mul, float* y, int ldy, int incy, int B,
+                 int O, int K, float scale, int accumulate, dge_stream_t stream);
+/* toRGB backward (:465-474): gx[b,p,i] = s[b,i]*wscale*sum_c g[b,c,p] Wrgb[c,i]; gs[b,i] (pre-zeroed) += sum_p (..)*x */
+int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb, const float* style, void* gx, float* gs, int B,
+                  int HW, int C, float wscale, int dtype, dge_stream_t stream);
+/* adjoint of the skip-branch 2x FIR upsample (:603-615): g [BC,2h,2w] -> gprev [BC,h,w] */
+int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, dge_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -76,3 +76,29 @@ def test_tsa_loss_and_gradient_vs_oracle():
     assert abs(float(loss) - float(tot)) < 2e-4 * abs(float(tot))
     err = (bg.grad.cpu() - b.grad).abs().max() / b.grad.abs().max()
     assert err < 2e-3, err
+
+
+def test_lreq_adam_vs_reference_golden():
+    from dge_amd.custom_adam import LREQAdam
+    g = golden("adam.npz")
+    names = ["lin.weight", "lin.bias", "conv.weight", "plain"]
+    shapes = [(7, 12), (7,), (6, 4, 3, 3), (1, 6, 1, 1)]
+    coef = g["coef"]
+    params = []
+    for k, s, c in zip(names, shapes, coef):
+        p = torch.nn.Parameter(R.randn("adam.p." + k, s, 0, 0.3).cuda())
+        if c >= 0:
+            p.lr_equalization_coef = float(c)
+        params.append(p)
+    opt = LREQAdam([{"params": params}], lr=0.0015, betas=(0.0, 0.99), weight_decay=0)
+    for step in range(3):
+        for k, s, p in zip(names, shapes, params):
+            p.grad = R.randn(f"adam.g{step}." + k, s, 0, 0.01 * (step + 1)).cuda()
+        if step == 1:
+            params[3].grad = None
+        opt.step()
+        for k, p in zip(names, params):
+            ref = g[f"s{step}:{k}"]
+            assert np.abs(p.detach().cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max() + 1e-7, (step, k)
+    with pytest.raises(ValueError):
+        LREQAdam(params, betas=(0.5, 0.99))           # custom_adam.py:14

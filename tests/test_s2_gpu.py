@@ -126,3 +126,20 @@ def test_conv_vs_oracle_random_shapes(cd):
         assert e < TOL[cd], ((B, cin, cout, H, W, k), e)
         s_ref = torch.stack([ref.sum(dim=(2, 3)), (ref * ref).sum(dim=(2, 3))], dim=2)
         assert relerr(stats, s_ref) < (1e-4 if cd == "f32" else 3e-2)
+
+
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_synthesis_grad_wp_vs_reference_golden(cd):
+    """d<image, gimg>/d wp (what phase E of the train step back-propagates into the encoder)."""
+    import dge_amd
+    g = golden("s2_small.npz")
+    P = R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11)
+    G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype=cd).cuda()
+    G.load_state_dict(P)
+    wp = R.randn("s2.wp", (2, 10, 512), 5).cuda().requires_grad_(True)
+    img = G.synthesis(wp)["image"]
+    assert relerr(img, g["syn_image"]) < (2e-4 if cd == "f32" else 6e-2)
+    gimg = R.randn("s2.gimg", tuple(img.shape), 5, 1.0 / img.numel() ** 0.5).cuda()
+    (img * gimg).sum().backward()
+    e = relerr(wp.grad, g["grad_wp"])
+    assert e < (1e-3 if cd == "f32" else 8e-2), e
