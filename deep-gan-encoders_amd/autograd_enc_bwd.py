@@ -1,0 +1,101 @@
+"""Hand-written backward of the encoder (reference model/E/E.py:50-85,122-136 differentiated).
+
+Gradient enters only through the latent codes w (E_align_s2.py:203-221: neither phase uses the
+encoder's const output in a loss that is back-propagated).  Weights are re-packed from the
+*current* parameter values at backward time, so the second backward of a step sees the weights
+already updated by LREQAdam together with the activations saved before the update - the
+reference's behaviour.
+"""
+import torch
+
+from . import ops
+from .autograd_enc import _packed
+
+
+def _linear_backward(lin, g_w, musig, grads, name):
+    """w = musig @ W^T + b  ->  g_musig [B,2C]; parameter gradients into `grads`."""
+    B = g_w.shape[0]
+    W = lin.weight.detach()
+    gms = torch.empty((B, W.shape[1]), dtype=torch.float32, device=g_w.device)
+    ops.linear_t(g_w, W, gms, ldx=g_w.stride(0), B=B)
+    gw = torch.empty_like(W)
+    gb = torch.empty_like(lin.bias)
+    ops.dense_wgrad(g_w, musig, gw, gb)
+    grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+    return gms
+
+
+def encoder_backward(E, saved, g_w):
+    """Returns gradients for E.parameters() in registration order (None where the reference
+    produces none, e.g. the last block's noise_weight_2 / bias_2)."""
+    if saved is None:
+        raise RuntimeError("encoder forward ran without saved activations")
+    cache = E.__dict__.setdefault("_pack_cache", {})
+    dev = g_w.device
+    L = E.layer_count
+    B = g_w.shape[0]
+    grads = {}
+    g_out = None
+    R = saved["img"].shape[2]
+    dt = ops.dtype_of(saved["x0"])
+    for j in range(L - 1, -1, -1):
+        blk = E.decode_block[j]
+        rec = saved["blocks"][j]
+        pre = f"decode_block.{j}."
+        Cc, C2 = blk.inputs, blk.outputs
+        H = R >> j
+        N = H * H
+        last = not blk.has_last_conv
+        has3 = Cc != C2
+        # w index map (E.py:130-134): w[:, 2(L-1-j)] = w2_j, w[:, 2(L-1-j)+1] = w1_j
+        g_w2, g_w1 = g_w[:, 2 * (L - 1 - j)], g_w[:, 2 * (L - 1 - j) + 1]
+        gms2 = _linear_backward(blk.inver_mod2, g_w2, rec["musig2"], grads, pre + "inver_mod2")
+        gms1 = _linear_backward(blk.inver_mod1, g_w1, rec["musig1"], grads, pre + "inver_mod1")
+        x, x1 = rec["x"], rec["x1"]
+        extra, extra_pool, extra_scale = None, False, 1.0
+        if not last:
+            if g_out is None:
+                raise RuntimeError("non-final encoder block without an output gradient")
+            red2 = torch.zeros((C2, 2), dtype=torch.float32, device=dev)
+            g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2)
+            grads[pre + "bias_2"] = red2[:, 0].reshape(1, C2, 1, 1)
+            grads[pre + "noise_weight_2"] = red2[:, 1].reshape(1, C2, 1, 1)
+            gW2 = torch.zeros_like(blk.conv_2.weight)
+            ops.conv_wgrad(g_pre2, x1, gW2, rec["sc2"], rec["sh2"])
+            grads[pre + "conv_2.weight"] = gW2
+            dots2 = torch.zeros((B, Cc, 2), dtype=torch.float32, device=dev)
+            g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots2, dot_src=x1)
+            if has3:
+                grads[pre + "conv_3.bias"] = ops.chan_sum(g_out, 0.889)
+                gW3 = torch.zeros_like(blk.conv_3.weight)
+                ops.conv_wgrad(g_out, rec["xp"], gW3)
+                grads[pre + "conv_3.weight"] = ops.scale_(gW3, 0.889)
+                extra = ops.conv2d(g_out, _packed(cache, blk.conv_3, dt, ops.PACK_DGRAD), Cc, 1, gain=0.889)
+                extra_pool, extra_scale = True, 0.25
+            else:
+                extra, extra_pool, extra_scale = g_out, True, 0.889 * 0.25
+        else:
+            if g_out is not None:
+                raise RuntimeError("the final encoder block's activation output carries no gradient in E_align")
+            g_y2, dots2 = None, None
+        coef2 = ops.in_bwd_coef(dots2, gms2, rec["musig2"], rec["sc2"], rec["sh2"], N)
+        red1 = torch.zeros((Cc, 2), dtype=torch.float32, device=dev)
+        g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1)
+        grads[pre + "bias_1"] = red1[:, 0].reshape(1, Cc, 1, 1)
+        grads[pre + "noise_weight_1"] = red1[:, 1].reshape(1, Cc, 1, 1)
+        gW1 = torch.zeros_like(blk.conv_1.weight)
+        ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
+        grads[pre + "conv_1.weight"] = gW1
+        dots1 = torch.zeros((B, Cc, 2), dtype=torch.float32, device=dev)
+        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD), Cc, 3, stats=dots1, dot_src=x)
+        coef1 = ops.in_bwd_coef(dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
+        g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
+    fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float())
+    C0 = E.startf
+    grads["FromRGB.from_rgb.weight"] = fr[:, :3].reshape(C0, 3, 1, 1)
+    grads["FromRGB.from_rgb.bias"] = fr[:, 3]
+    out = []
+    for name, p in E.named_parameters():
+        g = grads.get(name)
+        out.append(g.contiguous() if g is not None else None)
+    return out

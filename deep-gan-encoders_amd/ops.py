@@ -221,3 +221,67 @@ def up2_bwd(g):
     out = torch.empty((B, Cc, H // 2, W // 2), dtype=torch.float32, device=g.device)
     check(lib().dge_up2_bwd(_f32(g), _p(out), B * Cc, H // 2, W // 2, _stream()), "dge_up2_bwd")
     return out
+
+
+# ------------------------------------------------------------------ encoder backward ops
+def conv_wgrad(g, x, dw, in_scale=None, in_shift=None):
+    """dw [Cout,Cin,k,k] f32 (pre-zeroed or accumulating) += wgrad(g, x*in_scale+in_shift)."""
+    B, H, W, Cin = x.shape
+    cout, _, k, _ = dw.shape
+    check(lib().dge_conv_wgrad(_p(g), _p(x), _f32(in_scale), _f32(in_shift), _f32(dw), B, H, W, cout, Cin, k, dtype_of(x),
+                               _stream()), "dge_conv_wgrad")
+    return dw
+
+
+def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None):
+    B, H, W, Cc = a.shape
+    gpre = torch.empty_like(a)
+    check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(red), B, H, W, Cc, 1 if pool else 0, float(scale),
+                            dtype_of(a), _stream()), "dge_act_bwd")
+    return gpre
+
+
+def in_bwd_coef(dots, gms, musig, sc, sh, npix):
+    B, Cc = sc.shape
+    coef = torch.empty((B, Cc, 3), dtype=torch.float32, device=sc.device)
+    check(lib().dge_in_bwd_coef(_f32(dots), _f32(gms), _f32(musig), _f32(sc), _f32(sh), _p(coef), B, Cc, int(npix), _stream()),
+          "dge_in_bwd_coef")
+    return coef
+
+
+def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=None, act=False, red=None):
+    B, H, W, Cc = x.shape
+    gout = torch.empty_like(x)
+    check(lib().dge_in_bwd(_p(gy), _p(x), _f32(coef), _p(extra), _f32(noise), _p(gout), _f32(red), B, H, W, Cc,
+                           1 if extra_pool else 0, float(extra_scale), 1 if act else 0, dtype_of(x), _stream()), "dge_in_bwd")
+    return gout
+
+
+def chan_sum(x, scale=1.0):
+    B, H, W, Cc = x.shape
+    out = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+    check(lib().dge_chan_sum(_p(x), _p(out), B, H * W, Cc, float(scale), dtype_of(x), _stream()), "dge_chan_sum")
+    return out
+
+
+def fromrgb_bwd(gx, x0, img):
+    B, H, W, Cc = x0.shape
+    out = torch.zeros((Cc, 4), dtype=torch.float32, device=x0.device)
+    check(lib().dge_fromrgb_bwd(_p(gx), _p(x0), _f32(img.contiguous()), _p(out), B, H * W, Cc, dtype_of(x0), _stream()),
+          "dge_fromrgb_bwd")
+    return out
+
+
+def dense_wgrad(gy, x, gw, gb=None, accumulate=False):
+    """gy: [B,O] view (row stride free), x: [B,I]; gw [O,I], gb [O]."""
+    B, O = gy.shape
+    I = x.shape[1]
+    check(lib().dge_dense_wgrad(C.c_void_p(gy.data_ptr()), gy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0), _f32(gw),
+                                _f32(gb), B, O, I, 1 if accumulate else 0, _stream()), "dge_dense_wgrad")
+    return gw, gb
+
+
+def scale_(t, factor):
+    """in-place t *= factor on the device (dge_axpy_scalar)."""
+    check(lib().dge_axpy_scalar(_f32(t), None, _p(t), t.numel(), float(factor), 0, _stream()), "dge_axpy_scalar")
+    return t

@@ -159,6 +159,27 @@ int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb, const flo
 /* adjoint of the skip-branch 2x FIR upsample (:603-615): g [BC,2h,2w] -> gprev [BC,h,w] */
 int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, dge_stream_t stream);
 
+/* ---- encoder backward (model/E/E.py:50-85 differentiated; conv data gradients use dge_conv2d) */
+/* dw[o][i][tap] (f32, OIHW like the parameter, pre-zeroed) += sum_{b,p} g[b,p,o] * (x*in_scale+in_shift)[b,p+tap,i] */
+int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H, int W,
+                   int cout, int cin, int ksize, int dtype, dge_stream_t stream);
+/* gpre = scale * gup[q(p)] * lrelu'(a) (q = 2x2 pooling parent when pool); red[c,2] += {sum gpre, sum gpre*noise} */
+int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int B, int H, int W, int C, int pool,
+                float scale, int dtype, dge_stream_t stream);
+/* coefficients (A,Bc,Cc)[B,C,3] of the instance-norm + (mean,std) backward; see DESIGN.md */
+int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh, float* coef,
+                    int B, int C, int npix, dge_stream_t stream);
+/* gout = A*gy + Bc*x + Cc + extra_scale*extra[q(p)], then optional lrelu' of x with bias/noise reductions */
+int dge_in_bwd(const void* gy, const void* x, const float* coef, const void* extra, const float* noise, void* gout, float* red,
+               int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, dge_stream_t stream);
+int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, int dtype, dge_stream_t stream);
+/* out4[o][0..2] += sum g_pre*img[c], out4[o][3] += sum g_pre with g_pre = gx*lrelu'(x0)  (FromRGB, net.py:231-240) */
+int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img, float* out4, int B, int HW, int C, int dtype,
+                    dge_stream_t stream);
+/* gw[o][i] (+)= sum_b gy[b][o]*x[b][i]; gb[o] (+)= sum_b gy[b][o]   (ln.Linear parameter gradients) */
+int dge_dense_wgrad(const float* gy, int ldgy, const float* x, int ldx, float* gw, float* gb, int B, int O, int I,
+                    int accumulate, dge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,3 +55,43 @@ def test_state_dict_surface():
         for k, p in E.named_parameters():
             c = getattr(p, "lr_equalization_coef", -1.0)
             assert abs(c - coefs[k]) < 1e-6 * max(1.0, abs(coefs[k])), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_encoder_backward_vs_reference_golden(cd):
+    """All parameter gradients of <w, gw> against the reference's autograd (enc_small.npz)."""
+    g = golden("enc_small.npz")
+    E = small_encoder(cd)
+    img = R.randn("enc.img", (2, 3, 32, 32), 9, 0.5).cuda()
+    noises = [R.randn(f"enc.noise{i}", s, 9).cuda() for i, s in enumerate(O.enc_noise_shapes(4, 2, 32))]
+    x, w = E(img, noises=noises)
+    gw = R.randn("enc.gw", tuple(w.shape), 9, 0.05).cuda()
+    (w * gw).sum().backward()
+    # f32: max-abs error relative to the tensor's max magnitude.  bf16: gradients travel through bf16
+    # tensors and the instance-norm backward subtracts projections, so the bound is on direction and
+    # L2 norm (cosine > 0.995, relative L2 < 0.12) on this deliberately tiny 32x32 / 4x4-bottleneck case.
+    bad = {}
+    for k, p in E.named_parameters():
+        if "grad:" + k in g.files:
+            assert p.grad is not None, k
+            a, b = p.grad.float().cpu().flatten(), torch.from_numpy(g["grad:" + k]).flatten()
+            if cd == "f32":
+                e = ((a - b).abs().max() / b.abs().max()).item()
+                if not e < 2e-3:
+                    bad[k] = e
+            else:
+                l2 = ((a - b).norm() / b.norm()).item()
+                cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+                if not (l2 < 0.12 and cos > 0.995):
+                    bad[k] = (l2, cos)
+        else:
+            assert p.grad is None, f"{k} must not receive a gradient (reference leaves it None)"
+    assert not bad, bad
+    # retain_graph semantics: a second backward over the same saved activations works (E_align_s2.py:204-220)
+    E.zero_grad()
+    x, w = E(img, noises=noises)
+    (w * gw).sum().backward(retain_graph=True)
+    g1 = E.decode_block[0].conv_1.weight.grad.clone()
+    (w * gw).sum().backward()
+    assert relerr(E.decode_block[0].conv_1.weight.grad, (2 * g1).cpu()) < 1e-5
