@@ -52,12 +52,18 @@ SIGNATURES = {
     "dge_torgb_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "dge_up2_bwd": [_P, _P, _I, _I, _I, _P],
     "dge_conv_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dge_act_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dge_act_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_in_bwd_coef": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dge_in_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dge_chan_sum": [_P, _P, _I, _I, _I, _F, _I, _P],
     "dge_fromrgb_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dge_dense_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "dge_lpips_prep": [_P, _P, _I, _I, _I, _P, _P, _I, _P],
+    "dge_lpips_prep_bwd": [_P, _P, _I, _I, _I, _P, _F, _I, _I, _P],
+    "dge_maxpool2": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dge_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dge_lpips_head": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
+    "dge_mean": [_P, _P, _I, _P],
     "dge_version": [],
 }
 

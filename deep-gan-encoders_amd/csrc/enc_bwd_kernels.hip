@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gup, const T* __restrict__ a,
                                                        const float* __restrict__ noise, T* __restrict__ gpre,
-                                                       float* __restrict__ red_out, int H, int W, int C, int pool, float scale) {
+                                                       float* __restrict__ red_out, int H, int W, int C, int pool, float scale, float slope) {
     constexpr int EP = Elem<T>::PER16;
     __shared__ float red[256 * 2 * EP];
     const int b = blockIdx.y;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gup,
             const float nz = noise ? noise[(size_t)b * HW + p] : 0.f;
 #pragma unroll
             for (int e = 0; e < EP; e++) {
-                g[e] = scale * g[e] * (av[e] > 0.f ? 1.f : 0.2f);
+                g[e] = scale * g[e] * (av[e] > 0.f ? 1.f : slope);
                 s[0][e] += g[e]; s[1][e] += g[e] * nz;
             }
             *(uint4*)(gpre + ((size_t)b * HW + p) * C + chunk * EP) = pack16(g, (T*)nullptr);
@@ -337,12 +337,12 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
 }
 
 extern "C" int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int B, int H, int W, int C,
-                           int pool, float scale, int dtype, hipStream_t s) {
+                           int pool, float scale, float slope, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "act_bwd: unsupported channel count %d", C);
     dim3 grid(sgrid(H * W, 256 / (C / ep)), B);
-    if (dtype == DGE_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gup, (const bf16_t*)a, noise, (bf16_t*)gpre, red, H, W, C, pool, scale);
-    else hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gup, (const float*)a, noise, (float*)gpre, red, H, W, C, pool, scale);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gup, (const bf16_t*)a, noise, (bf16_t*)gpre, red, H, W, C, pool, scale, slope);
+    else hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gup, (const float*)a, noise, (float*)gpre, red, H, W, C, pool, scale, slope);
     DGE_LAUNCH_CHECK("act_bwd");
     return 0;
 }

@@ -233,11 +233,11 @@ def conv_wgrad(g, x, dw, in_scale=None, in_shift=None):
     return dw
 
 
-def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None):
+def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2):
     B, H, W, Cc = a.shape
     gpre = torch.empty_like(a)
     check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(red), B, H, W, Cc, 1 if pool else 0, float(scale),
-                            dtype_of(a), _stream()), "dge_act_bwd")
+                            float(slope), dtype_of(a), _stream()), "dge_act_bwd")
     return gpre
 
 

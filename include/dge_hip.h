@@ -163,9 +163,9 @@ int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, dge_stream_t
 /* dw[o][i][tap] (f32, OIHW like the parameter, pre-zeroed) += sum_{b,p} g[b,p,o] * (x*in_scale+in_shift)[b,p+tap,i] */
 int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H, int W,
                    int cout, int cin, int ksize, int dtype, dge_stream_t stream);
-/* gpre = scale * gup[q(p)] * lrelu'(a) (q = 2x2 pooling parent when pool); red[c,2] += {sum gpre, sum gpre*noise} */
+/* gpre = scale * gup[q(p)] * (a > 0 ? 1 : slope) (q = 2x2 pooling parent when pool); red[c,2] += {sum gpre, sum gpre*noise} */
 int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int B, int H, int W, int C, int pool,
-                float scale, int dtype, dge_stream_t stream);
+                float scale, float slope, int dtype, dge_stream_t stream);
 /* coefficients (A,Bc,Cc)[B,C,3] of the instance-norm + (mean,std) backward; see DESIGN.md */
 int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh, float* coef,
                     int B, int C, int npix, dge_stream_t stream);
@@ -179,6 +179,19 @@ int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img, float* out
 /* gw[o][i] (+)= sum_b gy[b][o]*x[b][i]; gb[o] (+)= sum_b gy[b][o]   (ln.Linear parameter gradients) */
 int dge_dense_wgrad(const float* gy, int ldgy, const float* x, int ldx, float* gw, float* gb, int B, int O, int I,
                     int accumulate, dge_stream_t stream);
+
+/* ---- LPIPS(net='vgg') glue (third-party algorithm called at training_utils.py:93; VGG convs use dge_conv2d) */
+int dge_lpips_prep(const float* img, void* x, int B, int HW, int cpad, const float* host_shift3, const float* host_scale3,
+                   int dtype, dge_stream_t stream);                 /* ScalingLayer + NCHW f32 -> NHWC (channels padded) */
+int dge_lpips_prep_bwd(const void* gx, float* gimg, int B, int HW, int cpad, const float* host_scale3, float factor,
+                       int accumulate, int dtype, dge_stream_t stream);
+int dge_maxpool2(const void* x, void* y, int B, int H, int W, int C, int dtype, dge_stream_t stream);   /* MaxPool2d(2,2) */
+int dge_maxpool2_bwd(const void* gy, const void* x, const void* addend, void* gx, int B, int H, int W, int C, int dtype,
+                     dge_stream_t stream);
+/* one tap: feat [2B,h,w,C] (a then b); val[b] += spatial mean of sum_c lin_c (n_a - n_b)^2; g1 = gscale * dval/dfeat_b */
+int dge_lpips_head(const void* feat, const float* lin, float* val, void* g1, int B, int HW, int C, float gscale, int dtype,
+                   dge_stream_t stream);
+int dge_mean(const float* v, float* out, int n, dge_stream_t stream);
 
 #ifdef __cplusplus
 }
