@@ -10,7 +10,7 @@ def _packed(cache, conv, dtype, mode):
     """Packed copy of a conv weight, rebuilt when the parameter was updated in place."""
     w = conv.weight
     key = (id(w), mode, dtype)
-    ver = (w._version, w.data_ptr())
+    ver = (w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
     hit = cache.get(key)
     if hit is None or hit[0] != ver:
         hit = (ver, ops.pack_conv_weight(w, mode, dtype, 1.0))

@@ -51,7 +51,7 @@ def synthesis_run(mod, wp, randomize_noise=False, save=False):
 
 def _dgrad_weight(L, dtype):
     mode = ops.PACK_UPFOLD_DGRAD if L.up else ops.PACK_DGRAD
-    key = ("dg", dtype, L.weight._version, L.weight.data_ptr())
+    key = ("dg", dtype, L.weight._version, L.weight.data_ptr(), getattr(L.weight, "_dge_gen", 0))
     c = L._cache.get("dg")
     if c is None or c[0] != key:
         c = (key, ops.pack_conv_weight(L.weight, mode, dtype, L.wscale))

@@ -50,6 +50,9 @@ class LREQAdam(Optimizer):
                     step_size *= p.lr_equalization_coef
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 keep.append(g)
+                # the kernel writes through the raw pointer (like the reference's p.data update, it does not touch
+                # autograd's version counter): bump our own generation so packed weight copies are rebuilt
+                p._dge_gen = getattr(p, "_dge_gen", 0) + 1
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); vs.append(state["exp_avg_sq"].data_ptr())
                 ns.append(p.numel()); steps.append(step_size)
             n = len(ps)

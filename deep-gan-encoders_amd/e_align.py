@@ -1,0 +1,164 @@
+"""E_align stage-2 encoder training step (reference E_align_s2.py:23-299) on the HIP path.
+
+`EAlignStep.step()` is one iteration of the reference's hot loop (:102-221) for mtype 2
+(StyleGAN2): seed -> z -> G (no grad, train-mode quirks kept) -> E -> G.synthesis (grad) ->
+loss_imgs + 5*loss_medium + 9*loss_small -> backward(retain_graph) -> LREQAdam.step ->
+0.01*loss_w -> backward -> step.  One process per GPU; with torch.distributed initialised the
+encoder gradients are all-reduced over RCCL once per phase (flat 97 MB bucket at FFHQ-1024) and
+the batch-coupled loss terms (cosine, means) use globally reduced sums so that N ranks x B
+images reproduce a single-process run at batch N*B.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import losses
+from .custom_adam import LREQAdam
+
+
+def set_seed(seed):
+    """training_utils.py:46-52"""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+class EAlignStep:
+    def __init__(self, generator, E, lpips_model, lr=0.0015, beta_1=0.0, batch_size=2, z_dim=512,
+                 reference_noise=False, exact_ddp=True):
+        self.G, self.E, self.lpips = generator, E, lpips_model
+        self.opt = LREQAdam([{"params": E.parameters()}], lr=lr, betas=(beta_1, 0.99), weight_decay=0)
+        self.batch_size, self.z_dim = batch_size, z_dim
+        self.reference_noise = reference_noise      # True: CPU-generated noise in the reference's order (Q6)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.exact_ddp = exact_ddp
+        self.dev = next(E.parameters()).device
+        self._flat = None
+        self.last = {}
+
+    # ------------------------------------------------------------------ DDP gradient exchange
+    def _sync_grads(self):
+        """All-reduce (sum) of every encoder gradient as one flat bucket; p.grad become views."""
+        if self.world == 1:
+            return None
+        ps = [p for p in self.E.parameters() if p.grad is not None]
+        n = sum(p.numel() for p in ps)
+        if self._flat is None or self._flat.numel() != n:
+            self._flat = torch.empty(n, dtype=torch.float32, device=self.dev)
+        off = 0
+        views = []
+        for p in ps:
+            v = self._flat[off:off + p.numel()].view_as(p)
+            v.copy_(p.grad)
+            views.append(v)
+            off += p.numel()
+        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        for p, v in zip(ps, views):
+            p.grad = v
+        # exact mode: every rank differentiated the GLOBAL loss w.r.t. its own samples -> sum.
+        # plain mode: local losses -> mean.
+        return None if self.exact_ddp else torch.full((1,), 1.0 / self.world, device=self.dev)
+
+    # ------------------------------------------------------------------ one iteration
+    def step(self, iteration, z=None, noises=None):
+        G, E = self.G, self.E
+        B = self.batch_size
+        set_seed(iteration % 30000)
+        if z is None:
+            # every rank draws the same global z and takes its slice
+            zg = torch.randn(B * self.world, self.z_dim)
+            z = zg[self.rank * B:(self.rank + 1) * B]
+        z = z.to(self.dev)
+        with torch.no_grad():
+            result_all = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+            imgs1, w1 = result_all["image"], result_all["wp"]
+        if noises is None and self.reference_noise:
+            from .autograd_enc import draw_noises
+            noises = [n.to(self.dev) for n in draw_noises(E, B, imgs1.shape[2], "cpu")]
+        const2, w2 = E(imgs1, noises=noises)
+        imgs2 = G.synthesis(w2)["image"]
+
+        gctx = losses.GlobalBatch(self.world) if (self.world > 1 and self.exact_ddp) else None
+        loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, global_batch=gctx)
+        self.opt.zero_grad()
+        loss_tsa.backward(retain_graph=True)
+        gs = self._sync_grads()
+        self.opt.step(grad_scale=gs)
+
+        loss_w, info_w = losses.space_loss(w1, w2, image_space=False, global_batch=gctx)
+        loss_mtv = loss_w * 0.01
+        self.opt.zero_grad()
+        loss_mtv.backward()
+        gs = self._sync_grads()
+        self.opt.step(grad_scale=gs)
+        self.last = dict(imgs1=imgs1, imgs2=imgs2, w1=w1, w2=w2, const2=const2, loss_tsa=loss_tsa.detach(),
+                         info_img=info_img, loss_w=loss_w.detach(), info_w=info_w)
+        return self.last
+
+
+def build_models(img_size=1024, start_features=16, compute_dtype="bf16", device="cuda", lpips=True, seed=0,
+                 fmaps_base=32 << 10, fmaps_max=512, enc_maxf=512):
+    """Models of BASELINE config 3 with seeded random-init weights (no checkpoints ship)."""
+    from .stylegan2_generator import StyleGAN2Generator
+    from .encoder import BE
+    from .lpips import LPIPS
+    torch.manual_seed(seed)
+    G = StyleGAN2Generator(img_size, fmaps_base=fmaps_base, fmaps_max=fmaps_max, compute_dtype=compute_dtype).to(device)
+    for p in G.parameters():
+        p.requires_grad_(False)          # G weight gradients are never used
+    with torch.no_grad():
+        for name, p in G.named_parameters():
+            if name.endswith("noise_strength"):
+                p.fill_(0.05)
+    E = BE(startf=start_features, maxf=enc_maxf, layer_count=int(math.log2(img_size) - 1), compute_dtype=compute_dtype).to(device)
+    LP = LPIPS(compute_dtype=compute_dtype).to(device) if lpips else None
+    return G, E, LP
+
+
+def train(tensor_writer=None, args=None):
+    """Reference E_align_s2.train() for --mtype 2 (flags: E_align_s2.py:304-318)."""
+    if args.mtype != 2:
+        raise NotImplementedError("only --mtype 2 (StyleGAN2) is wired into the training loop in this round")
+    G, E, LP = build_models(args.img_size, args.start_features, getattr(args, "compute_dtype", "bf16"))
+    if args.checkpoint_dir_GAN:
+        ckpt = torch.load(args.checkpoint_dir_GAN, map_location="cpu")
+        G.load_state_dict(ckpt["generator_smooth"] if "generator_smooth" in ckpt else ckpt["generator"])
+    if args.checkpoint_dir_E is not None:
+        E.load_state_dict(torch.load(args.checkpoint_dir_E, map_location="cpu"))
+    st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim)
+    for iteration in range(args.iterations):
+        r = st.step(iteration)
+        if iteration % 100 == 0:
+            print("ep_%d_iter_%d" % (iteration // 30000, iteration % 30000), "loss_tsa", float(r["loss_tsa"]),
+                  "loss_w", float(r["loss_w"]))
+        if iteration % 5000 == 0 and getattr(args, "experiment_dir", None):
+            torch.save(E.state_dict(), "%s/E_model_ep%d_iter%d.pth" % (args.experiment_dir, iteration // 30000, iteration % 30000))
+    return st
+
+
+def main(argv=None):
+    import argparse
+    parser = argparse.ArgumentParser(description="the training args")
+    parser.add_argument("--iterations", type=int, default=210000)
+    parser.add_argument("--lr", type=float, default=0.0015)
+    parser.add_argument("--beta_1", type=float, default=0.0)
+    parser.add_argument("--batch_size", type=int, default=2)
+    parser.add_argument("--experiment_dir", default=None)
+    parser.add_argument("--checkpoint_dir_GAN", default=None)
+    parser.add_argument("--config_dir", default=None)
+    parser.add_argument("--checkpoint_dir_E", default=None)
+    parser.add_argument("--img_size", type=int, default=1024)
+    parser.add_argument("--img_channels", type=int, default=3)
+    parser.add_argument("--z_dim", type=int, default=512)
+    parser.add_argument("--mtype", type=int, default=2)
+    parser.add_argument("--start_features", type=int, default=16)
+    parser.add_argument("--compute_dtype", default="bf16")
+    return train(None, parser.parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,20 @@ from ._lib import lib, check
 from .ops import _f32, _p, _stream
 
 
+class GlobalBatch:
+    """Makes the batch-coupled terms of space_loss (cosine over the batch-flattened vector, means,
+    the 1/N of mse / ssim / lpips) refer to the GLOBAL batch of a data-parallel run: the per-rank
+    partial sums are all-reduced before the loss and its gradient are formed."""
+
+    def __init__(self, world):
+        self.world = world
+
+    def reduce(self, t):
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+
 def _pool_factor(h):
     k = 1
     while h > 256:          # training_utils.py:81 tests shape[2] only
@@ -22,7 +36,7 @@ def attention_windows(H, W):
     return [(0, 0, H, W), (0, W // 8, H, W - 2 * (W // 8)), (oy, ox, H - 2 * oy, W - 2 * ox)]
 
 
-def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accumulate):
+def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accumulate, gb=None):
     """One space_loss evaluation on a window of a,b [B,C,H,W].  Returns out8 (device) and, when
     g_out is given, adds weight * dloss/db into it."""
     B, Cc, H, W = a.shape
@@ -32,6 +46,11 @@ def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accum
     sums = torch.zeros(8, dtype=torch.float32, device=dev)
     check(L.dge_loss_reduce(_f32(a), _f32(b), _p(sums), B, Cc, H, W, y0, x0, h, w, _stream()), "dge_loss_reduce")
     n = float(B * Cc * h * w)
+    world = 1
+    if gb is not None:
+        gb.reduce(sums)
+        world = gb.world
+        n *= world
     out8 = torch.empty(8, dtype=torch.float32, device=dev)
     gp, k, npool = None, 1, 1.0
     ssum = lp = None
@@ -42,17 +61,21 @@ def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accum
         bp = torch.empty_like(ap)
         check(L.dge_crop_pool(_f32(a), _p(ap), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
         check(L.dge_crop_pool(_f32(b), _p(bp), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
-        npool = float(B * Cc * hp * wp)
+        npool = float(B * Cc * hp * wp) * world
         ssum = torch.zeros(1, dtype=torch.float32, device=dev)
         dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if g_out is not None else None
         check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(ssum), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
+        if gb is not None:
+            gb.reduce(ssum)
         if g_out is not None:
             gp = torch.empty_like(bp)
             check(L.dge_ssim_bwd(_p(ap), _p(bp), _p(dmap), _p(gp), B * Cc, hp, wp, -1.0 / npool, 0, _stream()), "dge_ssim_bwd")
         if lpips_model is not None:
             lp, g_lp = lpips_model.value_and_grad(ap, bp, need_grad=g_out is not None)   # mean over batch, d/dbp
+            if gb is not None:
+                check(L.dge_axpy_scalar(_p(gb.reduce(lp.clone())), None, _p(lp), 1, 1.0 / world, 0, _stream()), "dge_axpy_scalar")
             if g_out is not None:
-                check(L.dge_axpy_scalar(_p(g_lp), None, _p(gp), gp.numel(), 2.0, 1, _stream()), "dge_axpy_scalar")
+                check(L.dge_axpy_scalar(_p(g_lp), None, _p(gp), gp.numel(), 2.0 / world, 1, _stream()), "dge_axpy_scalar")
     check(L.dge_space_loss_finalize(_p(sums), _p(ssum), _p(lp), _p(out8), n, npool, 1 if image_space else 0, _stream()),
           "dge_space_loss_finalize")
     if g_out is not None:
@@ -77,7 +100,7 @@ class _ScaledGrad(torch.autograd.Function):
         return out, None, None
 
 
-def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0)):
+def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0), global_batch=None):
     """loss_tsa = loss_imgs + 5*loss_medium + 9*loss_small (E_align_s2.py:185-203).
     Returns (loss [] on device, info [3,8] on device: rows full/AT1/AT2, columns
     loss, mse, mse_mean, mse_std, kl, cos, ssim, lpips).  No host synchronisation."""
@@ -87,7 +110,7 @@ def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0)):
     g = torch.zeros_like(b) if need else None
     infos = []
     for i, win in enumerate(attention_windows(a.shape[2], a.shape[3])):
-        infos.append(_space_loss_window(a, b, win, True, lpips_model, weights[i], g, accumulate=True))
+        infos.append(_space_loss_window(a, b, win, True, lpips_model, weights[i], g, accumulate=True, gb=global_batch))
     info = torch.stack(infos)
     wv = torch.tensor(weights, dtype=torch.float32, device=a.device)
     loss = (info[:, 0] * wv).sum()
@@ -96,7 +119,7 @@ def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0)):
     return loss, info
 
 
-def space_loss(imgs1, imgs2, image_space=True, lpips_model=None):
+def space_loss(imgs1, imgs2, image_space=True, lpips_model=None, global_batch=None):
     """Drop-in for training_utils.space_loss; returns (loss tensor, info tensor[8] on device)
     instead of Python floats (the reference's 7 .item() syncs per call are deferred)."""
     a = imgs1.detach().float().contiguous()
@@ -105,13 +128,13 @@ def space_loss(imgs1, imgs2, image_space=True, lpips_model=None):
     g = torch.empty_like(b) if need else None
     if image_space:
         B, Cc, H, W = a.shape
-        out8 = _space_loss_window(a, b, (0, 0, H, W), True, lpips_model, 1.0, g, accumulate=False)
+        out8 = _space_loss_window(a, b, (0, 0, H, W), True, lpips_model, 1.0, g, accumulate=False, gb=global_batch)
     else:
         # 3-D latents: the implicit softmax dim is 0 (the batch) -> planes = batch (training_utils.py:67)
         Bt = a.shape[0]
         n_in = a.numel() // Bt
         out8 = _space_loss_window(a.view(1, Bt, 1, n_in), b.view(1, Bt, 1, n_in), (0, 0, 1, n_in), False, None, 1.0,
-                                  g.view(1, Bt, 1, n_in) if need else None, accumulate=False)
+                                  g.view(1, Bt, 1, n_in) if need else None, accumulate=False, gb=global_batch)
     loss = out8[0]
     if need:
         loss = _ScaledGrad.apply(imgs2, loss, g)

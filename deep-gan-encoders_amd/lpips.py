@@ -73,7 +73,7 @@ class LPIPS(nn.Module):
     def _packed(self, ci, dt, mode):
         conv = self.convs[ci]
         key = (ci, dt, mode)
-        ver = (conv.weight._version, conv.weight.data_ptr())
+        ver = (conv.weight._version, conv.weight.data_ptr(), getattr(conv.weight, "_dge_gen", 0))
         hit = self._cache.get(key)
         if hit is None or hit[0] != ver:
             w = conv.weight.detach()

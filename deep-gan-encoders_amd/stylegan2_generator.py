@@ -148,7 +148,7 @@ class ModulateConvBlock(nn.Module):
 
     # -- derived weights, rebuilt only when the parameter changes ---------------------------
     def _prepared(self, dtype):
-        key = (dtype, self.weight._version, self.weight.data_ptr())
+        key = (dtype, self.weight._version, self.weight.data_ptr(), getattr(self.weight, "_dge_gen", 0))
         c = self._cache.get("w")
         if c is None or c[0] != key:
             mode = ops.PACK_UPFOLD if self.up else ops.PACK_FWD
@@ -257,7 +257,13 @@ class StyleGAN2Generator(nn.Module):
             w = mapping_results["w"]
             # train-mode side effects the reference keeps active during E_align
             if self.training and w_moving_decay < 1:
-                self.truncation.w_avg.copy_(self.truncation.w_avg * w_moving_decay + w.mean(dim=0) * (1 - w_moving_decay))
+                batch_w_avg = w.mean(dim=0)
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    # the upstream code all_gather'ed w here (reference :178, commented out): global batch mean
+                    dist.all_reduce(batch_w_avg)
+                    batch_w_avg = batch_w_avg / dist.get_world_size()
+                self.truncation.w_avg.copy_(self.truncation.w_avg * w_moving_decay + batch_w_avg * (1 - w_moving_decay))
             if self.training and style_mixing_prob > 0:
                 new_z = torch.randn_like(z)
                 new_w = self.mapping(new_z, label)["w"]
