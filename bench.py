@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Headline benchmark: encoder-train images/sec (E_align_s2 step, StyleGAN2 FFHQ-1024,
+BASELINE.json config 3) on N GPUs of one node, one process per GPU over RCCL.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` = images of all ranks / max-over-ranks time of the K
+timed steps (inputs are generated on the device inside the step, as in the reference loop).
+Extra objects: `roofline` (conv_igemm kernels, HIP events on the launch stream, in a separate
+instrumented pass over the same step) and `cpu_baseline` (the CPU oracle timed on the host
+cores, rank 0, N=1 only, bounded sample).  Also reports G-synthesis ms/img (second half of the
+BASELINE metric) as `synthesis_ms_per_img`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU (reference default, E_align_s2.py:308)")
+    ap.add_argument("--img-size", type=int, default=1024)
+    ap.add_argument("--start-features", type=int, default=16)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-size", type=int, default=256, help="image size of the bounded CPU-oracle sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(img_size, start_features):
+    """Bounded sample: ONE oracle E_align step, batch 1, at `img_size` (same architecture family:
+    StyleGAN2 generator + E.BE + LPIPS), all host cores through torch's CPU ops."""
+    import math
+    from tests.golden import recipe as R
+    from tests.helpers import s2_shapes, enc_shapes
+    from oracle import ref_torch as O, lpips_ref as LR, step_ref
+    # torch's intra-op pool degrades badly with hundreds of threads on these small convs (measured:
+    # 479 s with 256 threads vs 13 s with 8): use at most 16 host cores and report that number
+    ncores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(ncores)
+    L = int(math.log2(img_size) - 1)
+    PG = R.fill_s2(s2_shapes(img_size), seed=1)
+    PE = {k: v.requires_grad_(True) for k, v in R.fill_encoder(enc_shapes(start_features, 512, L), seed=2).items()}
+    PL = LR.seeded_params(0)
+    z = R.randn("bench.z", (1, 512), 0)
+    noises = [R.randn(f"bench.n{i}", s, 0) for i, s in enumerate(O.enc_noise_shapes(L, 1, img_size))]
+    t0 = time.time()
+    step_ref.e_align_step(PG, PE, PL, z, noises)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "images/sec", "cores": ncores, "kind": "port",
+            "sample": f"1 oracle E_align_s2 step (oracle/step_ref.py: torch fp32 CPU restatement), batch 1, "
+                      f"StyleGAN2-{img_size} + E.BE(startf={start_features}) + LPIPS-VGG16, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    import dge_amd
+    from dge_amd import ops
+    from dge_amd.e_align import EAlignStep, build_models
+
+    G, E, LP = build_models(a.img_size, a.start_features, a.dtype, dev, seed=0)
+    G.train()                       # the reference never calls .eval() on G
+    st = EAlignStep(G, E, LP, batch_size=a.batch)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        st.step(i)
+    sync()
+    t0 = time.time()
+    for i in range(a.steps):
+        st.step(a.warmup + i)
+    sync()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    imgs = a.batch * world * a.steps
+    out = {
+        "metric": "encoder-train images/sec (E_align_s2 step, StyleGAN2 FFHQ-1024)", "value": imgs / dt, "unit": "images/sec",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"E_align_s2 two-phase step, StyleGAN2-{a.img_size} G (train mode) + E.BE(startf={a.start_features}, "
+                               f"L={E.layer_count}) + LPIPS-VGG16 (seeded stand-in weights), batch {a.batch}/GPU",
+                   "global_batch": a.batch * world, "img_size": a.img_size, "parallelism": f"dp{world}"},
+    }
+
+    # ---- G-synthesis ms/img (second half of the BASELINE metric), eval-mode synthesis(wp)
+    with torch.no_grad():
+        wp = torch.randn(a.batch, G.num_layers, 512, device=dev)
+        for _ in range(2):
+            G.synthesis(wp)
+        sync()
+        t0 = time.time()
+        n = 10
+        for _ in range(n):
+            G.synthesis(wp)
+        sync()
+        out["synthesis_ms_per_img"] = (time.time() - t0) / n / a.batch * 1e3
+
+    # ---- roofline of the dominant kernel family (conv_igemm), instrumented extra pass
+    if not a.no_roofline:
+        ops.PROFILE = []
+        for i in range(2):
+            st.step(1000 + i)
+        torch.cuda.synchronize()
+        fl, ms = 0.0, 0.0
+        for (e0, e1, flops, tag) in ops.PROFILE:
+            fl += flops
+            ms += e0.elapsed_time(e1)
+        nlaunch = len(ops.PROFILE)
+        ops.PROFILE = None
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = 2500.0 if a.dtype == "bf16" else 157.3
+        out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                           "traffic": None, "kernel": "conv_igemm_kernel<*> (all implicit-GEMM conv launches of a step)",
+                           "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
+                           "algorithmic_gflop_per_step": fl / 2 / 1e9}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_size, 64 if a.cpu_size <= 256 else 16)
+        except Exception as ex:      # the baseline is informative; never lose the GPU numbers over it
+            out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {ex!r}"}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

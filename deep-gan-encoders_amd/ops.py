@@ -10,6 +10,7 @@ from ._lib import lib, check, ConvDesc, DgeError
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
 PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD = 0, 1, 2, 3
+PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag) per conv launch
 
 
 def tdtype(dtype):
@@ -120,6 +121,21 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt
     if w_packed.dtype != x.dtype:
         raise DgeError("conv2d: packed weight dtype differs from activation dtype")
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
+        e1.record()
+        # algorithmic work: a folded up layer / its adjoint count as the 3x3 transposed conv they replace
+        # (9*Cin*Cout MACs per INPUT pixel), everything else k*k*Cin*Cout per output pixel
+        if up:
+            macs = 9.0 * Cin * cout * H * W
+        elif in_s2d:
+            macs = 9.0 * (Cin // 4) * cout * H * W
+        else:
+            macs = float(ksize * ksize) * Cin * cout * H * W
+        PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, ksize, up, in_s2d)))
+        return out
     check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
     return out
 

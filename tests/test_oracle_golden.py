@@ -183,3 +183,36 @@ def test_shape_tables_match_reference_state_dicts():
         assert set(mine.keys()) == set(ek[tag].keys())
         assert all(list(mine[k]) == ek[tag][k] for k in mine)
     assert len(ek["1024_16_9"]) == 101 and len(ek["256_64_7"]) == 77
+
+
+def test_c_oracle_modconv():
+    """The plain-C restatement of the north-star kernel (oracle/modconv_oracle.c, the reference's
+    fused per-sample-weight formulation) against the reference's own outputs."""
+    import ctypes as C
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    lib = C.CDLL(so)
+    fp = C.POINTER(C.c_float)
+    ptr = lambda t: t.contiguous().data_ptr()
+    g = golden("s2_blocks.npz")
+    from tests.helpers import modconv_shapes
+    for ci in range(5):          # case 5 (512x512) is covered by the torch oracle; keep the C loop nests fast
+        cin, cout, res, up, k = [int(v) for v in g[f"c{ci}_cfg"]]
+        torgb = (k == 1)
+        P = R.fill_s2(modconv_shapes(cin, cout, res, k, noise=not torgb, up=bool(up)), seed=100 + ci)
+        rin = res // 2 if up else res
+        x = R.randn(f"mc{ci}.x", (2, cin, rin, rin), 7)
+        w = R.randn(f"mc{ci}.w", (2, 512), 7)
+        style = torch.empty(2, cin)
+        lib.orc_style(C.c_void_p(ptr(w)), C.c_void_p(ptr(P["style.weight"])), C.c_void_p(ptr(P["style.bias"])),
+                      C.c_void_p(ptr(style)), 2, cin, 512)
+        close(style, g[f"c{ci}_style"])
+        y = torch.empty(2, cout, res, res)
+        noise = P["noise"].reshape(-1) if not torgb else None
+        lib.orc_modconv(C.c_void_p(ptr(x)), C.c_void_p(ptr(P["weight"])), C.c_void_p(ptr(style)), C.c_void_p(ptr(P["bias"])),
+                        C.c_void_p(ptr(noise)) if noise is not None else None,
+                        C.c_float(float(P["noise_strength"]) if not torgb else 0.0), C.c_void_p(ptr(y)),
+                        2, cin, cout, res, k, int(up), int(not torgb), int(not torgb))
+        close(y, g[f"c{ci}_y"])
