@@ -8,6 +8,11 @@
 //   MFMA: v_mfma_f32_32x32x16_bf16 (bf16 storage) or v_mfma_f32_32x32x2_f32 (f32 storage,
 //   exact f32 - the parity path); 64-wide wavefronts, 4 waves per workgroup.
 //
+//   Pipeline: one stage = one kernel ROW (3 taps) of one K chunk.  While the MFMAs of stage s run,
+//   the weight tile of stage s+1 (and, at the first row of a chunk, the next chunk's input halo
+//   tile) is in flight from L2/HBM into registers; it is written to the other LDS buffer after the
+//   MFMAs and ONE barrier closes the stage.  A and B are both double-buffered in LDS.
+//
 // Fused prologue : per-(sample, in-channel) affine a*x+b applied while staging
 //                  (StyleGAN2 style modulation s[b,i]; instance-norm apply in the encoder).
 // Fused epilogue : per-(sample, out-channel) scale (demodulation d[b,o]), noise*weight, bias,
@@ -17,6 +22,8 @@
 //
 // Reference math: model/stylegan2_generator.py:855-922 (ModulateConvBlock.forward, shared-weight
 // form :876-877,:908-909), model/E/E.py:50-85 (BEBlock.forward).
+#include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 #include "conv_params.h"
 
@@ -35,6 +42,20 @@ template <> struct Mma<float> {
     }
 };
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+template <int N, int I = 0> struct StaticFor {
+    template <class F> __device__ static __forceinline__ void run(F&& f) { f(std::integral_constant<int, I>{}); StaticFor<N, I + 1>::run(f); }
+};
+template <int N> struct StaticFor<N, N> { template <class F> __device__ static __forceinline__ void run(F&&) {} };
+
+// N uint4 values with compile-time-only indexing (keeps prefetch buffers in VGPRs: a plain array
+// indexed inside a lambda was being demoted to scratch / LDS by the compiler).
+template <int N> struct Regs {
+    uint4 v; Regs<N - 1> rest;
+    template <int I> __device__ __forceinline__ uint4& get() { if constexpr (I == 0) return v; else return rest.template get<I - 1>(); }
+};
+template <> struct Regs<0> { template <int I> __device__ __forceinline__ uint4& get(); };
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -49,14 +70,20 @@ struct ConvCfg {
     static constexpr int HALO = KS / 2;
     static constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO;
     static constexpr int RPITCH = rup(HW * PSTR, 256);
-    static constexpr int A_BYTES = HH * RPITCH;
-    static constexpr int B_BYTES = BN * PSTR;
+    static constexpr int A_BYTES = HH * RPITCH;              // one halo tile
+    static constexpr int B_BYTES = KS * BN * KCB;            // one stage: KS taps (a kernel row), rows unpadded, 16-B chunks XOR-swizzled
+    static constexpr int RP = 16 / CH;                       // weight rows per 256-byte LDS bank row
+    static constexpr int B_PIECES = B_BYTES / 1024;          // 1 KiB wave-level LDS-DMA pieces per stage
     static constexpr int ESTR = 32 * (int)sizeof(T) + 16;
     static constexpr int E_BYTES = 4 * 32 * ESTR;
-    static constexpr int LDS_BYTES = cmax(A_BYTES + 2 * B_BYTES, E_BYTES);
+    static constexpr int N_BYTES = 4 * BM * 4;                 // noise values of the tile (x4 phases in up mode)
+    static constexpr int LDS_BYTES = cmax(A_BYTES + 2 * B_BYTES, E_BYTES) + N_BYTES;
+    static constexpr int NA_ITEMS = HH * HW * CH, NA_PER = (NA_ITEMS + 255) / 256;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(MT >= 1 && NT >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-    static_assert(KCB % 32 == 0, "K chunk");
+    static_assert(KCB % 32 == 0 && 256 % CH == 0, "K chunk");
+    static_assert(B_BYTES % 1024 == 0 && BN % 16 == 0 && (BN / RP) % CH == 0, "weight stage must be whole 1 KiB pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
@@ -64,8 +91,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>;
     constexpr int EP16 = Elem<T>::PER16;
     __shared__ __attribute__((aligned(256))) unsigned char lds[C::LDS_BYTES];
-    unsigned char* ldsA = lds;
-    unsigned char* ldsB = lds + C::A_BYTES;
+    unsigned char* ldsA = lds;                         // halo tile of the current K chunk
+    unsigned char* ldsB = lds + C::A_BYTES;            // 2 weight stages
+    float* ldsN = (float*)(lds + C::LDS_BYTES - C::N_BYTES);   // noise tile, lives until the epilogue
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -87,122 +115,161 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // per-lane LDS offsets of the MFMA fragments
     int aoff[C::MT];
 #pragma unroll
     for (int i = 0; i < C::MT; i++) {
         const int m = wm * C::WTM + i * 32 + (lane & 31);
         aoff[i] = (m / TW) * C::RPITCH + (m % TW) * C::PSTR + (lane >> 5) * 16;
     }
-    int boff[C::NT];
+    int bbase[C::NT], bsw[C::NT];           // weight row byte offset and its chunk swizzle
 #pragma unroll
-    for (int j = 0; j < C::NT; j++) boff[j] = (wn * C::WTN + j * 32 + (lane & 31)) * C::PSTR + (lane >> 5) * 16;
+    for (int j = 0; j < C::NT; j++) {
+        const int n = wn * C::WTN + j * 32 + (lane & 31);
+        bbase[j] = n * C::KCB; bsw[j] = (n / C::RP) % C::CH;
+    }
 
-    constexpr int NTAP = KS * KS;
-    constexpr int NB_ITEMS = BN * C::CH;
-    constexpr int NB_PER = (NB_ITEMS + 255) / 256;
     const int nchunks = p.Cin / KC;
-    uint4 breg[NB_PER];
+    const bool affine = p.in_scale || p.in_shift;
+    const int cphys = p.in_s2d ? (p.Cin >> 2) : p.Cin;
+    const int achunk = tid % C::CH;                    // the 16-byte channel sub-range this thread stages
 
-    auto load_b = [&](int tap, int kc) {
+    Regs<C::NA_PER> areg;
+    float asc[EP16], ash[EP16];                        // affine of the chunk held in areg
+
+    // ---- input halo tile: global -> registers (zero outside the image)
+    auto load_a = [&](int kc) {
+        const int cbase = kc * KC;
+        int ph = 0, cb = cbase;
+        if (p.in_s2d) { ph = cbase / cphys; cb = cbase - ph * cphys; }
+        if (affine) {
+            const int ci = b * p.Cin + cbase + achunk * EP16;
 #pragma unroll
-        for (int i = 0; i < NB_PER; i++) {
-            const int idx = tid + i * 256;
-            if (NB_ITEMS % 256 == 0 || idx < NB_ITEMS) {
-                const int c = idx % C::CH, row = idx / C::CH;
-                const T* src = Wp + ((size_t)(tap * p.Ntot + bn0 + row) * p.Cin + kc * KC) + c * EP16;
-                breg[i] = *(const uint4*)src;
+            for (int e = 0; e < EP16; e++) {
+                asc[e] = p.in_scale ? p.in_scale[ci + e] : 1.f;
+                ash[e] = p.in_shift ? p.in_shift[ci + e] : 0.f;
             }
         }
-    };
-    auto store_b = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NB_PER; i++) {
+        StaticFor<C::NA_PER>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
             const int idx = tid + i * 256;
-            if (NB_ITEMS % 256 == 0 || idx < NB_ITEMS) {
-                const int c = idx % C::CH, row = idx / C::CH;
-                *(uint4*)(ldsB + buf * C::B_BYTES + row * C::PSTR + c * 16) = breg[i];
-            }
-        }
-    };
-
-    int buf = 0;
-    for (int kc = 0; kc < nchunks; kc++) {
-        __syncthreads();               // everyone finished reading A / B of the previous chunk
-        // ---- stage the input halo tile for this K chunk (prologue affine fused) ----
-        {
-            constexpr int ITEMS = C::HH * C::HW * C::CH;
-            static_assert(256 % C::CH == 0, "a thread keeps one channel sub-range");
-            const int cbase = kc * KC;
-            const int c = tid % C::CH;
-            const bool affine = p.in_scale || p.in_shift;
-            float sc[EP16], sh[EP16];
-            if (affine) {
-                const int ci = b * p.Cin + cbase + c * EP16;
-#pragma unroll
-                for (int e = 0; e < EP16; e++) {
-                    sc[e] = p.in_scale ? p.in_scale[ci + e] : 1.f;
-                    sh[e] = p.in_shift ? p.in_shift[ci + e] : 0.f;
-                }
-            }
-            for (int idx = tid; idx < ITEMS; idx += 256) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (C::NA_ITEMS % 256 == 0 || idx < C::NA_ITEMS) {
                 const int pix = idx / C::CH;
                 const int hx = pix % C::HW, hy = pix / C::HW;
                 const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
-                uint4 v = make_uint4(0, 0, 0, 0);
                 if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                    if (p.in_s2d) {       // logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid
-                        const int cphys = p.Cin >> 2, ph = cbase / cphys, cb = cbase - ph * cphys;
-                        v = *(const uint4*)(X + ((size_t)(b * 2 * p.H + 2 * gy + (ph >> 1)) * (2 * p.W) + 2 * gx + (ph & 1)) * cphys + cb + c * EP16);
-                    } else
-                    v = *(const uint4*)(X + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cin + cbase + c * EP16);
-                    if (affine) {
-                        float f[EP16];
-                        unpack16(v, f, (T*)nullptr);
-#pragma unroll
-                        for (int e = 0; e < EP16; e++) f[e] = f[e] * sc[e] + sh[e];
-                        v = pack16(f, (T*)nullptr);
-                    }
+                    if (p.in_s2d)     // logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid
+                        v = *(const uint4*)(X + ((size_t)(b * 2 * p.H + 2 * gy + (ph >> 1)) * (2 * p.W) + 2 * gx + (ph & 1)) * cphys + cb + achunk * EP16);
+                    else
+                        v = *(const uint4*)(X + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cin + cbase + achunk * EP16);
                 }
-                *(uint4*)(ldsA + hy * C::RPITCH + hx * C::PSTR + c * 16) = v;
             }
+            areg.template get<i>() = v;
+        });
+    };
+    // ---- registers -> LDS with the fused per-(b,c) affine (inside the image only)
+    auto store_a = [&]() {
+        StaticFor<C::NA_PER>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int idx = tid + i * 256;
+            if (C::NA_ITEMS % 256 == 0 || idx < C::NA_ITEMS) {
+                const int pix = idx / C::CH;
+                const int hx = pix % C::HW, hy = pix / C::HW;
+                uint4 v = areg.template get<i>();
+                const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
+                if (affine && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {     // padding stays zero
+                    float f[EP16];
+                    unpack16(v, f, (T*)nullptr);
+#pragma unroll
+                    for (int e = 0; e < EP16; e++) f[e] = f[e] * asc[e] + ash[e];
+                    v = pack16(f, (T*)nullptr);
+                }
+                *(uint4*)(ldsA + hy * C::RPITCH + hx * C::PSTR + achunk * 16) = v;
+            }
+        });
+    };
+    // ---- weight stage (kernel row `row` of chunk kc): KS taps x BN rows x KC, global -> LDS directly
+    // (global_load_lds: no VGPR round trip; the LDS image is lane-linear per 1 KiB piece, so the
+    // bank-conflict swizzle is applied to the per-lane SOURCE chunk and undone by the fragment reads)
+    auto dma_b = [&](int kc, int row, int buf) {
+        constexpr int RPP = 1024 / C::KCB;                   // weight rows per piece
+        for (int pc = wave; pc < C::B_PIECES; pc += 4) {
+            const int r = pc * RPP + lane / C::CH;           // row within the stage = t*BN + n
+            const int c = (lane % C::CH) ^ ((r / C::RP) % C::CH);
+            const int t = r / BN, n = r % BN;
+            const T* src = Wp + ((size_t)((row * KS + t) * p.Ntot + bn0 + n) * p.Cin + kc * KC) + c * EP16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ldsB + buf * C::B_BYTES + pc * 1024), 16, 0, 0);
         }
-        load_b(0, kc);
-        for (int tap = 0; tap < NTAP; tap++) {
-            store_b(buf);
-            __syncthreads();
-            if (tap + 1 < NTAP) load_b(tap + 1, kc);      // global loads fly under the MFMAs
-            const int tapoff = (tap / KS) * C::RPITCH + (tap % KS) * C::PSTR;
-            const unsigned char* bb = ldsB + buf * C::B_BYTES;
+    };
+
+    // ---- prologue: first halo tile, first weight stage, noise tile
+    dma_b(0, 0, 0);
+    load_a(0);
+    if (p.noise) {
+        const int OHn = p.up ? 2 * p.H : p.H, OWn = p.up ? 2 * p.W : p.W;
+        const int nph = p.up ? 4 : 1;
+        for (int idx = tid; idx < nph * C::BM; idx += 256) {
+            const int m = idx % C::BM, ph = idx / C::BM;
+            const int gy = y0 + m / TW, gx = x0 + m % TW;
+            const int oy = p.up ? 2 * gy + (ph >> 1) : gy, ox = p.up ? 2 * gx + (ph & 1) : gx;
+            ldsN[idx] = (gy < p.H && gx < p.W) ? p.noise[(size_t)b * p.noise_bstride + (size_t)oy * OWn + ox] : 0.f;
+        }
+    }
+    store_a();
+    __syncthreads();
+
+    const int nstages = nchunks * KS;
+    int sbuf = 0;
+    for (int s = 0; s < nstages; s++) {
+        const int kc = s / KS, row = s - kc * KS;
+        const bool has_next = s + 1 < nstages;
+        const int nkc = (s + 1) / KS, nrow = (s + 1) - nkc * KS;
+        if (has_next && !(p.dbg & 1)) dma_b(nkc, nrow, sbuf ^ 1);   // lands under the MFMAs below
+        if (row == 0 && kc + 1 < nchunks && !(p.dbg & 1)) load_a(kc + 1);   // consumed after the last row of this chunk
+        const unsigned char* aa = ldsA + row * C::RPITCH;
+        const unsigned char* bb = ldsB + sbuf * C::B_BYTES;
+        if (!(p.dbg & 2))
+#pragma unroll
+        for (int t = 0; t < KS; t++) {
 #pragma unroll
             for (int ks = 0; ks < C::KCB / 32; ks++) {
                 uint4 af[C::MT], bf[C::NT];
 #pragma unroll
-                for (int i = 0; i < C::MT; i++) af[i] = *(const uint4*)(ldsA + aoff[i] + tapoff + ks * 32);
+                for (int i = 0; i < C::MT; i++) af[i] = *(const uint4*)(aa + aoff[i] + t * C::PSTR + ks * 32);
 #pragma unroll
-                for (int j = 0; j < C::NT; j++) bf[j] = *(const uint4*)(bb + boff[j] + ks * 32);
+                for (int j = 0; j < C::NT; j++)
+                    bf[j] = *(const uint4*)(bb + t * BN * C::KCB + bbase[j] + (((ks * 2 + (lane >> 5)) ^ bsw[j]) << 4));
 #pragma unroll
                 for (int i = 0; i < C::MT; i++)
 #pragma unroll
                     for (int j = 0; j < C::NT; j++) Mma<T>::run(af[i], bf[j], acc[i][j]);
             }
-            buf ^= 1;
         }
+        __syncthreads();                                       // drains the LDS-DMA and closes the stage
+        if (row == KS - 1 && kc + 1 < nchunks) {               // chunk boundary: replace the halo tile
+            store_a();
+            __syncthreads();
+        }
+        sbuf ^= 1;
     }
-    __syncthreads();   // LDS is re-used as the epilogue transpose buffer from here
+    // LDS is re-used as the epilogue transpose buffer from here (all reads done: barrier above)
 
     // ---------------------------------------------------------------- epilogue
-    unsigned char* est = lds + wave * (32 * C::ESTR);
+    // NOTE: every accumulator index below is a compile-time constant (StaticFor): a run-time index
+    // into acc[][] would push the whole accumulator file to scratch on every main-loop iteration.
+    unsigned char* est = lds + wave * (32 * C::ESTR);     // (the noise tile at the end of `lds` stays valid)
     const int OH = p.up ? 2 * p.H : p.H, OW = p.up ? 2 * p.W : p.W;
     T* __restrict__ Y = (T*)p.y;
     const T* __restrict__ ADD = (const T*)p.addend;
     const T* __restrict__ DOT = (const T*)p.dot_src;
     constexpr int CPR = 32 / EP16;              // 16-byte chunks per 32-channel row
     constexpr int PPP = 64 / CPR;               // pixels per read-back pass
-#pragma unroll
-    for (int j = 0; j < C::NT; j++) {
+    if (!(p.dbg & 4))
+    StaticFor<C::NT>::run([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         const int n0 = bn0 + wn * C::WTN + j * 32;          // first N of this 32-wide tile
-        if (n0 >= p.Ntot_valid) continue;                   // wave-uniform
+        if (n0 >= p.Ntot_valid) return;                     // wave-uniform
         const int phase = p.up ? n0 / p.Cout : 0;
         const int o0 = p.up ? n0 % p.Cout : n0;
         const int py = phase >> 1, px = phase & 1;
@@ -212,10 +279,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale : 0.f;
         const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] : 0.f;
         float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-        for (int i = 0; i < C::MT; i++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
+        StaticFor<C::MT>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const f32x16_t a = acc[i][j];
+            StaticFor<16>::run([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
                 const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int m = wm * C::WTM + i * 32 + ml;
                 const int gy = y0 + m / TW, gx = x0 + m % TW;
@@ -224,18 +292,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 if (DOT) {            // reductions of the raw accumulator (data-gradient statistics)
                     if (pvalid && ovalid) {
                         const float dv = Elem<T>::ld(DOT + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o);
-                        ssum += acc[i][j][r] * dv; ssq += acc[i][j][r];
+                        ssum += a[r] * dv; ssq += a[r];
                     }
                 }
-                float v = acc[i][j][r] * osc;
-                if (p.noise && pvalid) v += nw * p.noise[(size_t)b * p.noise_bstride + (size_t)oy * OW + ox];
+                float v = a[r] * osc;
+                if (p.noise) v += nw * ldsN[phase * C::BM + m];
                 v += bia;
                 v = act_apply(v, p.act) * p.gain;
                 if (ADD && pvalid && ovalid)
                     v += p.add_scale * Elem<T>::ld(ADD + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o);
                 if (pvalid && !DOT) { ssum += v; ssq += v * v; }
                 Elem<T>::st((T*)(est + ml * C::ESTR) + (lane & 31), v);
-            }
+            });
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < 32 / PPP; q++) {
@@ -249,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 }
             }
             __builtin_amdgcn_wave_barrier();
-        }
+        });
         if (p.stats) {
             ssum += __shfl_xor(ssum, 32, 64);
             ssq += __shfl_xor(ssq, 32, 64);
@@ -258,13 +326,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 atomicAdd(p.stats + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
             }
         }
-    }
+    });
 }
 
 // ------------------------------------------------------------------------- dispatch
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
 static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
+    { const char* e = getenv("DGE_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     const int ntiles = (p.Ntot + BN - 1) / BN;
@@ -274,32 +343,29 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     return 0;
 }
 
-// N-tile width the launcher will use for a given Ntot (the packer pads Ntot to this).
+// N-tile width the packer pads to (the launcher uses this or a divisor of it).
 extern "C" int dge_conv_ntile(int ntot) { return ntot >= 128 ? 128 : (ntot > 32 ? 64 : 32); }
-// K-chunk (elements) the launcher will use for a given Cin / dtype.
-static int kchunk(int cin, int esize) {
-    const int maxkc = 128 / esize;
-    if (cin % maxkc == 0) return maxkc;
-    if (cin % (maxkc / 2) == 0) return maxkc / 2;
-    return maxkc / 4;
-}
+// K-chunk (elements): 64 bytes when the channel count allows it, else 32 bytes.
+static int kchunk(int cin, int esize) { return cin % (64 / esize) == 0 ? 64 / esize : 32 / esize; }
 
 template <typename T, int KS>
 static int launch_t(const ConvParams& p, hipStream_t s) {
     constexpr int E = (int)sizeof(T);
-    constexpr int K0 = 128 / E, K1 = 64 / E, K2 = 32 / E;
-    const int bn = dge_conv_ntile(p.Ntot);
+    constexpr int K0 = 64 / E, K1 = 32 / E;
+    int bn = dge_conv_ntile(p.Ntot);
+    if (bn > 64) bn = 64;        // 64-wide N tiles keep 2 workgroups per CU (measured faster than 128: 83 vs 107 us on 256->256 @128^2)
+    { const char* e = getenv("DGE_CONV_BN"); if (e) bn = atoi(e); }
     const int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
-    const bool small = (p.H <= 8 && p.W <= 8) || ((long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn) < 256L * 256);
+    const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
+    const bool small = (p.H <= 8 && p.W <= 8) || work < 256L * 256;
 #define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
-    if (small) {           // 8x8 pixel tiles: more workgroups for the low-resolution layers
-        if (bn == 128) { if (kc == K0) GO(8, 8, 128, K0, 1, 4); if (kc == K1) GO(8, 8, 128, K1, 1, 4); GO(8, 8, 128, K2, 1, 4); }
-        if (bn == 64)  { if (kc == K0) GO(8, 8, 64, K0, 2, 2);  if (kc == K1) GO(8, 8, 64, K1, 2, 2);  GO(8, 8, 64, K2, 2, 2); }
-        if (kc == K0) GO(8, 16, 32, K0, 4, 1); if (kc == K1) GO(8, 16, 32, K1, 4, 1); GO(8, 16, 32, K2, 4, 1);
+    if (small) {           // 8x8 pixel tiles, narrower N tiles: more workgroups for the low-resolution layers
+        if (bn >= 64) { if (kc == K0) GO(8, 8, 64, K0, 2, 2); GO(8, 8, 64, K1, 2, 2); }
+        if (kc == K0) GO(8, 16, 32, K0, 4, 1); GO(8, 16, 32, K1, 4, 1);
     }
-    if (bn == 128) { if (kc == K0) GO(16, 16, 128, K0, 2, 2); if (kc == K1) GO(16, 16, 128, K1, 2, 2); GO(16, 16, 128, K2, 2, 2); }
-    if (bn == 64)  { if (kc == K0) GO(16, 16, 64, K0, 4, 1);  if (kc == K1) GO(16, 16, 64, K1, 4, 1);  GO(16, 16, 64, K2, 4, 1); }
-    if (kc == K0) GO(16, 16, 32, K0, 4, 1); if (kc == K1) GO(16, 16, 32, K1, 4, 1); GO(16, 16, 32, K2, 4, 1);
+    if (bn == 128) { if (kc == K0) GO(16, 16, 128, K0, 2, 2); GO(16, 16, 128, K1, 2, 2); }
+    if (bn == 64)  { if (kc == K0) GO(16, 16, 64, K0, 4, 1);  GO(16, 16, 64, K1, 4, 1); }
+    if (kc == K0) GO(16, 16, 32, K0, 4, 1); GO(16, 16, 32, K1, 4, 1);
 #undef GO
 }
 

@@ -25,6 +25,7 @@ struct ConvParams {
     int act;
     float bias_scale, gain, add_scale;
     int tiles_x, tiles_y;     // filled by the launcher
+    int dbg;                  // ablation switches for tuning (DGE_CONV_DBG), 0 in production
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);

@@ -97,39 +97,67 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ gy, const T* __restrict
 
 // LPIPS head for one tap.  f: [2B,h,w,C] T (samples [0,B) = image a, [B,2B) = image b), lin [C] f32.
 // val[b] (pre-zeroed) += (1/(h*w)) sum_p sum_c lin_c (n0_c - n1_c)^2,  n = f / (||f||_2 + 1e-10)
-// g1 (optional, [B,h,w,C] T) = gscale * d val[b] / d f[B+b]        (one wavefront per pixel)
-template <typename T>
+// g1 (optional, [B,h,w,C] T) = gscale * d val[b] / d f[B+b]
+// LPP = min(64, C/EP) lanes cooperate on one pixel with 16-byte loads; a wave walks PPW pixels per
+// iteration and a block walks a contiguous pixel range of ONE sample, so val gets one atomic per wave.
+template <typename T, int NJ>
 __global__ __launch_bounds__(256) void lpips_head_kernel(const T* __restrict__ f, const float* __restrict__ lin,
                                                           float* __restrict__ val, T* __restrict__ g1, int B, int HW, int C,
-                                                          float gscale) {
-    const int lane = threadIdx.x & 63;
-    const long pix = blockIdx.x * 4L + (threadIdx.x >> 6);
-    if (pix >= (long)B * HW) return;
-    const int b = pix / HW;
-    const T* f0 = f + (size_t)pix * C;
-    const T* f1 = f + ((size_t)B * HW + pix) * C;
-    float s0 = 0.f, s1 = 0.f;
-    for (int c = lane; c < C; c += 64) { const float a = Elem<T>::ld(f0 + c), bq = Elem<T>::ld(f1 + c); s0 += a * a; s1 += bq * bq; }
-    s0 = wave_sum(s0); s1 = wave_sum(s1);
-    const float n0 = sqrtf(s0), n1 = sqrtf(s1), r0 = 1.f / (n0 + 1e-10f), r1 = 1.f / (n1 + 1e-10f);
-    float d = 0.f, dot = 0.f;                     // dot = sum_c gn1_c * f1_c
-    for (int c = lane; c < C; c += 64) {
-        const float a = Elem<T>::ld(f0 + c) * r0, bv = Elem<T>::ld(f1 + c), bq = bv * r1, u = a - bq, l = lin[c];
-        d += l * u * u;
-        dot += (-2.f * l * u) * bv;
-    }
-    d = wave_sum(d); dot = wave_sum(dot);
+                                                          float gscale, int lpp, int pix_per_block) {
+    constexpr int EP = Elem<T>::PER16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int ppw = 64 / lpp, sub = lane / lpp, li = lane % lpp;
+    const int p_begin = blockIdx.x * pix_per_block, p_end = min(HW, p_begin + pix_per_block);
+    float linv[NJ][EP];
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int e = 0; e < EP; e++) linv[j][e] = lin[(j * lpp + li) * EP + e];
     const float inv_hw = 1.f / (float)HW;
-    if (lane == 0) atomicAdd(val + b, d * inv_hw);
-    if (g1) {
-        T* gp = g1 + (size_t)pix * C;
-        const float k = n1 > 0.f ? dot * r1 * r1 / n1 : 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float a = Elem<T>::ld(f0 + c) * r0, bv = Elem<T>::ld(f1 + c), u = a - bv * r1;
-            const float gn = -2.f * lin[c] * u;
-            Elem<T>::st(gp + c, gscale * inv_hw * (gn * r1 - bv * k));
+    float dacc = 0.f;
+    for (int p0 = p_begin + wave * ppw; p0 < p_end; p0 += 4 * ppw) {
+        const int p = p0 + sub;
+        const bool ok = p < p_end;
+        const size_t o0 = ((size_t)b * HW + (ok ? p : p_begin)) * C, o1 = ((size_t)(B + b) * HW + (ok ? p : p_begin)) * C;
+        float a[NJ][EP], bv[NJ][EP];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            unpack16(*(const uint4*)(f + o0 + (j * lpp + li) * EP), a[j], (T*)nullptr);
+            unpack16(*(const uint4*)(f + o1 + (j * lpp + li) * EP), bv[j], (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < EP; e++) { s0 += a[j][e] * a[j][e]; s1 += bv[j][e] * bv[j][e]; }
+        }
+        for (int m = lpp >> 1; m > 0; m >>= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
+        const float n1 = sqrtf(s1), r0 = 1.f / (sqrtf(s0) + 1e-10f), r1 = 1.f / (n1 + 1e-10f);
+        float d = 0.f, dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                const float u = a[j][e] * r0 - bv[j][e] * r1;
+                d += linv[j][e] * u * u;
+                dot += (-2.f * linv[j][e] * u) * bv[j][e];
+            }
+        for (int m = lpp >> 1; m > 0; m >>= 1) { d += __shfl_xor(d, m, 64); dot += __shfl_xor(dot, m, 64); }
+        if (ok && li == 0) dacc += d;
+        if (g1 && ok) {
+            const float k = n1 > 0.f ? dot * r1 * r1 / n1 : 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                float g[EP];
+#pragma unroll
+                for (int e = 0; e < EP; e++) {
+                    const float u = a[j][e] * r0 - bv[j][e] * r1;
+                    g[e] = gscale * inv_hw * ((-2.f * linv[j][e] * u) * r1 - bv[j][e] * k);
+                }
+                *(uint4*)(g1 + ((size_t)b * HW + p) * C + (j * lpp + li) * EP) = pack16(g, (T*)nullptr);
+            }
         }
     }
+    dacc = wave_sum(dacc);
+    if (lane == 0 && dacc != 0.f) atomicAdd(val + b, dacc * inv_hw);
 }
 
 // out[0] = mean_b val[b]
@@ -181,11 +209,27 @@ extern "C" int dge_maxpool2_bwd(const void* gy, const void* x, const void* adden
     return 0;
 }
 
+template <typename T>
+static int lpips_head_launch(const void* feat, const float* lin, float* val, void* g1, int B, int HW, int C, float gscale, hipStream_t s) {
+    constexpr int EP = Elem<T>::PER16;
+    const int chunks = C / EP;
+    const int lpp = chunks >= 64 ? 64 : chunks;          // power of two for C in {64,128,256,512}
+    const int nj = chunks / lpp;
+    int ppb = 4 * (64 / lpp) * 8;                         // 8 iterations per wave
+    dim3 grid((HW + ppb - 1) / ppb, B);
+#define LH(NJ) hipLaunchKernelGGL((lpips_head_kernel<T, NJ>), grid, dim3(256), 0, s, (const T*)feat, lin, val, (T*)g1, B, HW, C, gscale, lpp, ppb)
+    if (nj == 1) LH(1); else if (nj == 2) LH(2); else if (nj == 4) LH(4); else { dge_set_error("lpips_head: unsupported C=%d", C); return -1; }
+#undef LH
+    return 0;
+}
+
 extern "C" int dge_lpips_head(const void* feat, const float* lin, float* val, void* g1, int B, int HW, int C, float gscale,
                               int dtype, hipStream_t s) {
-    const long npix = (long)B * HW;
-    if (dtype == DGE_BF16) hipLaunchKernelGGL(lpips_head_kernel<bf16_t>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, (const bf16_t*)feat, lin, val, (bf16_t*)g1, B, HW, C, gscale);
-    else hipLaunchKernelGGL(lpips_head_kernel<float>, dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, s, (const float*)feat, lin, val, (float*)g1, B, HW, C, gscale);
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && ((C / ep) & (C / ep - 1)) == 0, "lpips_head: C=%d must be a power-of-two multiple of %d", C, ep);
+    const int rc = dtype == DGE_BF16 ? lpips_head_launch<bf16_t>(feat, lin, val, g1, B, HW, C, gscale, s)
+                                      : lpips_head_launch<float>(feat, lin, val, g1, B, HW, C, gscale, s);
+    if (rc) return rc;
     DGE_LAUNCH_CHECK("lpips_head");
     return 0;
 }

@@ -54,18 +54,35 @@ __global__ void demod_bwd_kernel(const float* __restrict__ R, const float* __res
 }
 
 // y[b*ldy + k*incy] (+)= scale * mul[b,k] * sum_o x[b*ldx + o*incx] * W[o,k]
-__global__ void linear_t_kernel(const float* __restrict__ x, int ldx, int incx, const float* __restrict__ W,
+// block = 4 waves: lanes own 64 consecutive k (coalesced W rows), waves split the o range, LDS combine.
+__global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__ x, int ldx, int incx, const float* __restrict__ W,
                                 const float* __restrict__ mul, float* __restrict__ y, int ldy, int incy, int B, int O, int K,
                                 float scale, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= B * K) return;
-    const int b = idx / K, k = idx % K;
-    float s = 0.f;
-    for (int o = 0; o < O; o++) s += x[(size_t)b * ldx + (size_t)o * incx] * W[(size_t)o * K + k];
-    s *= scale;
-    if (mul) s *= mul[(size_t)b * K + k];
-    float* yp = y + (size_t)b * ldy + (size_t)k * incy;
-    *yp = accumulate ? *yp + s : s;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, b = blockIdx.y;
+    const int per = (O + 3) / 4, o0 = wave * per, o1 = min(O, o0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (k < K) {
+        const float* xr = x + (size_t)b * ldx;
+        int o = o0;
+        for (; o + 3 < o1; o += 4) {
+            s0 += xr[(size_t)o * incx] * W[(size_t)o * K + k];
+            s1 += xr[(size_t)(o + 1) * incx] * W[(size_t)(o + 1) * K + k];
+            s2 += xr[(size_t)(o + 2) * incx] * W[(size_t)(o + 2) * K + k];
+            s3 += xr[(size_t)(o + 3) * incx] * W[(size_t)(o + 3) * K + k];
+        }
+        for (; o < o1; o++) s0 += xr[(size_t)o * incx] * W[(size_t)o * K + k];
+    }
+    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wave == 0 && k < K) {
+        float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        s *= scale;
+        if (mul) s *= mul[(size_t)b * K + k];
+        float* yp = y + (size_t)b * ldy + (size_t)k * incy;
+        *yp = accumulate ? *yp + s : s;
+    }
 }
 
 // toRGB backward: t_i = wscale * sum_c g[b,c,p] Wrgb[c,i];  gx[b,p,i] = t_i * s[b,i];  gs[b,i] += sum_p t_i x[b,p,i]
@@ -154,7 +171,7 @@ extern "C" int dge_demod_bwd(const float* R, const float* d, const float* bias, 
 
 extern "C" int dge_linear_t(const float* x, int ldx, int incx, const float* w, const float* mul, float* y, int ldy, int incy,
                             int B, int O, int K, float scale, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(linear_t_kernel, dim3((B * K + 255) / 256), dim3(256), 0, s, x, ldx, incx, w, mul, y, ldy, incy, B, O, K, scale, accumulate);
+    hipLaunchKernelGGL(linear_t_kernel, dim3((K + 63) / 64, B), dim3(256), 0, s, x, ldx, incx, w, mul, y, ldy, incy, B, O, K, scale, accumulate);
     DGE_LAUNCH_CHECK("linear_t");
     return 0;
 }
