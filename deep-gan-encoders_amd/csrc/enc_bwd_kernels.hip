@@ -7,34 +7,13 @@
 
 // ------------------------------------------------------------------ conv weight gradient
 // dW[o][i][tap] += sum_{b,p} g[b,p,o] * Xn[b,p+tap,i],  Xn = X*sc[b,i] + sh[b,i] inside the image, 0 outside.
-// GEMM view: M = o (32 per block), N = i (32 per block), K = pixels.  One MFMA K-step = one 16-pixel
-// tile row; activations stay NHWC in LDS and K-contiguous fragments are gathered with 16-bit LDS
-// reads (bf16) or single dword reads (f32).
-template <typename T> struct WgMma;
-template <> struct WgMma<bf16_t> {
-    static constexpr int KSTEP = 16;                  // pixels per MFMA
-    // lane (m = l&31, kg = l>>5) gathers 8 pixels kg*8..kg*8+7 of channel m
-    __device__ static __forceinline__ uint4 gather(const bf16_t* base, int pix_stride_elems, int kg) {
-        const bf16_t* p = base + (size_t)(kg * 8) * pix_stride_elems;
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            w[j] = (uint32_t)p[(2 * j) * pix_stride_elems] | ((uint32_t)p[(2 * j + 1) * pix_stride_elems] << 16);
-        return make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    __device__ static __forceinline__ void mma(const uint4& a, const uint4& b, f32x16_t& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, c, 0, 0, 0);
-    }
-};
-template <> struct WgMma<float> {
-    static constexpr int KSTEP = 16;                  // processed as 8 x (32x32x2)
-    __device__ static __forceinline__ void run16(const float* abase, const float* bbase, int astr, int bstr, int kg, f32x16_t& c) {
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            c = __builtin_amdgcn_mfma_f32_32x32x2f32(abase[(size_t)(2 * j + kg) * astr], bbase[(size_t)(2 * j + kg) * bstr], c, 0, 0, 0);
-    }
-};
-
+// GEMM view: M = o (32 per block), N = i (32 per block), K = pixels of an 8x16 tile.
+// MFMA wants K-contiguous fragments but NHWC has the channels contiguous, so both tiles are
+// TRANSPOSED on their way into LDS ([channel][row][col], 16-bit scatter writes) and fragments are
+// read with aligned 16-byte LDS reads.  The three x-shifts of a kernel row are produced in
+// registers from one aligned window (v_alignbit for dx=1, register renaming for dx=2), so one
+// window read feeds 3 MFMAs.  Each wave owns two tile rows and ALL taps (9 accumulator tiles), the
+// g fragment of a row is reused by its 9 taps; waves never exchange data and flush with f32 atomics.
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ X,
                                                           const float* __restrict__ sc, const float* __restrict__ sh,
@@ -42,33 +21,44 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
                                                           int tiles_x, int tiles_y, int ntile_groups) {
     constexpr int TH = 8, TW = 16, HALO = KS / 2, HH = TH + 2 * HALO, HW = TW + 2 * HALO;
     constexpr int EP = Elem<T>::PER16;
-    constexpr int CSTR = 32 + EP;                       // elements per pixel row in LDS (padded)
+    constexpr int ES = (int)sizeof(T);
     constexpr int NTAP = KS * KS;
-    constexpr int TPW = (NTAP + 3) / 4;                 // taps per wave (KS=3: 3,2,2,2)
-    __shared__ __attribute__((aligned(16))) T lg[TH * TW * CSTR];
-    __shared__ __attribute__((aligned(16))) T lx[HH * HW * CSTR];
+    constexpr int GPIT = TH * TW + 16 / ES;              // g^T: elements per channel (padded, 16-B multiple)
+    constexpr int XROW = 24 * 2 / ES >= 24 ? 24 : 24;     // x^T: elements per halo row (>= HW + 2, 16-B multiple)
+    constexpr int XPIT = HH * XROW + 16 / ES;            // x^T: elements per channel
+    constexpr int LG_BYTES = 32 * GPIT * ES, LX_BYTES = 32 * XPIT * ES;
+    constexpr int SM_BYTES = (LG_BYTES + LX_BYTES) > 16384 ? (LG_BYTES + LX_BYTES) : 16384;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
+    T* lg = (T*)smem;
+    T* lx = (T*)(smem + LG_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_it = (Ci + 31) / 32;
     const int o0 = (blockIdx.x / n_it) * 32, i0 = (blockIdx.x % n_it) * 32;
-    f32x16_t acc[TPW];
+    f32x16_t acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < TPW; t++)
+    for (int t = 0; t < NTAP; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     const int ntiles = tiles_x * tiles_y * B;
-    constexpr int CPR = 32 / EP;                        // 16-byte chunks per 32-channel row
+    constexpr int CPR = 32 / EP;                        // 16-byte channel chunks per 32-channel slab
+    const int m = lane & 31, kg = lane >> 5;
     for (int tile = blockIdx.y; tile < ntiles; tile += ntile_groups) {
         const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx_i * TW, y0 = ty_i * TH;
         __syncthreads();
-        for (int idx = tid; idx < TH * TW * CPR; idx += 256) {       // gradient tile
-            const int c = idx % CPR, pix = idx / CPR, gy = y0 + pix / TW, gx = x0 + pix % TW;
+        // ---- gradient tile, transposed: consecutive lanes take consecutive pixels of one channel chunk
+        for (int idx = tid; idx < TH * TW * CPR; idx += 256) {
+            const int pix = idx % (TH * TW), c = idx / (TH * TW), gy = y0 + pix / TW, gx = x0 + pix % TW;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (gy < H && gx < W && o0 + c * EP < Co) v = *(const uint4*)(g + ((size_t)(b * H + gy) * W + gx) * Co + o0 + c * EP);
-            *(uint4*)(lg + pix * CSTR + c * EP) = v;
+            const T* e = (const T*)&v;
+#pragma unroll
+            for (int q = 0; q < EP; q++) lg[(c * EP + q) * GPIT + pix] = e[q];
         }
-        for (int idx = tid; idx < HH * HW * CPR; idx += 256) {       // normalised input halo tile
-            const int c = idx % CPR, pix = idx / CPR, gy = y0 + pix / HW - HALO, gx = x0 + pix % HW - HALO;
+        // ---- normalised input halo tile, transposed
+        for (int idx = tid; idx < HH * HW * CPR; idx += 256) {
+            const int pix = idx % (HH * HW), c = idx / (HH * HW), hy = pix / HW, hx = pix % HW;
+            const int gy = y0 + hy - HALO, gx = x0 + hx - HALO;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (gy >= 0 && gy < H && gx >= 0 && gx < W && i0 + c * EP < Ci) {
                 v = *(const uint4*)(X + ((size_t)(b * H + gy) * W + gx) * Ci + i0 + c * EP);
@@ -76,63 +66,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
                     float f[EP];
                     unpack16(v, f, (T*)nullptr);
 #pragma unroll
-                    for (int e = 0; e < EP; e++) {
-                        const int ci = b * Ci + i0 + c * EP + e;
-                        f[e] = f[e] * sc[ci] + sh[ci];
+                    for (int q = 0; q < EP; q++) {
+                        const int ci = b * Ci + i0 + c * EP + q;
+                        f[q] = f[q] * sc[ci] + sh[ci];
                     }
                     v = pack16(f, (T*)nullptr);
                 }
             }
-            *(uint4*)(lx + pix * CSTR + c * EP) = v;
+            const T* e = (const T*)&v;
+#pragma unroll
+            for (int q = 0; q < EP; q++) lx[(c * EP + q) * XPIT + hy * XROW + hx] = e[q];
         }
         __syncthreads();
-        const int m = lane & 31, kg = lane >> 5;
-        if (KS == 3) {
+        // ---- MFMA: wave w owns tile rows {2w, 2w+1}
 #pragma unroll
-            for (int t = 0; t < TPW; t++) {
-                const int tap = wave + 4 * t;
-                if (tap < NTAP) {
-                    const int dy = tap / 3, dx = tap % 3;
+        for (int rr = 0; rr < 2; rr++) {
+            const int row = 2 * wave + rr;
+            if constexpr (sizeof(T) == 2) {
+                const uint4 a = *(const uint4*)(lg + m * GPIT + row * TW + kg * 8);
 #pragma unroll
-                    for (int ks = 0; ks < TH; ks++) {                  // one 16-pixel row per MFMA K-step
-                        const T* ab = lg + (ks * TW) * CSTR + m;
-                        const T* bb = lx + ((ks + dy) * HW + dx) * CSTR + m;
-                        if constexpr (sizeof(T) == 2) {
-                            const uint4 a = WgMma<bf16_t>::gather((const bf16_t*)ab, CSTR, kg);
-                            const uint4 bq = WgMma<bf16_t>::gather((const bf16_t*)bb, CSTR, kg);
-                            WgMma<bf16_t>::mma(a, bq, acc[t]);
-                        } else {
-                            WgMma<float>::run16((const float*)ab, (const float*)bb, CSTR, CSTR, kg, acc[t]);
-                        }
+                for (int dy = 0; dy < KS; dy++) {
+                    const T* xr = lx + m * XPIT + (row + dy) * XROW + kg * 8;
+                    const uint4 v0 = *(const uint4*)xr;
+                    if constexpr (KS == 3) {
+                        const uint32_t v1 = *(const uint32_t*)(xr + 8);
+                        const uint4 b1 = make_uint4(__builtin_amdgcn_alignbit(v0.y, v0.x, 16), __builtin_amdgcn_alignbit(v0.z, v0.y, 16),
+                                                    __builtin_amdgcn_alignbit(v0.w, v0.z, 16), __builtin_amdgcn_alignbit(v1, v0.w, 16));
+                        const uint4 b2 = make_uint4(v0.y, v0.z, v0.w, v1);
+                        acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&v0, acc[dy * 3 + 0], 0, 0, 0);
+                        acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b1, acc[dy * 3 + 1], 0, 0, 0);
+                        acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b2, acc[dy * 3 + 2], 0, 0, 0);
+                    } else {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&v0, acc[0], 0, 0, 0);
                     }
                 }
-            }
-        } else {                                                       // 1x1: waves split the pixel rows
+            } else {
+                // f32: MFMA step j contracts pixels (j, j+8) of the row: lane half kg reads 8 consecutive floats
+                const float* ar = (const float*)lg + m * GPIT + row * TW + kg * 8;
+                float af[8];
+                *(uint4*)&af[0] = *(const uint4*)ar; *(uint4*)&af[4] = *(const uint4*)(ar + 4);
 #pragma unroll
-            for (int q = 0; q < TH / 4; q++) {
-                const int ks = wave + 4 * q;
-                const T* ab = lg + (ks * TW) * CSTR + m;
-                const T* bb = lx + (ks * HW) * CSTR + m;
-                if constexpr (sizeof(T) == 2) {
-                    const uint4 a = WgMma<bf16_t>::gather((const bf16_t*)ab, CSTR, kg);
-                    const uint4 bq = WgMma<bf16_t>::gather((const bf16_t*)bb, CSTR, kg);
-                    WgMma<bf16_t>::mma(a, bq, acc[0]);
-                } else {
-                    WgMma<float>::run16((const float*)ab, (const float*)bb, CSTR, CSTR, kg, acc[0]);
+                for (int dy = 0; dy < KS; dy++) {
+                    const float* xr = (const float*)lx + m * XPIT + (row + dy) * XROW + kg * 8;
+                    float xf[12];
+                    *(uint4*)&xf[0] = *(const uint4*)xr; *(uint4*)&xf[4] = *(const uint4*)(xr + 4);
+                    if constexpr (KS == 3) *(uint4*)&xf[8] = *(const uint4*)(xr + 8);
+#pragma unroll
+                    for (int dx = 0; dx < KS; dx++)
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            acc[dy * KS + dx] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], xf[j + dx], acc[dy * KS + dx], 0, 0, 0);
                 }
             }
         }
     }
-    // flush: D[m = o][n = i]
+    // ---- flush: combine the 4 waves' partial tiles in LDS, then ONE f32 atomic per output element per block
+    // (atomics to the small dW array are the scarce resource: keep their count ~ blocks * Co*Ci*taps)
+    float* red = (float*)smem;                            // 4 x 1024 floats, re-uses the tile storage
 #pragma unroll
-    for (int t = 0; t < TPW; t++) {
-        const int tap = KS == 3 ? wave + 4 * t : 0;
-        if (tap >= NTAP) continue;
-        const int i = i0 + (lane & 31);
+    for (int t = 0; t < NTAP; t++) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (o < Co && i < Ci) atomicAdd(dW + ((size_t)o * Ci + i) * NTAP + tap, acc[t][r]);
+        for (int r = 0; r < 16; r++) red[wave * 1024 + r * 64 + lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = tid + q * 256;                  // e = r*64 + lane'
+            const int r = e >> 6, ln = e & 63;
+            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), i = i0 + (ln & 31);
+            const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+            if (o < Co && i < Ci) atomicAdd(dW + ((size_t)o * Ci + i) * NTAP + t, v);
         }
     }
 }
@@ -326,7 +329,7 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     const int tx = (W + 15) / 16, ty = (H + 7) / 8;
     const int ntiles = tx * ty * B;
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
-    int groups = 2048 / noi; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;
+    int groups = 512 / noi; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;   // few, long-running workgroups: one atomic flush each
     dim3 grid(noi, groups);
 #define WG(T, KS) hipLaunchKernelGGL((conv_wgrad_kernel<T, KS>), grid, dim3(256), 0, s, (const T*)g, (const T*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups)
     if (dtype == DGE_BF16) { if (ksize == 3) WG(bf16_t, 3); else WG(bf16_t, 1); }
