@@ -34,5 +34,20 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.noise_w_stride = d->noise_w_per_channel ? 1 : 0;
     p.act = d->act; p.bias_scale = d->bias_scale; p.gain = d->gain; p.add_scale = d->add_scale;
     p.tiles_x = p.tiles_y = 0;
+    p.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
     return dge_conv_launch(p, d->dtype, d->ksize, s);
+}
+
+// out[i] (+)= sum_s partial[s][i]   (combines the spread statistics copies of dge_conv2d)
+__global__ void sum_slots_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslot, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nslot; k++) s += partial[(size_t)k * n + i];
+    out[i] = accumulate ? out[i] + s : s;
+}
+extern "C" int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(sum_slots_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, out, nslot, n, accumulate);
+    DGE_LAUNCH_CHECK("sum_slots");
+    return 0;
 }

@@ -74,7 +74,7 @@ struct ConvCfg {
     static constexpr int B_BYTES = KS * BN * KCB;            // one stage: KS taps (a kernel row), rows unpadded, 16-B chunks XOR-swizzled
     static constexpr int RP = 16 / CH;                       // weight rows per 256-byte LDS bank row
     static constexpr int B_PIECES = B_BYTES / 1024;          // 1 KiB wave-level LDS-DMA pieces per stage
-    static constexpr int ESTR = 32 * (int)sizeof(T) + 16;
+    static constexpr int ESTR = 32 * 4 + 16;                  // epilogue staging is always f32
     static constexpr int E_BYTES = 4 * 32 * ESTR;
     static constexpr int N_BYTES = 4 * BM * 4;                 // noise values of the tile (x4 phases in up mode)
     static constexpr int LDS_BYTES = cmax(A_BYTES + 2 * B_BYTES, E_BYTES) + N_BYTES;
@@ -265,6 +265,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const T* __restrict__ DOT = (const T*)p.dot_src;
     constexpr int CPR = 32 / EP16;              // 16-byte chunks per 32-channel row
     constexpr int PPP = 64 / CPR;               // pixels per read-back pass
+    // Two kinds of epilogue work:
+    //   "pre"  (per accumulator element, this lane owns ONE channel): demodulation scale, noise,
+    //          bias, activation, gain, plain statistics;
+    //   "post" (after the LDS transpose, this lane owns 8/4 consecutive channels of one pixel, so
+    //          every global access is a 16-byte vector): residual addend, the data-gradient dot
+    //          products with dot_src, statistics of results that include the addend.
+    // In DOT mode (data gradients) the per-channel scale is applied post, on the staged raw value.
+    const bool post_stats = p.stats && (DOT || ADD);
+    float* __restrict__ STATS = p.stats ? p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * p.Cout * 2 : nullptr;
     if (!(p.dbg & 4))
     StaticFor<C::NT>::run([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -275,10 +284,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         const int py = phase >> 1, px = phase & 1;
         const int o = o0 + (lane & 31);
         const bool ovalid = o < p.Cout;
-        const float osc = (p.out_scale && ovalid) ? p.out_scale[b * p.Cout + o] : 1.f;
+        const float osc = (p.out_scale && ovalid && !DOT) ? p.out_scale[b * p.Cout + o] : 1.f;
         const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale : 0.f;
         const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] : 0.f;
         float ssum = 0.f, ssq = 0.f;
+        // post-side per-lane channel vector (channels o0 + chq*EP16 .. +EP16)
+        const int chq = lane % CPR;
+        const bool cvalid = o0 + chq * EP16 < p.Cout;
+        float posc[EP16], ps0[EP16], ps1[EP16];
+#pragma unroll
+        for (int e = 0; e < EP16; e++) {
+            posc[e] = (DOT && p.out_scale && cvalid) ? p.out_scale[b * p.Cout + o0 + chq * EP16 + e] : 1.f;
+            ps0[e] = 0.f; ps1[e] = 0.f;
+        }
         StaticFor<C::MT>::run([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const f32x16_t a = acc[i][j];
@@ -286,44 +304,69 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                 constexpr int r = decltype(rc)::value;
                 const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int m = wm * C::WTM + i * 32 + ml;
-                const int gy = y0 + m / TW, gx = x0 + m % TW;
-                const bool pvalid = gy < p.H && gx < p.W;
-                const int oy = p.up ? 2 * gy + py : gy, ox = p.up ? 2 * gx + px : gx;
-                if (DOT) {            // reductions of the raw accumulator (data-gradient statistics)
-                    if (pvalid && ovalid) {
-                        const float dv = Elem<T>::ld(DOT + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o);
-                        ssum += a[r] * dv; ssq += a[r];
-                    }
-                }
                 float v = a[r] * osc;
                 if (p.noise) v += nw * ldsN[phase * C::BM + m];
                 v += bia;
                 v = act_apply(v, p.act) * p.gain;
-                if (ADD && pvalid && ovalid)
-                    v += p.add_scale * Elem<T>::ld(ADD + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o);
-                if (pvalid && !DOT) { ssum += v; ssq += v * v; }
-                Elem<T>::st((T*)(est + ml * C::ESTR) + (lane & 31), v);
+                if (p.stats && !post_stats) {
+                    const int gy = y0 + m / TW, gx = x0 + m % TW;
+                    if (gy < p.H && gx < p.W) { ssum += v; ssq += v * v; }
+                }
+                *((float*)(est + ml * C::ESTR) + (lane & 31)) = v;
             });
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < 32 / PPP; q++) {
-                const int ml = q * PPP + lane / CPR, ch = lane % CPR;
+                const int ml = q * PPP + lane / CPR;
                 const int m = wm * C::WTM + i * 32 + ml;
                 const int gy = y0 + m / TW, gx = x0 + m % TW;
                 const int oy = p.up ? 2 * gy + py : gy, ox = p.up ? 2 * gx + px : gx;
-                if (gy < p.H && gx < p.W && o0 + ch * EP16 < p.Cout) {
-                    const uint4 v = *(const uint4*)(est + ml * C::ESTR + ch * 16);
-                    *(uint4*)(Y + ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o0 + ch * EP16) = v;
+                if (gy < p.H && gx < p.W && cvalid) {
+                    float f[EP16];
+#pragma unroll
+                    for (int e4 = 0; e4 < EP16 / 4; e4++)
+                        *(uint4*)&f[e4 * 4] = *(const uint4*)(est + ml * C::ESTR + chq * EP16 * 4 + e4 * 16);
+                    const size_t off = ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o0 + chq * EP16;
+                    if (DOT || ADD) {
+                        if (DOT) {
+                            float d[EP16];
+                            unpack16(*(const uint4*)(DOT + off), d, (T*)nullptr);
+#pragma unroll
+                            for (int e = 0; e < EP16; e++) { ps0[e] += f[e] * d[e]; ps1[e] += f[e]; f[e] *= posc[e]; }
+                        }
+                        if (ADD) {
+                            float ad[EP16];
+                            unpack16(*(const uint4*)(ADD + off), ad, (T*)nullptr);
+#pragma unroll
+                            for (int e = 0; e < EP16; e++) f[e] += p.add_scale * ad[e];
+                        }
+                        if (post_stats && !DOT) {
+#pragma unroll
+                            for (int e = 0; e < EP16; e++) { ps0[e] += f[e]; ps1[e] += f[e] * f[e]; }
+                        }
+                    }
+                    *(uint4*)(Y + off) = pack16(f, (T*)nullptr);
                 }
             }
             __builtin_amdgcn_wave_barrier();
         });
-        if (p.stats) {
+        if (p.stats && !post_stats) {
             ssum += __shfl_xor(ssum, 32, 64);
             ssq += __shfl_xor(ssq, 32, 64);
             if (lane < 32 && ovalid) {
-                atomicAdd(p.stats + ((size_t)b * p.Cout + o) * 2, ssum);
-                atomicAdd(p.stats + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
+                atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2, ssum);
+                atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
+            }
+        }
+        if (post_stats) {          // lanes with equal chq hold partial sums of the same channels
+#pragma unroll
+            for (int e = 0; e < EP16; e++) {
+#pragma unroll
+                for (int msk = CPR; msk < 64; msk <<= 1) { ps0[e] += __shfl_xor(ps0[e], msk, 64); ps1[e] += __shfl_xor(ps1[e], msk, 64); }
+                if (lane < CPR && cvalid) {
+                    atomicAdd(STATS + ((size_t)b * p.Cout + o0 + chq * EP16 + e) * 2, ps0[e]);
+                    atomicAdd(STATS + ((size_t)b * p.Cout + o0 + chq * EP16 + e) * 2 + 1, ps1[e]);
+                }
             }
         }
     });

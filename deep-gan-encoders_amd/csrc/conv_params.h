@@ -14,7 +14,8 @@ struct ConvParams {
     const float* bias;        // optional [Cout]
     const float* noise;       // optional [nB,OH,OW]
     const float* noise_w;     // [Cout] (stride 1) or scalar (stride 0)
-    float* stats;             // optional [B,Cout,2] (sum, sum of squares), atomically accumulated
+    float* stats;             // optional [slots][B,Cout,2] (sum, sum of squares), atomically accumulated
+    int stats_slots;          // workgroups spread their atomics over this many copies (contention)
     int B, H, W, Cin, Cout;
     int Ntot;                 // packed N (padded to the N tile); = 4*Cout (+pad) in up mode
     int Ntot_valid;           // unpadded N

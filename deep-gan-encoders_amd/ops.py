@@ -113,7 +113,15 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d = ConvDesc()
     d.x, d.w_packed, d.y, d.addend, d.dot_src = _p(x), _p(w_packed), _p(out), _p(addend), _p(dot_src)
     d.in_scale, d.in_shift, d.out_scale = _f32(in_scale), _f32(in_shift), _f32(out_scale)
-    d.bias, d.noise, d.noise_w, d.stats = _f32(bias), _f32(noise), _f32(noise_w), _f32(stats)
+    # statistics atomics of large grids are spread over several copies (same-address contention), then combined
+    partial, nslot = None, 1
+    if stats is not None:
+        nblk = ((H + 15) // 16) * ((W + 15) // 16) * B
+        nslot = max(1, min(64, nblk // 16))
+        if nslot > 1:
+            partial = torch.zeros((nslot,) + tuple(stats.shape), dtype=torch.float32, device=x.device)
+    d.bias, d.noise, d.noise_w, d.stats = _f32(bias), _f32(noise), _f32(noise_w), _f32(partial if partial is not None else stats)
+    d.stats_slots = nslot
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
     d.ksize, d.up, d.in_s2d = ksize, 1 if up else 0, 1 if in_s2d else 0
     d.noise_batch = 1 if noise is None else noise.shape[0]
@@ -135,8 +143,10 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         else:
             macs = float(ksize * ksize) * Cin * cout * H * W
         PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, ksize, up, in_s2d)))
-        return out
-    check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
+    else:
+        check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
+    if partial is not None:
+        check(lib().dge_sum_slots(_p(partial), _p(stats), nslot, stats.numel(), 1, _stream()), "dge_sum_slots")
     return out
 
 

@@ -59,7 +59,7 @@ typedef struct dge_conv_desc {
     const float* bias;        /* optional [Cout]                    */
     const float* noise;       /* optional [noise_batch,OH,OW]       */
     const float* noise_w;     /* [Cout] or [1]                      */
-    float* stats;             /* optional [B,Cout,2], pre-zeroed    */
+    float* stats;             /* optional [stats_slots][B,Cout,2], pre-zeroed */
     int B, H, W, Cin, Cout;
     int ksize;                /* 1 or 3 (stride 1, pad ksize/2)     */
     int up;                   /* 0 / 1                              */
@@ -69,8 +69,10 @@ typedef struct dge_conv_desc {
     int act;                  /* DGE_ACT_*                          */
     float bias_scale, gain, add_scale;
     int dtype;
+    int stats_slots;          /* >=1: workgroups spread their statistics atomics over this many copies (combine with dge_sum_slots) */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
+int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumulate, dge_stream_t stream);
 
 /* Weight preparation (once per weight update).  w_oihw: [Cout][Cin][k][k] f32 as stored by the
  * reference (model/stylegan2_generator.py:814-819; model/utils/lreq.py:107-110).  `out` holds
