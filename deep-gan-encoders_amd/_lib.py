@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdge_hip.so")
+LIB_PATH = os.environ.get("DGE_LIB_PATH", os.path.join(_HERE, "libdge_hip.so"))   # override: A/B builds while tuning
 
 
 class DgeError(RuntimeError):

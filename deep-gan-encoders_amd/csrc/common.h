@@ -18,8 +18,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {           // round-to-nearest-
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// two f32 -> packed bf16 pair, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+#ifdef DGE_SOFT_BF16
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+#endif
+    f32x2_t v = {lo, hi};
+    bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+    return *(uint32_t*)&h;
 }
 
 template <typename T> struct Elem;

@@ -56,6 +56,20 @@ template <int N> struct Regs {
 };
 template <> struct Regs<0> { template <int I> __device__ __forceinline__ uint4& get(); };
 
+// 16-byte-per-lane global -> LDS DMA issued from inline asm, so that hipcc does NOT track it: with the
+// builtin form the compiler inserts s_waitcnt vmcnt(0) in front of the next ds_read (it cannot prove
+// the read does not alias the DMA destination), which serialises the weight stream behind the MFMAs.
+// The LDS destination is wave-uniform base (M0) + lane*16; completion is awaited by hand
+// (s_waitcnt vmcnt(0) right before the stage barrier).
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -77,23 +91,29 @@ struct ConvCfg {
     static constexpr int ESTR = 32 * 4 + 16;                  // epilogue staging is always f32
     static constexpr int E_BYTES = 4 * 32 * ESTR;
     static constexpr int N_BYTES = 4 * BM * 4;                 // noise values of the tile (x4 phases in up mode)
-    static constexpr int LDS_BYTES = cmax(A_BYTES + 2 * B_BYTES, E_BYTES) + N_BYTES;
+    // weight-stage ring: 4 deep (DMA issued 3 stages ahead) when two workgroups still fit a CU, else 2 deep
+    static constexpr int NBUF = (A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2;
+    static constexpr int DPW = B_PIECES / 4;                   // DMA instructions every wave issues per stage (floor)
+    static constexpr int LDS_BYTES = cmax(A_BYTES + NBUF * B_BYTES, E_BYTES) + N_BYTES;
     static constexpr int NA_ITEMS = HH * HW * CH, NA_PER = (NA_ITEMS + 255) / 256;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(MT >= 1 && NT >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
     static_assert(KCB % 32 == 0 && 256 % CH == 0, "K chunk");
     static_assert(B_BYTES % 1024 == 0 && BN % 16 == 0 && (BN / RP) % CH == 0, "weight stage must be whole 1 KiB pieces");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    // workgroups per CU the LDS footprint allows (1..3) = waves per SIMD to ask the register allocator for
+    static constexpr int MINW = LDS_BYTES <= 53 * 1024 ? 3 : (LDS_BYTES <= 80 * 1024 ? 2 : 1);
 };
 
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)) void conv_igemm_kernel(ConvParams p) {
     using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>;
     constexpr int EP16 = Elem<T>::PER16;
     __shared__ __attribute__((aligned(256))) unsigned char lds[C::LDS_BYTES];
     unsigned char* ldsA = lds;                         // halo tile of the current K chunk
     unsigned char* ldsB = lds + C::A_BYTES;            // 2 weight stages
     float* ldsN = (float*)(lds + C::LDS_BYTES - C::N_BYTES);   // noise tile, lives until the epilogue
+    const unsigned ldsB_off = lds_offset_of(ldsB);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -198,13 +218,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
             const int c = (lane % C::CH) ^ ((r / C::RP) % C::CH);
             const int t = r / BN, n = r % BN;
             const T* src = Wp + ((size_t)((row * KS + t) * p.Ntot + bn0 + n) * p.Cin + kc * KC) + c * EP16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ldsB + buf * C::B_BYTES + pc * 1024), 16, 0, 0);
+            glds16_untracked(src, __builtin_amdgcn_readfirstlane(ldsB_off + buf * C::B_BYTES + pc * 1024));
         }
     };
 
-    // ---- prologue: first halo tile, first weight stage, noise tile
-    dma_b(0, 0, 0);
+    // ---- prologue: first halo tile, first NBUF-1 weight stages, noise tile
+    const int nstages = nchunks * KS;
+#pragma unroll
+    for (int q = 0; q < C::NBUF - 1; q++)
+        if (q < nstages) dma_b(q / KS, q % KS, q);
     load_a(0);
     if (p.noise) {
         const int OHn = p.up ? 2 * p.H : p.H, OWn = p.up ? 2 * p.W : p.W;
@@ -217,16 +239,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
         }
     }
     store_a();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the untracked weight DMAs
     __syncthreads();
 
-    const int nstages = nchunks * KS;
-    int sbuf = 0;
-    for (int s = 0; s < nstages; s++) {
+    for (int s = 0; s < ((p.dbg & 8) ? 0 : nstages); s++) {
         const int kc = s / KS, row = s - kc * KS;
-        const bool has_next = s + 1 < nstages;
-        const int nkc = (s + 1) / KS, nrow = (s + 1) - nkc * KS;
-        if (has_next && !(p.dbg & 1)) dma_b(nkc, nrow, sbuf ^ 1);   // lands under the MFMAs below
-        if (row == 0 && kc + 1 < nchunks && !(p.dbg & 1)) load_a(kc + 1);   // consumed after the last row of this chunk
+        const int sbuf = s % C::NBUF;
+        const int sn = s + C::NBUF - 1;                        // stage whose weights are requested now
+        if (sn < nstages && !(p.dbg & 1)) dma_b(sn / KS, sn % KS, sn % C::NBUF);   // ring slot last read in stage s-1
+        if (row == 0 && kc + 1 < nchunks && !(p.dbg & 1)) load_a(kc + 1);          // consumed after the last row of this chunk
         const unsigned char* aa = ldsA + row * C::RPITCH;
         const unsigned char* bb = ldsB + sbuf * C::B_BYTES;
         if (!(p.dbg & 2))
@@ -246,12 +267,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                     for (int j = 0; j < C::NT; j++) Mma<T>::run(af[i], bf[j], acc[i][j]);
             }
         }
-        __syncthreads();                                       // drains the LDS-DMA and closes the stage
-        if (row == KS - 1 && kc + 1 < nchunks) {               // chunk boundary: replace the halo tile
+        // Stage s+1's weights must have landed; DMA groups requested after it may stay in flight.
+        // vmcnt retires in order, so allowing (groups still wanted in flight) x DPW outstanding ops is
+        // exact for the DMAs and conservative w.r.t. the ordinary halo loads interleaved with them.
+        {
+            int fly = nstages - 2 - s; fly = fly < 0 ? 0 : (fly > C::NBUF - 2 ? C::NBUF - 2 : fly);
+            if (C::DPW == 0 || fly == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(C::DPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * C::DPW) : "memory");
+        }
+        __syncthreads();                                       // ... for every wave: stage closed
+        if (row == KS - 1 && kc + 1 < nchunks && !(p.dbg & 16)) {               // chunk boundary: replace the halo tile
             store_a();
             __syncthreads();
         }
-        sbuf ^= 1;
     }
     // LDS is re-used as the epilogue transpose buffer from here (all reads done: barrier above)
 
@@ -396,7 +425,11 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
     constexpr int E = (int)sizeof(T);
     constexpr int K0 = 64 / E, K1 = 32 / E;
     int bn = dge_conv_ntile(p.Ntot);
-    if (bn > 64) bn = 64;        // 64-wide N tiles keep 2 workgroups per CU (measured faster than 128: 83 vs 107 us on 256->256 @128^2)
+    if (bn == 128) {             // 128-wide N tiles only when they still give every CU two workgroups (measured: 223 vs 263 us
+                                 // on 256->256 @128^2 B=8, but 117 vs 88 us on 512->512 @64^2 B=2)
+        const long blocks128 = (long)((p.H + 15) / 16) * ((p.W + 15) / 16) * p.B * (p.Ntot / 128);
+        if (blocks128 < 512) bn = 64;
+    }
     { const char* e = getenv("DGE_CONV_BN"); if (e) bn = atoi(e); }
     const int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
     const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
