@@ -41,43 +41,79 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     const int ntiles = tiles_x * tiles_y * B;
     constexpr int CPR = 32 / EP;                        // 16-byte channel chunks per 32-channel slab
+    constexpr int NG = (TH * TW * CPR + 255) / 256, NX = (HH * HW * CPR + 255) / 256;
+    __shared__ float laff[64];                          // instance-norm affine of the current sample: sc[32] | sh[32]
     const int m = lane & 31, kg = lane >> 5;
-    for (int tile = blockIdx.y; tile < ntiles; tile += ntile_groups) {
+    uint4 greg[NG], xreg[NX];                           // next tile, in flight while the current one is in the MFMAs
+    auto load_tile = [&](int tile) {
         const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx_i * TW, y0 = ty_i * TH;
-        __syncthreads();
-        // ---- gradient tile, transposed: consecutive lanes take consecutive pixels of one channel chunk
-        for (int idx = tid; idx < TH * TW * CPR; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const int idx = tid + k * 256;
             const int pix = idx % (TH * TW), c = idx / (TH * TW), gy = y0 + pix / TW, gx = x0 + pix % TW;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy < H && gx < W && o0 + c * EP < Co) v = *(const uint4*)(g + ((size_t)(b * H + gy) * W + gx) * Co + o0 + c * EP);
-            const T* e = (const T*)&v;
-#pragma unroll
-            for (int q = 0; q < EP; q++) lg[(c * EP + q) * GPIT + pix] = e[q];
+            if (idx < TH * TW * CPR && gy < H && gx < W && o0 + c * EP < Co)
+                v = *(const uint4*)(g + ((size_t)(b * H + gy) * W + gx) * Co + o0 + c * EP);
+            greg[k] = v;
         }
-        // ---- normalised input halo tile, transposed
-        for (int idx = tid; idx < HH * HW * CPR; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int idx = tid + k * 256;
             const int pix = idx % (HH * HW), c = idx / (HH * HW), hy = pix / HW, hx = pix % HW;
             const int gy = y0 + hy - HALO, gx = x0 + hx - HALO;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W && i0 + c * EP < Ci) {
+            if (idx < HH * HW * CPR && gy >= 0 && gy < H && gx >= 0 && gx < W && i0 + c * EP < Ci)
                 v = *(const uint4*)(X + ((size_t)(b * H + gy) * W + gx) * Ci + i0 + c * EP);
-                if (sc) {
+            xreg[k] = v;
+        }
+    };
+    int b_aff = -1;
+    if ((int)blockIdx.y < ntiles) load_tile(blockIdx.y);
+    for (int tile = blockIdx.y; tile < ntiles; tile += ntile_groups) {
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx_i * TW, y0 = ty_i * TH;
+        __syncthreads();                                 // previous tile's fragments are consumed
+        if (sc && b != b_aff) {                          // (block-uniform) refresh the affine table
+            if (tid < 64) {
+                const int ch = i0 + (tid & 31);
+                laff[tid] = ch < Ci ? (tid < 32 ? sc[b * Ci + ch] : sh[b * Ci + ch]) : 0.f;
+            }
+            b_aff = b;
+            __syncthreads();
+        }
+        // ---- transposing scatter: consecutive lanes hold consecutive pixels of one channel chunk
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const int idx = tid + k * 256;
+            if (idx < TH * TW * CPR) {
+                const int pix = idx % (TH * TW), c = idx / (TH * TW);
+                const T* e = (const T*)&greg[k];
+#pragma unroll
+                for (int q = 0; q < EP; q++) lg[(c * EP + q) * GPIT + pix] = e[q];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int idx = tid + k * 256;
+            if (idx < HH * HW * CPR) {
+                const int pix = idx % (HH * HW), c = idx / (HH * HW), hy = pix / HW, hx = pix % HW;
+                const int gy = y0 + hy - HALO, gx = x0 + hx - HALO;
+                uint4 v = xreg[k];
+                if (sc && gy >= 0 && gy < H && gx >= 0 && gx < W) {      // padding stays zero
                     float f[EP];
                     unpack16(v, f, (T*)nullptr);
 #pragma unroll
-                    for (int q = 0; q < EP; q++) {
-                        const int ci = b * Ci + i0 + c * EP + q;
-                        f[q] = f[q] * sc[ci] + sh[ci];
-                    }
+                    for (int q = 0; q < EP; q++) f[q] = f[q] * laff[c * EP + q] + laff[32 + c * EP + q];
                     v = pack16(f, (T*)nullptr);
                 }
-            }
-            const T* e = (const T*)&v;
+                const T* e = (const T*)&v;
 #pragma unroll
-            for (int q = 0; q < EP; q++) lx[(c * EP + q) * XPIT + hy * XROW + hx] = e[q];
+                for (int q = 0; q < EP; q++) lx[(c * EP + q) * XPIT + hy * XROW + hx] = e[q];
+            }
         }
         __syncthreads();
+        if (tile + ntile_groups < ntiles) load_tile(tile + ntile_groups);   // flies under the MFMAs
         // ---- MFMA: wave w owns tile rows {2w, 2w+1}
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
