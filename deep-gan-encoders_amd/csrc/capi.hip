@@ -18,6 +18,7 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(d->dtype == DGE_F32 || d->dtype == DGE_BF16, "conv2d: bad dtype %d", d->dtype);
     DGE_CHECK(!(d->up && d->stats), "conv2d: stats are not available in up mode");
     DGE_CHECK(!(d->up && d->in_s2d), "conv2d: up and in_s2d are exclusive");
+    DGE_CHECK(!d->in_up2 || (!d->in_s2d && d->H % 2 == 0 && d->W % 2 == 0), "conv2d: in_up2 needs even H, W and no in_s2d");
     DGE_CHECK(!d->in_s2d || d->Cin % 4 == 0, "conv2d: in_s2d needs Cin %% 4 == 0");
     DGE_CHECK(!d->dot_src || d->stats, "conv2d: dot_src needs a stats buffer");
     DGE_CHECK(!d->noise || d->noise_w, "conv2d: noise without noise_w");
@@ -28,7 +29,7 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
     p.Ntot_valid = d->up ? 4 * d->Cout : d->Cout;
     p.Ntot = dge_packed_n(p.Ntot_valid);
-    p.up = d->up; p.in_s2d = d->in_s2d;
+    p.up = d->up; p.in_s2d = d->in_s2d; p.in_up2 = d->in_up2;
     const int OH = d->up ? 2 * d->H : d->H, OW = d->up ? 2 * d->W : d->W;
     p.noise_bstride = d->noise_batch > 1 ? OH * OW : 0;
     p.noise_w_stride = d->noise_w_per_channel ? 1 : 0;

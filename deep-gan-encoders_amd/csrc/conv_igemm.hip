@@ -178,7 +178,9 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                 const int hx = pix % C::HW, hy = pix / C::HW;
                 const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
                 if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                    if (p.in_s2d)     // logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid
+                    if (p.in_up2)     // upscale2d (nearest x2) fused into the read: pixel (y,x) <- source (y/2, x/2)
+                        v = *(const uint4*)(X + ((size_t)(b * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * p.Cin + cbase + achunk * EP16);
+                    else if (p.in_s2d)     // logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid
                         v = *(const uint4*)(X + ((size_t)(b * 2 * p.H + 2 * gy + (ph >> 1)) * (2 * p.W) + 2 * gx + (ph & 1)) * cphys + cb + achunk * EP16);
                     else
                         v = *(const uint4*)(X + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cin + cbase + achunk * EP16);

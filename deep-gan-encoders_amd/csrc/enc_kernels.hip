@@ -116,6 +116,73 @@ __global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ x, con
     if (stats) block_chan_flush<EP, 2>(sq, cpt, ppi, stats + (size_t)b * C * 2, C, red);
 }
 
+// ------------------------------------------------------------------ StyleGAN1 blur + noise + bias + lrelu
+// y = lrelu(blur(x) + nw[c]*noise[b,p] + bias[c], 0.2), blur = depthwise [1,2,1]x[1,2,1]/16 with zero padding
+template <typename T>
+__global__ __launch_bounds__(256) void blur_noise_act_kernel(const T* __restrict__ x, const float* __restrict__ noise,
+                                                              const float* __restrict__ nw, const float* __restrict__ bias,
+                                                              T* __restrict__ y, float* __restrict__ stats, int H, int W, int C,
+                                                              int do_blur, int noise_bstride) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * 2 * EP];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    const int HW = H * W;
+    float sq[2][EP], nwv[EP], bv[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) {
+        sq[0][e] = sq[1][e] = 0.f;
+        nwv[e] = nw ? nw[chunk * EP + e] : 0.f; bv[e] = bias ? bias[chunk * EP + e] : 0.f;
+    }
+    const T* xb = x + (size_t)b * HW * C;
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
+        const int p = p0 + slot;
+        if (slot < ppi && p < HW) {
+            float f[EP];
+            if (do_blur) {
+                const int py = p / W, px = p % W;
+#pragma unroll
+                for (int e = 0; e < EP; e++) f[e] = 0.f;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) {
+                        const int yy = py + dy, xx = px + dx;
+                        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                            float g[EP];
+                            unpack16(*(const uint4*)(xb + ((size_t)yy * W + xx) * C + chunk * EP), g, (T*)nullptr);
+                            const float wgt = (float)((2 - (dy < 0 ? -dy : dy)) * (2 - (dx < 0 ? -dx : dx))) * (1.f / 16.f);
+#pragma unroll
+                            for (int e = 0; e < EP; e++) f[e] += wgt * g[e];
+                        }
+                    }
+            } else {
+                unpack16(*(const uint4*)(xb + (size_t)p * C + chunk * EP), f, (T*)nullptr);
+            }
+            const float nz = noise ? noise[(size_t)b * noise_bstride + p] : 0.f;
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                float v = f[e] + nwv[e] * nz + bv[e];
+                v = v > 0.f ? v : 0.2f * v;
+                f[e] = v; sq[0][e] += v; sq[1][e] += v * v;
+            }
+            *(uint4*)(y + ((size_t)b * HW + p) * C + chunk * EP) = pack16(f, (T*)nullptr);
+        }
+    }
+    if (stats) block_chan_flush<EP, 2>(sq, cpt, ppi, stats + (size_t)b * C * 2, C, red);
+}
+
+// a = sc*(s0+1), b = sh*(s0+1) + s1  (instance norm followed by style_mod as one affine)
+__global__ void affine_compose_kernel(const float* __restrict__ sc, const float* __restrict__ sh, const float* __restrict__ style,
+                                      float* __restrict__ a, float* __restrict__ bq, int B, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx % C;
+    const float s0 = style[(size_t)b * 2 * C + c] + 1.f, s1 = style[(size_t)b * 2 * C + C + c];
+    a[idx] = sc[idx] * s0; bq[idx] = sh[idx] * s0 + s1;
+}
+
 // =================================================================== C ABI
 static int grid_for(int hw, int ppi) {
     int g = (hw + ppi - 1) / ppi;
@@ -153,5 +220,26 @@ extern "C" int dge_blend(const void* x, const void* z, void* y, const float* sc,
     else
         hipLaunchKernelGGL(blend_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)z, (float*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta);
     DGE_LAUNCH_CHECK("blend");
+    return 0;
+}
+
+extern "C" int dge_blur_noise_act(const void* x, const float* noise, const float* noise_w, const float* bias, void* y, float* stats,
+                                  int B, int H, int W, int C, int do_blur, int noise_batch, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "blur_noise_act: unsupported channel count %d", C);
+    const int ppi = 256 / (C / ep);
+    dim3 grid(grid_for(H * W, ppi), B);
+    const int nbs = noise_batch > 1 ? H * W : 0;
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(blur_noise_act_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, noise, noise_w, bias, (bf16_t*)y, stats, H, W, C, do_blur, nbs);
+    else
+        hipLaunchKernelGGL(blur_noise_act_kernel<float>, grid, dim3(256), 0, s, (const float*)x, noise, noise_w, bias, (float*)y, stats, H, W, C, do_blur, nbs);
+    DGE_LAUNCH_CHECK("blur_noise_act");
+    return 0;
+}
+
+extern "C" int dge_affine_compose(const float* sc, const float* sh, const float* style, float* a, float* b, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(affine_compose_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, sc, sh, style, a, b, B, C);
+    DGE_LAUNCH_CHECK("affine_compose");
     return 0;
 }

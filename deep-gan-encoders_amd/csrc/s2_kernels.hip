@@ -13,6 +13,23 @@
 //          stylegan2_generator.py:879-896 + :802-807, folded per output phase)
 // mode 2: data-gradient conv    out[tap][i][o]      = scale * W[o][i][KS*KS-1-tap]   (N = Cin, K = Cout)
 // mode 3: data-gradient of 1    out[tap][i][ph*Cout+o] = mode-1 weight of (ph, 8-tap, o, i)  (N = Cin, K = 4*Cout)
+// mode 4: StyleGAN1 fused up     w is [Cin][Cout][3][3] (ConvTranspose2d(3, stride 2, pad 1) + transform_kernel:
+//         W4[ky][kx] = W3[ky][kx] + W3[ky-1][kx] + W3[ky][kx-1] + W3[ky-1][kx-1], lreq.py:129-131);
+//         out[2m+py] takes x[m+dy] with ky = py + 1 - 2 dy  ->  out[tap][ph*Cout+o][c]
+__device__ __forceinline__ float sg1_up_weight(const float* __restrict__ w, int c, int o, int Cout, int ph, int tap) {
+    const int py = ph >> 1, px = ph & 1, dy = tap / 3 - 1, dx = tap % 3 - 1;
+    const int ky = py + 1 - 2 * dy, kx = px + 1 - 2 * dx;
+    if (ky < 0 || ky > 3 || kx < 0 || kx > 3) return 0.f;
+    const float* w3 = w + ((size_t)c * Cout + o) * 9;
+    float v = 0.f;
+    for (int a = 0; a < 2; a++)
+        for (int bq = 0; bq < 2; bq++) {
+            const int y = ky - a, x = kx - bq;
+            if (y >= 0 && y < 3 && x >= 0 && x < 3) v += w3[y * 3 + x];
+        }
+    return v;
+}
+
 // folded (transposed conv stride 2, flipped 3x3) * (4x4 FIR) weight of output phase `ph`, input tap (dy,dx)
 __device__ __forceinline__ float upfold_weight(const float* __restrict__ w, int o, int i, int Cin, int ph, int tap) {
     const int py = ph >> 1, px = ph & 1;
@@ -48,6 +65,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             if (n < Cin) v = w[((size_t)k * Cin + n) * ntap + (ntap - 1 - tap)];
         } else if (mode == 1) {
             if (n < 4 * Cout) v = upfold_weight(w, n % Cout, k, Cin, n / Cout, tap);
+        } else if (mode == 4) {
+            if (n < 4 * Cout) v = sg1_up_weight(w, k, n % Cout, Cout, n / Cout, tap);
         } else {
             if (n < Cin) v = upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap);
         }
@@ -180,14 +199,32 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict
     dst[idx] = Elem<T>::ld(src + ((size_t)b * HW + pix) * C + c);
 }
 
+// out[b,l,d] = avg[l*avg_stride + d] + (w[b,d] - avg[...]) * coefs[l]
+__global__ void lerp_layers_kernel(const float* __restrict__ w, const float* __restrict__ avg, int avg_stride,
+                                   const float* __restrict__ coefs, float* __restrict__ out, int B, int L, int D) {
+    const long idx = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (idx >= (long)B * L * D) return;
+    const int d = idx % D, l = (idx / D) % L, b = idx / ((long)D * L);
+    const float a = avg[(size_t)l * avg_stride + d];
+    out[idx] = a + (w[(size_t)b * D + d] - a) * coefs[l];
+}
+
 // =================================================================== C ABI
 #include "../../include/dge_hip.h"
 
+extern "C" int dge_lerp_layers(const float* w, const float* avg, int avg_stride, const float* coefs, float* out, int B, int L,
+                               int D, hipStream_t s) {
+    const long n = (long)B * L * D;
+    hipLaunchKernelGGL(lerp_layers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, avg, avg_stride, coefs, out, B, L, D);
+    DGE_LAUNCH_CHECK("lerp_layers");
+    return 0;
+}
+
 extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
                                     float scale, hipStream_t s) {
-    DGE_CHECK(mode >= 0 && mode <= 3, "pack: bad mode %d", mode);
-    DGE_CHECK((mode != 1 && mode != 3) || ksize == 3, "pack: up fold needs a 3x3 kernel");
-    const int nvalid = mode == 1 ? 4 * cout : (mode >= 2 ? cin : cout);
+    DGE_CHECK(mode >= 0 && mode <= 4, "pack: bad mode %d", mode);
+    DGE_CHECK((mode != 1 && mode != 3 && mode != 4) || ksize == 3, "pack: up fold needs a 3x3 kernel");
+    const int nvalid = (mode == 1 || mode == 4) ? 4 * cout : (mode >= 2 ? cin : cout);
     const int ntot = dge_packed_n(nvalid);
     const int kdim = mode == 2 ? cout : (mode == 3 ? 4 * cout : cin);
     const long total = (long)ksize * ksize * ntot * kdim;

@@ -9,7 +9,7 @@ from ._lib import lib, check, ConvDesc, DgeError
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
-PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD = 0, 1, 2, 3
+PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP = 0, 1, 2, 3, 4
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag) per conv launch
 
 
@@ -52,7 +52,9 @@ def packed_n(n):
 def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
     """w: [Cout,Cin,k,k] f32 (reference layout) -> packed [k*k, Npad, K] tensor of `dtype`."""
     cout, cin, k, _ = w.shape
-    nvalid = 4 * cout if mode == PACK_UPFOLD else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD) else cout)
+    if mode == PACK_SG1_UP:          # ConvTranspose2d parameter layout [Cin, Cout, k, k]
+        cin, cout = cout, cin
+    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD) else cout)
     kdim = cout if mode == PACK_DGRAD else (4 * cout if mode == PACK_UPFOLD_DGRAD else cin)
     out = torch.empty((k * k, packed_n(nvalid), kdim), dtype=tdtype(dtype), device=w.device)
     check(lib().dge_pack_conv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, k, mode, dtype, float(scale),
@@ -101,11 +103,13 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None):
+           out=None, in_s2d=False, dot_src=None, in_up2=False):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout]."""
     B, H, W, Cin = x.shape
     if in_s2d:            # x is the fine grid [B,2H,2W,C]; logical input is [B,H,W,4C]
         H, W, Cin = H // 2, W // 2, Cin * 4
+    if in_up2:            # x is the coarse grid; the conv runs on its nearest x2 upsample
+        H, W = 2 * H, 2 * W
     dt = dtype_of(x)
     OH, OW = (2 * H, 2 * W) if up else (H, W)
     if out is None:
@@ -123,7 +127,7 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d.bias, d.noise, d.noise_w, d.stats = _f32(bias), _f32(noise), _f32(noise_w), _f32(partial if partial is not None else stats)
     d.stats_slots = nslot
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
-    d.ksize, d.up, d.in_s2d = ksize, 1 if up else 0, 1 if in_s2d else 0
+    d.ksize, d.up, d.in_s2d, d.in_up2 = ksize, 1 if up else 0, 1 if in_s2d else 0, 1 if in_up2 else 0
     d.noise_batch = 1 if noise is None else noise.shape[0]
     d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
     d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt
@@ -311,3 +315,32 @@ def scale_(t, factor):
     """in-place t *= factor on the device (dge_axpy_scalar)."""
     check(lib().dge_axpy_scalar(_f32(t), None, _p(t), t.numel(), float(factor), 0, _stream()), "dge_axpy_scalar")
     return t
+
+
+# ------------------------------------------------------------------ StyleGAN1 ops
+def blur_noise_act(x, noise, noise_w, bias, blur=True, stats=None):
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    check(lib().dge_blur_noise_act(_p(x), _f32(noise), _f32(noise_w), _f32(bias), _p(y), _f32(stats), B, H, W, Cc,
+                                   1 if blur else 0, 1 if noise is None else noise.shape[0], dtype_of(x), _stream()),
+          "dge_blur_noise_act")
+    return y
+
+
+def affine_compose(sc, sh, style):
+    B, Cc = sc.shape
+    a = torch.empty_like(sc)
+    b = torch.empty_like(sc)
+    check(lib().dge_affine_compose(_f32(sc), _f32(sh), _f32(style), _p(a), _p(b), B, Cc, _stream()), "dge_affine_compose")
+    return a, b
+
+
+def lerp_layers(w, avg, coefs):
+    """w [B,D]; avg [D] or [L,D]; coefs [L] -> [B,L,D]"""
+    B, D = w.shape
+    L = coefs.numel()
+    out = torch.empty((B, L, D), dtype=torch.float32, device=w.device)
+    stride = D if avg.numel() == L * D else 0
+    check(lib().dge_lerp_layers(_f32(w), _f32(avg.contiguous()), stride, _f32(coefs.contiguous()), _p(out), B, L, D, _stream()),
+          "dge_lerp_layers")
+    return out

@@ -36,6 +36,7 @@ typedef struct ihipStream_t* dge_stream_t;   /* == hipStream_t */
 #define DGE_PACK_UPFOLD 1   /* [tap][4*Cout][Cin]: conv_transpose(s2)+FIR folded  */
 #define DGE_PACK_DGRAD 2    /* [tap][Cin][Cout], taps flipped                     */
 #define DGE_PACK_UPFOLD_DGRAD 3 /* [tap][Cin][4*Cout]: adjoint of DGE_PACK_UPFOLD  */
+#define DGE_PACK_SG1_UP 4    /* w is [Cin][Cout][3][3] (ConvTranspose2d 3,s2,p1 + transform_kernel, lreq.py:129-131) -> [tap][4*Cout][Cin] */
 
 const char* dge_last_error(void);
 int dge_version(void);
@@ -69,6 +70,7 @@ typedef struct dge_conv_desc {
     int act;                  /* DGE_ACT_*                          */
     float bias_scale, gain, add_scale;
     int dtype;
+    int in_up2;               /* 1: x is [B,H/2,W/2,Cin] read through a nearest x2 upsample (upscale2d, model/stylegan1/net.py:37-43) */
     int stats_slots;          /* >=1: workgroups spread their statistics atomics over this many copies (combine with dge_sum_slots) */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
@@ -194,6 +196,18 @@ int dge_maxpool2_bwd(const void* gy, const void* x, const void* addend, void* gx
 int dge_lpips_head(const void* feat, const float* lin, float* val, void* g1, int B, int HW, int C, float gscale, int dtype,
                    dge_stream_t stream);
 int dge_mean(const float* v, float* out, int n, dge_stream_t stream);
+
+/* ---- StyleGAN1 (model/stylegan1/net.py) streaming kernels ---------------------------------- */
+/* y = lrelu(blur3x3(x) + noise_w[c]*noise[b,p] + bias[c], 0.2) with optional per-(b,c) statistics:
+ * Blur :48-58 ([1,2,1]^2/16, zero pad) + the noise/bias/leaky_relu of DecodeBlock.forward :146-152,158-164. */
+int dge_blur_noise_act(const void* x, const float* noise, const float* noise_w, const float* bias, void* y, float* stats,
+                       int B, int H, int W, int C, int do_blur, int noise_batch, int dtype, dge_stream_t stream);
+/* instance norm + style_mod as one per-(b,c) affine: a = sc*(s0+1), b = sh*(s0+1) + s1 with style [B,2C] = [s0 | s1]
+ * (style_mod :32-34 after InstanceNorm2d :153-156) */
+int dge_affine_compose(const float* sc, const float* sh, const float* style, float* a, float* b, int B, int C, dge_stream_t stream);
+/* out[b,l,:] = avg[l*avg_stride + :] + (w[b,:] - avg[...]) * coefs[l]   (Mapping.forward lerp, :459-466) */
+int dge_lerp_layers(const float* w, const float* avg, int avg_stride, const float* coefs, float* out, int B, int L, int D,
+                    dge_stream_t stream);
 
 #ifdef __cplusplus
 }

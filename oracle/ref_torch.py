@@ -279,3 +279,56 @@ def lreq_adam_step(p, g, v, step, lr, beta2=0.99, eps=1e-8, coef=None):
     if coef is not None and coef >= 0:
         step_size *= coef
     return p - step_size * g / denom, v
+
+
+# ----------------------------------------------------------------------------- StyleGAN1
+def sg1_blur(x):
+    """Blur, model/stylegan1/net.py:48-58: depthwise [1,2,1]x[1,2,1]/16, zero pad 1."""
+    C = x.shape[1]
+    k = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.0
+    return F.conv2d(x, k.view(1, 1, 3, 3).repeat(C, 1, 1, 1), padding=1, groups=C)
+
+
+def sg1_style_mod(x, style):
+    """style_mod :32-34: y = s1 + x*(s0+1), style [B,2C] = [s0 | s1]."""
+    C = x.shape[1]
+    return x * (style[:, :C, None, None] + 1) + style[:, C:, None, None]
+
+
+def sg1_generator(P, styles, lod, noises):
+    """Generator.decode :331-336 + DecodeBlock.forward :141-169 (+ ToRGB :244-253)."""
+    x = P["const"]
+    ni = 0
+    for i in range(lod + 1):
+        pre = f"decode_block.{i}."
+        if i != 0:
+            w = P[pre + "conv_1.weight"]
+            if (4 << i) >= 128:      # fused scale: ConvTranspose2d(3, s2, p1) with transform_kernel (lreq.py:129-131)
+                wp = F.pad(w, (1, 1, 1, 1))
+                w4 = wp[:, :, 1:, 1:] + wp[:, :, :-1, 1:] + wp[:, :, 1:, :-1] + wp[:, :, :-1, :-1]
+                x = F.conv_transpose2d(x, w4, stride=2, padding=1)
+            else:                    # upscale2d (nearest x2) + conv
+                x = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+            x = sg1_blur(x)
+        x = F.leaky_relu(x + P[pre + "noise_weight_1"] * noises[ni] + P[pre + "bias_1"], 0.2); ni += 1
+        m, v = enc_stats(x)
+        s1 = styles[:, 2 * i] @ P[pre + "style_1.weight"].t() + P[pre + "style_1.bias"]
+        x = sg1_style_mod(inorm(x, m, v), s1)
+        x = F.conv2d(x, P[pre + "conv_2.weight"], padding=1)
+        x = F.leaky_relu(x + P[pre + "noise_weight_2"] * noises[ni] + P[pre + "bias_2"], 0.2); ni += 1
+        m, v = enc_stats(x)
+        s2 = styles[:, 2 * i + 1] @ P[pre + "style_2.weight"].t() + P[pre + "style_2.bias"]
+        x = sg1_style_mod(inorm(x, m, v), s2)
+    return F.conv2d(x, P[f"to_rgb.{lod}.to_rgb.weight"], P[f"to_rgb.{lod}.to_rgb.bias"])
+
+
+def sg1_mapping(P, z, buffer1, coefs):
+    """Mapping.forward :454-466 (pixel_norm :28, 8x lrelu(Linear)), lerp towards buffer1."""
+    x = z * torch.rsqrt(torch.mean(z * z, dim=1, keepdim=True) + 1e-8)
+    i = 1
+    while f"block_{i}.fc.weight" in P:
+        x = F.leaky_relu(x @ P[f"block_{i}.fc.weight"].t() + P[f"block_{i}.fc.bias"], 0.2)
+        i += 1
+    L = coefs.numel()
+    x = x[:, None].repeat(1, L, 1)
+    return buffer1 + (x - buffer1) * coefs.view(1, L, 1)

@@ -1,0 +1,114 @@
+"""StyleGAN1 generator / mapping: oracle vs reference golden (CPU) and the HIP
+path vs golden (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden, ROOT
+from tests.golden import recipe as R
+from oracle import ref_torch as O
+
+
+def sg1_shapes(startf, maxf, layer_count, latent=512):
+    s = {}
+    mul = 2 ** (layer_count - 1)
+    inputs = min(maxf, startf * mul)
+    s["const"] = [1, inputs, 4, 4]
+    for i in range(layer_count):
+        outputs = min(maxf, startf * mul)
+        p = f"decode_block.{i}."
+        for k in ("noise_weight_1", "bias_1", "noise_weight_2", "bias_2"):
+            s[p + k] = [1, outputs, 1, 1]
+        s[p + "blur.weight"] = [outputs, 1, 3, 3]
+        if i != 0:
+            s[p + "conv_1.weight"] = [inputs, outputs, 3, 3] if (4 << i) >= 128 else [outputs, inputs, 3, 3]
+        s[p + "style_1.weight"], s[p + "style_1.bias"] = [2 * outputs, latent], [2 * outputs]
+        s[p + "conv_2.weight"] = [outputs, outputs, 3, 3]
+        s[p + "style_2.weight"], s[p + "style_2.bias"] = [2 * outputs, latent], [2 * outputs]
+        inputs = outputs
+        mul //= 2
+    for i in range(layer_count):
+        c = min(maxf, startf * 2 ** (layer_count - 1 - i))
+        s[f"to_rgb.{i}.to_rgb.weight"], s[f"to_rgb.{i}.to_rgb.bias"] = [3, c, 1, 1], [3]
+    return s
+
+
+def small_params():
+    shapes = sg1_shapes(32, 64, 6)
+    sd = R.fill_encoder(shapes, seed=41)
+    blur = torch.tensor([[1., 2., 1.], [2., 4., 2.], [1., 2., 1.]]) / 16.0
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = blur.view(1, 1, 3, 3).repeat(shapes[k][0], 1, 1, 1)
+    sd["const"] = R.randn("sg1.const", tuple(shapes["const"]), 41)
+    return sd
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu(); b = torch.as_tensor(np.asarray(b)).float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def test_shapes_match_reference_state_dicts():
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "sg1_keys.json")))
+    for tag, (sf, lc) in (("256_64_7", (64, 7)), ("1024_16_9", (16, 9))):
+        mine = sg1_shapes(sf, 512, lc)
+        assert set(mine) == set(k["Gs_" + tag]) and all(mine[n] == k["Gs_" + tag][n] for n in mine)
+    assert len(k["Gs_256_64_7"]) == 91 and len(k["Gs_1024_16_9"]) == 117 and len(k["Gm"]) == 16
+    import dge_amd.stylegan1 as S
+    for tag, (sf, lc) in (("256_64_7", (64, 7)), ("1024_16_9", (16, 9))):
+        sd = S.Generator(startf=sf, maxf=512, layer_count=lc, latent_size=512).state_dict()
+        assert list(sd.keys()) == list(k["Gs_" + tag].keys())
+        assert all(list(sd[n].shape) == k["Gs_" + tag][n] for n in sd)
+    sd = S.Mapping(num_layers=14).state_dict()
+    assert {n: list(v.shape) for n, v in sd.items()} == k["Gm"]
+
+
+def test_oracle_vs_reference_golden():
+    g = golden("sg1_small.npz")
+    P = small_params()
+    assert abs(R.checksum(P) - float(g["state_checksum"])) < 1e-6 * float(g["state_checksum"])
+    styles = R.randn("sg1.styles", (2, 12, 512), 6)
+    noises = [R.randn(f"sg1.noise{i}", tuple(s), 6) for i, s in enumerate(g["noise_shapes"].tolist())]
+    img = O.sg1_generator(P, styles, 5, noises)
+    assert relerr(img, g["image"]) < 2e-4
+    noises3 = [R.randn(f"sg1b.noise{i}", tuple(s), 6) for i, s in enumerate(g["noise_shapes"].tolist()[:8])]
+    assert relerr(O.sg1_generator(P, styles, 3, noises3), g["image_lod3"]) < 2e-4
+    M = {f"block_{i}.fc.{n}": R.randn(f"sg1m.block_{i}.fc.{n}", (512, 512) if n == "weight" else (512,), 42, 0.05 if n == "weight" else 0.01)
+         for i in range(1, 9) for n in ("weight", "bias")}
+    coefs = torch.tensor([0.7] * 6 + [1.0] * 6)
+    w = O.sg1_mapping(M, R.randn("sg1m.z", (3, 512), 42), R.randn("sg1m.buffer1", (12, 512), 42, 0.5), coefs)
+    assert relerr(w, g["mapping_w"]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_hip_generator_vs_reference_golden(cd):
+    import dge_amd.stylegan1 as S
+    g = golden("sg1_small.npz")
+    G = S.Generator(startf=32, maxf=64, layer_count=6, latent_size=512, compute_dtype=cd).cuda()
+    G.load_state_dict(small_params())
+    styles = R.randn("sg1.styles", (2, 12, 512), 6).cuda()
+    noises = [R.randn(f"sg1.noise{i}", tuple(s), 6) for i, s in enumerate(g["noise_shapes"].tolist())]
+    img = G.forward(styles, 5, noises=noises)
+    tol = 3e-4 if cd == "f32" else 6e-2
+    assert relerr(img, g["image"]) < tol, relerr(img, g["image"])
+    noises3 = [R.randn(f"sg1b.noise{i}", tuple(s), 6) for i, s in enumerate(g["noise_shapes"].tolist()[:8])]
+    assert relerr(G.forward(styles, 3, noises=noises3), g["image_lod3"]) < tol
+
+
+@pytest.mark.gpu
+def test_hip_mapping_vs_reference_golden():
+    import dge_amd.stylegan1 as S
+    g = golden("sg1_small.npz")
+    M = S.Mapping(num_layers=12).cuda()
+    M.load_state_dict({k: R.randn("sg1m." + k, tuple(v.shape), 42, 0.05 if k.endswith("weight") else 0.01)
+                       for k, v in M.state_dict().items()})
+    M.buffer1 = R.randn("sg1m.buffer1", (12, 512), 42, 0.5)
+    layer_idx = torch.arange(12)[None, :, None]
+    coefs = torch.where(layer_idx < 6, 0.7 * torch.ones(1, 12, 1), torch.ones(1, 12, 1))
+    w = M(R.randn("sg1m.z", (3, 512), 42), coefs_m=coefs)
+    assert relerr(w, g["mapping_w"]) < 1e-5

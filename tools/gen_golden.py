@@ -382,7 +382,57 @@ def gen_step():
     save_npz("step_s2.npz", **out)
 
 
-SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step}
+# --------------------------------------------------------------------------- StyleGAN1
+def gen_sg1():
+    import model.stylegan1.net as SG1
+    keys = {}
+    for tag, (sf, lc) in (("256_64_7", (64, 7)), ("1024_16_9", (16, 9))):
+        g = SG1.Generator(startf=sf, maxf=512, layer_count=lc, latent_size=512, channels=3)
+        keys["Gs_" + tag] = shapes_of(g.state_dict())
+        del g
+    m = SG1.Mapping(num_layers=14, mapping_layers=8, latent_size=512, dlatent_size=512, mapping_fmaps=512)
+    keys["Gm"] = shapes_of(m.state_dict())
+    with open(os.path.join(OUT, "sg1_keys.json"), "w") as f:
+        json.dump(keys, f)
+    # reduced generator: 6 blocks (4..128), channels 64,64,64,64,64,32; the last block uses the fused
+    # ConvTranspose2d(3, stride 2) + transform_kernel path (resolution >= 128), the others upscale2d + conv
+    G = SG1.Generator(startf=32, maxf=64, layer_count=6, latent_size=512, channels=3)
+    sd = R.fill_encoder(shapes_of(G.state_dict()), seed=41)
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = G.state_dict()[k].clone()
+        if k == "const":
+            sd[k] = R.randn("sg1.const", tuple(sd[k].shape), 41)
+    G.load_state_dict(sd)
+    styles = R.randn("sg1.styles", (2, 12, 512), 6)
+    out = {}
+    feats = {}
+    hooks = [G.decode_block[j].register_forward_hook(lambda m_, i, o, j=j: feats.__setitem__(j, o.detach().clone())) for j in range(6)]
+    with torch.no_grad(), _NoiseFeeder("sg1", 6) as nf:
+        img = G.forward(styles, 5)
+    for h in hooks:
+        h.remove()
+    out["image"] = img
+    out["noise_shapes"] = np.array([list(s_) for s_ in nf.log])
+    for j in (0, 1):
+        out[f"blk{j}"] = feats[j]
+    with torch.no_grad(), _NoiseFeeder("sg1b", 6):
+        out["image_lod3"] = G.forward(styles, 3)
+    out["state_checksum"] = np.array(R.checksum(sd))
+    # mapping with truncation towards buffer1 (E_align_s2.py:32-41)
+    M = SG1.Mapping(num_layers=12, mapping_layers=8, latent_size=512, dlatent_size=512, mapping_fmaps=512)
+    msd = {k: R.randn("sg1m." + k, tuple(v.shape), 42, 0.05 if k.endswith("weight") else 0.01) for k, v in M.state_dict().items()}
+    M.load_state_dict(msd)
+    M.buffer1 = R.randn("sg1m.buffer1", (12, 512), 42, 0.5)
+    layer_idx = torch.arange(12)[np.newaxis, :, np.newaxis]
+    coefs = torch.where(layer_idx < 6, 0.7 * torch.ones(1, 12, 1), torch.ones(1, 12, 1))
+    z = R.randn("sg1m.z", (3, 512), 42)
+    with torch.no_grad():
+        out["mapping_w"] = M(z, coefs_m=coefs)
+    save_npz("sg1_small.npz", **out)
+
+
+SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step, "sg1": gen_sg1}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
