@@ -183,6 +183,40 @@ __global__ void affine_compose_kernel(const float* __restrict__ sc, const float*
     a[idx] = sc[idx] * s0; bq[idx] = sh[idx] * s0 + s1;
 }
 
+// ------------------------------------------------------------------ PGGAN pixel norm (NHWC)
+// y[p,:] = x[p,:] / sqrt(mean_c x[p,c]^2 + eps)    (model/pggan/pggan_generator.py:207-216)
+// LPP lanes cooperate on one pixel with 16-byte accesses.
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void pixelnorm_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, long npix, int C, int lpp, float eps) {
+    constexpr int EP = Elem<T>::PER16;
+    const int lane = threadIdx.x & 63;
+    const int ppw = 64 / lpp, sub = lane / lpp, li = lane % lpp;
+    const long p = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ppw + sub;
+    const bool ok = p < npix;
+    float f[NJ][EP];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        if (ok) unpack16(*(const uint4*)(x + (size_t)p * C + (j * lpp + li) * EP), f[j], (T*)nullptr);
+        else {
+#pragma unroll
+            for (int e = 0; e < EP; e++) f[j][e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < EP; e++) s += f[j][e] * f[j][e];
+    }
+    for (int m = lpp >> 1; m > 0; m >>= 1) s += __shfl_xor(s, m, 64);
+    const float r = rsqrtf(s / (float)C + eps);
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+#pragma unroll
+            for (int e = 0; e < EP; e++) f[j][e] *= r;
+            *(uint4*)(y + (size_t)p * C + (j * lpp + li) * EP) = pack16(f[j], (T*)nullptr);
+        }
+    }
+}
+
 // =================================================================== C ABI
 static int grid_for(int hw, int ppi) {
     int g = (hw + ppi - 1) / ppi;
@@ -241,5 +275,27 @@ extern "C" int dge_blur_noise_act(const void* x, const float* noise, const float
 extern "C" int dge_affine_compose(const float* sc, const float* sh, const float* style, float* a, float* b, int B, int C, hipStream_t s) {
     hipLaunchKernelGGL(affine_compose_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, sc, sh, style, a, b, B, C);
     DGE_LAUNCH_CHECK("affine_compose");
+    return 0;
+}
+
+template <typename T>
+static int pixelnorm_nhwc_launch(const void* x, void* y, long npix, int C, float eps, hipStream_t s) {
+    constexpr int EP = Elem<T>::PER16;
+    const int chunks = C / EP;
+    const int lpp = chunks >= 64 ? 64 : chunks;
+    const int nj = chunks / lpp;
+    const long ppb = 4 * (64 / lpp);
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb));
+#define PN(NJ) hipLaunchKernelGGL((pixelnorm_nhwc_kernel<T, NJ>), grid, dim3(256), 0, s, (const T*)x, (T*)y, npix, C, lpp, eps)
+    if (nj == 1) PN(1); else if (nj == 2) PN(2); else { dge_set_error("pixelnorm_nhwc: unsupported C=%d", C); return -1; }
+#undef PN
+    return 0;
+}
+extern "C" int dge_pixelnorm_nhwc(const void* x, void* y, long npix, int C, float eps, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && ((C / ep) & (C / ep - 1)) == 0, "pixelnorm_nhwc: C=%d must be a power-of-two multiple of %d", C, ep);
+    const int rc = dtype == DGE_BF16 ? pixelnorm_nhwc_launch<bf16_t>(x, y, npix, C, eps, s) : pixelnorm_nhwc_launch<float>(x, y, npix, C, eps, s);
+    if (rc) return rc;
+    DGE_LAUNCH_CHECK("pixelnorm_nhwc");
     return 0;
 }

@@ -344,3 +344,11 @@ def lerp_layers(w, avg, coefs):
     check(lib().dge_lerp_layers(_f32(w), _f32(avg.contiguous()), stride, _f32(coefs.contiguous()), _p(out), B, L, D, _stream()),
           "dge_lerp_layers")
     return out
+
+
+# ------------------------------------------------------------------ PGGAN ops
+def pixelnorm_nhwc(x, eps=1e-8):
+    B, H, W, Cc = x.shape
+    y = torch.empty_like(x)
+    check(lib().dge_pixelnorm_nhwc(_p(x), _p(y), B * H * W, Cc, float(eps), dtype_of(x), _stream()), "dge_pixelnorm_nhwc")
+    return y

@@ -209,6 +209,10 @@ int dge_affine_compose(const float* sc, const float* sh, const float* style, flo
 int dge_lerp_layers(const float* w, const float* avg, int avg_stride, const float* coefs, float* out, int B, int L, int D,
                     dge_stream_t stream);
 
+/* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */
+/* pixel-wise feature normalisation over the channel axis of an NHWC tensor (PixelNormLayer :207-216) */
+int dge_pixelnorm_nhwc(const void* x, void* y, long npix, int C, float eps, int dtype, dge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

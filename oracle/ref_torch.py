@@ -332,3 +332,29 @@ def sg1_mapping(P, z, buffer1, coefs):
     L = coefs.numel()
     x = x[:, None].repeat(1, L, 1)
     return buffer1 + (x - buffer1) * coefs.view(1, L, 1)
+
+
+# ----------------------------------------------------------------------------- PGGAN
+def pg_pixel_norm(x):
+    return x / torch.sqrt(torch.mean(x * x, dim=1, keepdim=True) + 1e-8)
+
+
+def pg_generator(P, z):
+    """PGGANGenerator.forward (lod 0) model/pggan/pggan_generator.py:154-204 + ConvBlock.forward :319-339."""
+    def block(name, x, up=False, k=3, pad=1, gain=math.sqrt(2.0), act=True):
+        w = P[name + ".weight"]
+        x = pg_pixel_norm(x)
+        if up:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+        y = F.conv2d(x, w * (gain / math.sqrt(w.shape[1] * k * k)), P[name + ".bias"], padding=pad)
+        return F.leaky_relu(y, 0.2) if act else y
+    x = pg_pixel_norm(z).view(z.shape[0], -1, 1, 1)
+    # layer0: pixel norm is applied by forward() on z (:160) and again inside the ConvBlock (:320) - idempotent on [B,C,1,1]
+    x = block("layer0", x, k=4, pad=3)
+    k = 0
+    while f"layer{2 * k + 1}.weight" in P:
+        if k > 0:
+            x = block(f"layer{2 * k}", x, up=True)
+        x = block(f"layer{2 * k + 1}", x)
+        k += 1
+    return block(f"output{k - 1}", x, k=1, pad=0, gain=1.0, act=False)

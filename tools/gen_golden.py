@@ -432,7 +432,24 @@ def gen_sg1():
     save_npz("sg1_small.npz", **out)
 
 
-SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step, "sg1": gen_sg1}
+# --------------------------------------------------------------------------- PGGAN
+def gen_pggan():
+    import contextlib, io
+    from model.pggan.pggan_generator import PGGANGenerator
+    keys = {"256": shapes_of(PGGANGenerator(256).state_dict())}
+    with open(os.path.join(OUT, "pggan_keys.json"), "w") as f:
+        json.dump(keys, f)
+    G = PGGANGenerator(32, fmaps_base=1024, fmaps_max=64)
+    sd = {k: (R.randn("pg." + k, tuple(v.shape), 51, 0.2 if k.endswith("bias") else 1.0) if v.ndim else v.clone())
+          for k, v in G.state_dict().items()}
+    G.load_state_dict(sd)
+    z = R.randn("pg.z", (2, 512), 51)
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):    # the reference prints x.shape (:196)
+        r = G(z)
+    save_npz("pggan_small.npz", image=r["image"], z=r["z"], state_checksum=np.array(R.checksum(sd)))
+
+
+SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step, "sg1": gen_sg1, "pggan": gen_pggan}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
