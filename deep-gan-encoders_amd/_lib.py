@@ -65,7 +65,7 @@ SIGNATURES = {
     "dge_maxpool2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dge_lpips_head": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "dge_mean": [_P, _P, _I, _P],
-    "dge_blur_noise_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dge_blur_noise_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_affine_compose": [_P, _P, _P, _P, _P, _I, _I, _P],
     "dge_lerp_layers": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
     "dge_pixelnorm_nhwc": [_P, _P, C.c_long, _I, _F, _I, _P],

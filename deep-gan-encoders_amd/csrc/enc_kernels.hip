@@ -122,7 +122,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void blur_noise_act_kernel(const T* __restrict__ x, const float* __restrict__ noise,
                                                               const float* __restrict__ nw, const float* __restrict__ bias,
                                                               T* __restrict__ y, float* __restrict__ stats, int H, int W, int C,
-                                                              int do_blur, int noise_bstride) {
+                                                              int do_blur, int noise_bstride, int act) {
     constexpr int EP = Elem<T>::PER16;
     __shared__ float red[256 * 2 * EP];
     const int b = blockIdx.y;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void blur_noise_act_kernel(const T* __restrict
 #pragma unroll
             for (int e = 0; e < EP; e++) {
                 float v = f[e] + nwv[e] * nz + bv[e];
-                v = v > 0.f ? v : 0.2f * v;
+                if (act) v = v > 0.f ? v : 0.2f * v;
                 f[e] = v; sq[0][e] += v; sq[1][e] += v * v;
             }
             *(uint4*)(y + ((size_t)b * HW + p) * C + chunk * EP) = pack16(f, (T*)nullptr);
@@ -258,16 +258,16 @@ extern "C" int dge_blend(const void* x, const void* z, void* y, const float* sc,
 }
 
 extern "C" int dge_blur_noise_act(const void* x, const float* noise, const float* noise_w, const float* bias, void* y, float* stats,
-                                  int B, int H, int W, int C, int do_blur, int noise_batch, int dtype, hipStream_t s) {
+                                  int B, int H, int W, int C, int do_blur, int noise_batch, int act, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "blur_noise_act: unsupported channel count %d", C);
     const int ppi = 256 / (C / ep);
     dim3 grid(grid_for(H * W, ppi), B);
     const int nbs = noise_batch > 1 ? H * W : 0;
     if (dtype == DGE_BF16)
-        hipLaunchKernelGGL(blur_noise_act_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, noise, noise_w, bias, (bf16_t*)y, stats, H, W, C, do_blur, nbs);
+        hipLaunchKernelGGL(blur_noise_act_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, noise, noise_w, bias, (bf16_t*)y, stats, H, W, C, do_blur, nbs, act);
     else
-        hipLaunchKernelGGL(blur_noise_act_kernel<float>, grid, dim3(256), 0, s, (const float*)x, noise, noise_w, bias, (float*)y, stats, H, W, C, do_blur, nbs);
+        hipLaunchKernelGGL(blur_noise_act_kernel<float>, grid, dim3(256), 0, s, (const float*)x, noise, noise_w, bias, (float*)y, stats, H, W, C, do_blur, nbs, act);
     DGE_LAUNCH_CHECK("blur_noise_act");
     return 0;
 }

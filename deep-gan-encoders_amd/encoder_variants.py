@@ -1,0 +1,210 @@
+"""Encoder variants of the reference on the HIP kernels (forward):
+
+* `E_Blur.BE`  (model/E/E_Blur.py:16-134, "case 2", used by embedding_img.py): E.BE plus a depthwise
+  blur before conv_2 and, for block resolutions >= 128, a stride-2 conv_2 with `transform_kernel`
+  (model/utils/lreq.py:145-147).  That 4x4 stride-2 kernel 0.25*sum-of-4-shifts is algebraically
+  conv3x3 followed by avg_pool2d(2) (zero padding included), so it runs as conv3x3 + the pooling
+  blend; noise / bias / leaky_relu are then applied at the HALF resolution, as in the reference.
+* `E_PG.BE`    (model/E/E_PG.py:39-164, PGGAN encoder): IN -> conv -> noise -> bias -> lrelu -> IN ->
+  conv -> noise -> bias -> (+ affine-IN(conv1x1(residual))) -> lrelu -> avgpool; FC head.
+  The reference returns (tensor(0), tensor(0)); the evident intent is implemented:
+  `(tensor(0), new_final(x.view(B, -1)))`, and `trunk()` exposes the activation before the head.
+
+State_dict keys match the reference (110 keys for E_Blur 1024/16/9, 57 for E_PG 256/64/7).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from . import lreq as ln
+from . import ops
+from .autograd_enc import _packed, draw_noises
+from .encoder import FromRGB
+from .stylegan1 import Blur
+from .stylegan2_generator import _dt
+
+
+# ----------------------------------------------------------------------------------- E_Blur
+class BlurBEBlock(nn.Module):
+    def __init__(self, inputs, outputs, latent_size, has_last_conv=True, fused_scale=True):
+        super().__init__()
+        self.has_last_conv, self.fused_scale, self.inputs, self.outputs = has_last_conv, fused_scale, inputs, outputs
+        self.noise_weight_1 = nn.Parameter(torch.zeros(1, inputs, 1, 1))
+        self.bias_1 = nn.Parameter(torch.zeros(1, inputs, 1, 1))
+        self.inver_mod1 = ln.Linear(2 * inputs, latent_size, gain=1)
+        self.conv_1 = ln.Conv2d(inputs, inputs, 3, 1, 1, bias=False)
+        self.noise_weight_2 = nn.Parameter(torch.zeros(1, outputs, 1, 1))
+        self.bias_2 = nn.Parameter(torch.zeros(1, outputs, 1, 1))
+        self.inver_mod2 = ln.Linear(2 * inputs, latent_size, gain=1)
+        self.blur = Blur(inputs)
+        if has_last_conv:
+            self.conv_2 = ln.Conv2d(inputs, outputs, 3, 1, 1, bias=False)     # stride 2 is realised as conv + pool (see module doc)
+        if inputs != outputs:
+            self.conv_3 = ln.Conv2d(inputs, outputs, 1, 1, 0)
+
+
+class BlurBE(nn.Module):
+    """E_Blur.BE"""
+
+    def __init__(self, startf=16, maxf=512, layer_count=9, latent_size=512, channels=3, compute_dtype="bf16"):
+        super().__init__()
+        _dt(compute_dtype)
+        self.maxf, self.startf, self.latent_size, self.layer_count, self.compute_dtype = maxf, startf, latent_size, layer_count, compute_dtype
+        self.decode_block = nn.ModuleList()
+        self.FromRGB = FromRGB(channels, startf)
+        inputs, outputs, resolution = startf, startf * 2, 1024
+        for i in range(layer_count):
+            self.decode_block.append(BlurBEBlock(inputs, outputs, latent_size, i + 1 != layer_count, fused_scale=resolution >= 128))
+            inputs, outputs = min(maxf, inputs * 2), min(maxf, outputs * 2)
+            resolution /= 2
+
+    @torch.no_grad()
+    def forward(self, img, block_num=9, noises=None):
+        dt = _dt(self.compute_dtype)
+        dev = img.device
+        B, _, R, _ = img.shape
+        if noises is None:
+            noises = draw_noises(self, B, R, dev)
+            # fused-scale blocks draw their second noise at half resolution
+            ni = 0
+            for j, blk in enumerate(self.decode_block):
+                ni += 1
+                if blk.has_last_conv:
+                    if blk.fused_scale:
+                        r = (R >> j) // 2
+                        noises[ni] = torch.randn(B, 1, r, r, device=dev)
+                    ni += 1
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        zeros = lambda c: torch.zeros((B, c, 2), dtype=torch.float32, device=dev)
+        fr = self.FromRGB.from_rgb
+        stats = zeros(self.startf)
+        x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats)
+        ws, ni = [], 0
+        for j, blk in enumerate(self.decode_block):
+            Cc, C2, H = blk.inputs, blk.outputs, R >> j
+            last = not blk.has_last_conv
+            musig1, sc1, sh1 = ops.stats_finalize(stats, H * H)
+            w1 = ops.linear(musig1, blk.inver_mod1.weight.detach(), blk.inver_mod1.bias.detach())
+            n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
+            st1 = zeros(Cc)
+            x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
+                            noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
+                            act=ops.ACT_LRELU, stats=st1)
+            musig2, sc2, sh2 = ops.stats_finalize(st1, H * H)
+            w2 = ops.linear(musig2, blk.inver_mod2.weight.detach(), blk.inver_mod2.bias.detach())
+            nstats = zeros(C2) if not last else None
+            if not last:
+                y2 = ops.blur_noise_act(ops.blend(x1, sc=sc2, sh=sh2), None, None, None, blur=True, act=False)   # blur(IN2(x1))
+                wpk = _packed(cache, blk.conv_2, dt, ops.PACK_FWD)
+                n2 = noises[ni]; ni += 1
+                nw2, b2 = blk.noise_weight_2.detach().reshape(-1), blk.bias_2.detach().reshape(-1)
+                if blk.fused_scale:        # conv(s2, transform_kernel) == pool(conv); noise/bias/lrelu at half resolution
+                    t = ops.blend(ops.conv2d(y2, wpk, C2, 3), pool=True)
+                    x2 = ops.blur_noise_act(t, n2.reshape(B, H // 2, H // 2).contiguous(), nw2, b2, blur=False)
+                else:
+                    a2 = ops.conv2d(y2, wpk, C2, 3, noise=n2.reshape(B, H, H).contiguous(), noise_w=nw2, bias=b2, act=ops.ACT_LRELU)
+                    x2 = ops.blend(a2, pool=True)
+                xp = ops.blend(x, pool=True)
+                if Cc != C2:
+                    out = ops.conv2d(xp, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(),
+                                     gain=0.889, addend=x2, add_scale=0.111, stats=nstats)
+                else:
+                    out = ops.blend(x2, z=xp, alpha=0.111, beta=0.889, stats=nstats)
+            else:
+                out = ops.blend(x1, z=x, sc=sc2, sh=sh2, alpha=0.111, beta=0.889)
+            ws = [w2, w1] + ws
+            x, stats = out, nstats
+        return ops.nhwc_to_nchw(x), torch.stack(ws, dim=1)
+
+
+# ----------------------------------------------------------------------------------- E_PG
+class _AffineIN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+class PGBEBlock(nn.Module):
+    def __init__(self, inputs, outputs, latent_size, has_second_conv=True):
+        super().__init__()
+        self.has_second_conv, self.inputs, self.outputs = has_second_conv, inputs, outputs
+        self.noise_weight_1 = nn.Parameter(torch.zeros(1, inputs, 1, 1))
+        self.bias_1 = nn.Parameter(torch.zeros(1, inputs, 1, 1))
+        self.conv_1 = ln.Conv2d(inputs, inputs, 3, 1, 1, bias=False)
+        self.noise_weight_2 = nn.Parameter(torch.zeros(1, outputs, 1, 1))
+        self.bias_2 = nn.Parameter(torch.zeros(1, outputs, 1, 1))
+        if has_second_conv:
+            self.conv_2 = ln.Conv2d(inputs, outputs, 3, 1, 1, bias=False)
+        if inputs != outputs:
+            self.conv_3 = ln.Conv2d(inputs, outputs, 1, 1, 0)
+            self.instance_norm_3 = _AffineIN(outputs)
+
+
+class PGBE(nn.Module):
+    """E_PG.BE"""
+
+    def __init__(self, startf=16, maxf=512, layer_count=9, latent_size=512, channels=3, pggan=False, compute_dtype="bf16"):
+        super().__init__()
+        _dt(compute_dtype)
+        self.maxf, self.startf, self.latent_size, self.layer_count, self.compute_dtype = maxf, startf, latent_size, layer_count, compute_dtype
+        self.decode_block = nn.ModuleList()
+        self.FromRGB = FromRGB(channels, startf)
+        inputs, outputs = startf, startf * 2
+        for i in range(layer_count):
+            self.decode_block.append(PGBEBlock(inputs, outputs, latent_size, i + 1 != layer_count))
+            inputs, outputs = min(maxf, inputs * 2), min(maxf, outputs * 2)
+        self.pggan = pggan
+        if pggan:
+            self.new_final = ln.Linear(512 * 16, latent_size, gain=1)
+
+    @torch.no_grad()
+    def trunk(self, img, noises=None):
+        """Activation [B,C,4,4] (NCHW f32) after the last block - what the reference computes and then discards."""
+        dt = _dt(self.compute_dtype)
+        dev = img.device
+        B, _, R, _ = img.shape
+        if noises is None:
+            noises = draw_noises(self, B, R, dev)
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        zeros = lambda c: torch.zeros((B, c, 2), dtype=torch.float32, device=dev)
+        fr = self.FromRGB.from_rgb
+        stats = zeros(self.startf)
+        x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats)
+        ni = 0
+        for j, blk in enumerate(self.decode_block):
+            Cc, C2, H = blk.inputs, blk.outputs, R >> j
+            _, sc1, sh1 = ops.stats_finalize(stats, H * H)
+            st1 = zeros(Cc)
+            x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1,
+                            noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_1.detach().reshape(-1),
+                            bias=blk.bias_1.detach().reshape(-1), act=ops.ACT_LRELU, stats=st1)
+            ni += 1
+            if not blk.has_second_conv:
+                x = x1
+                break
+            _, sc2, sh2 = ops.stats_finalize(st1, H * H)
+            pre2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=sc2, in_shift=sh2,
+                              noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_2.detach().reshape(-1),
+                              bias=blk.bias_2.detach().reshape(-1))
+            ni += 1
+            if Cc != C2:
+                st3 = zeros(C2)
+                r3 = ops.conv2d(x, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(), stats=st3)
+                _, sc3, sh3 = ops.stats_finalize(st3, H * H)
+                g, bta = blk.instance_norm_3.weight.detach(), blk.instance_norm_3.bias.detach()
+                s = ops.blend(r3, z=pre2, sc=(sc3 * g).contiguous(), sh=(sh3 * g + bta).contiguous(), alpha=1.0, beta=1.0)
+            else:
+                s = ops.blend(x, z=pre2, alpha=1.0, beta=1.0)
+            nstats = zeros(C2)
+            x = ops.blend(ops.blur_noise_act(s, None, None, None, blur=False), pool=True, stats=nstats)     # lrelu, then avg_pool2d
+            stats = nstats
+        return ops.nhwc_to_nchw(x)
+
+    @torch.no_grad()
+    def forward(self, img, block_num=9, noises=None):
+        x = self.trunk(img, noises)
+        if not self.pggan:
+            return torch.tensor(0), torch.tensor(0)
+        z = ops.linear(x.reshape(x.shape[0], -1).contiguous(), self.new_final.weight.detach(), self.new_final.bias.detach())
+        return torch.tensor(0), z

@@ -318,12 +318,12 @@ def scale_(t, factor):
 
 
 # ------------------------------------------------------------------ StyleGAN1 ops
-def blur_noise_act(x, noise, noise_w, bias, blur=True, stats=None):
+def blur_noise_act(x, noise, noise_w, bias, blur=True, stats=None, act=True):
     B, H, W, Cc = x.shape
     y = torch.empty_like(x)
     check(lib().dge_blur_noise_act(_p(x), _f32(noise), _f32(noise_w), _f32(bias), _p(y), _f32(stats), B, H, W, Cc,
-                                   1 if blur else 0, 1 if noise is None else noise.shape[0], dtype_of(x), _stream()),
-          "dge_blur_noise_act")
+                                   1 if blur else 0, 1 if noise is None else noise.shape[0], 1 if act else 0, dtype_of(x),
+                                   _stream()), "dge_blur_noise_act")
     return y
 
 

@@ -198,10 +198,10 @@ int dge_lpips_head(const void* feat, const float* lin, float* val, void* g1, int
 int dge_mean(const float* v, float* out, int n, dge_stream_t stream);
 
 /* ---- StyleGAN1 (model/stylegan1/net.py) streaming kernels ---------------------------------- */
-/* y = lrelu(blur3x3(x) + noise_w[c]*noise[b,p] + bias[c], 0.2) with optional per-(b,c) statistics:
+/* y = act(blur3x3(x) + noise_w[c]*noise[b,p] + bias[c]) (act: 0 none, 1 lrelu 0.2; blur/noise/bias optional) with optional per-(b,c) statistics:
  * Blur :48-58 ([1,2,1]^2/16, zero pad) + the noise/bias/leaky_relu of DecodeBlock.forward :146-152,158-164. */
 int dge_blur_noise_act(const void* x, const float* noise, const float* noise_w, const float* bias, void* y, float* stats,
-                       int B, int H, int W, int C, int do_blur, int noise_batch, int dtype, dge_stream_t stream);
+                       int B, int H, int W, int C, int do_blur, int noise_batch, int act, int dtype, dge_stream_t stream);
 /* instance norm + style_mod as one per-(b,c) affine: a = sc*(s0+1), b = sh*(s0+1) + s1 with style [B,2C] = [s0 | s1]
  * (style_mod :32-34 after InstanceNorm2d :153-156) */
 int dge_affine_compose(const float* sc, const float* sh, const float* style, float* a, float* b, int B, int C, dge_stream_t stream);

@@ -358,3 +358,62 @@ def pg_generator(P, z):
         x = block(f"layer{2 * k + 1}", x)
         k += 1
     return block(f"output{k - 1}", x, k=1, pad=0, gain=1.0, act=False)
+
+
+# ----------------------------------------------------------------------------- encoder variants
+def enc_blur_forward(P, img, noises, fused):
+    """E_Blur.BE.forward (model/E/E_Blur.py:50-85,122-135): E.BE + blur before conv_2; blocks with
+    fused[j] use conv2d(stride 2) with the transform_kernel weights (model/utils/lreq.py:145-147)."""
+    x = F.leaky_relu(F.conv2d(img, P["FromRGB.from_rgb.weight"], P["FromRGB.from_rgb.bias"]), 0.2)
+    L = len(fused)
+    ws, ni = [], 0
+    for j in range(L):
+        pre = f"decode_block.{j}."
+        last = (j == L - 1)
+        m1, v1 = enc_stats(x)
+        w1 = torch.cat([m1, v1.sqrt()], 1) @ P[pre + "inver_mod1.weight"].t() + P[pre + "inver_mod1.bias"]
+        res = x
+        y = F.conv2d(inorm(x, m1, v1), P[pre + "conv_1.weight"], padding=1)
+        y = F.leaky_relu(y + P[pre + "noise_weight_1"] * noises[ni] + P[pre + "bias_1"], 0.2); ni += 1
+        m2, v2 = enc_stats(y)
+        w2 = torch.cat([m2, v2.sqrt()], 1) @ P[pre + "inver_mod2.weight"].t() + P[pre + "inver_mod2.bias"]
+        y = inorm(y, m2, v2)
+        if not last:
+            y = sg1_blur(y)
+            w = P[pre + "conv_2.weight"]
+            if fused[j]:
+                wp = F.pad(w, (1, 1, 1, 1))
+                w4 = (wp[:, :, 1:, 1:] + wp[:, :, :-1, 1:] + wp[:, :, 1:, :-1] + wp[:, :, :-1, :-1]) * 0.25
+                y = F.conv2d(y, w4, stride=2, padding=1)
+            else:
+                y = F.conv2d(y, w, padding=1)
+            y = F.leaky_relu(y + P[pre + "noise_weight_2"] * noises[ni] + P[pre + "bias_2"], 0.2); ni += 1
+            if not fused[j]:
+                y = F.avg_pool2d(y, 2, 2)
+            res = F.avg_pool2d(res, 2, 2)
+        if pre + "conv_3.weight" in P:
+            res = F.conv2d(res, P[pre + "conv_3.weight"], P[pre + "conv_3.bias"])
+        x = 0.111 * y + 0.889 * res
+        ws = [w2, w1] + ws
+    return x, torch.stack(ws, dim=1)
+
+
+def encpg_forward(P, img, noises, L):
+    """E_PG.BE trunk + head (model/E/E_PG.py:73-108,150-164) with the evident-intent return."""
+    x = F.leaky_relu(F.conv2d(img, P["FromRGB.from_rgb.weight"], P["FromRGB.from_rgb.bias"]), 0.2)
+    ni = 0
+    for j in range(L):
+        pre = f"decode_block.{j}."
+        res = x
+        x = F.conv2d(inorm(x, *enc_stats(x)), P[pre + "conv_1.weight"], padding=1)
+        x = F.leaky_relu(x + P[pre + "noise_weight_1"] * noises[ni] + P[pre + "bias_1"], 0.2); ni += 1
+        if j == L - 1:
+            break
+        x = F.conv2d(inorm(x, *enc_stats(x)), P[pre + "conv_2.weight"], padding=1)
+        x = x + P[pre + "noise_weight_2"] * noises[ni] + P[pre + "bias_2"]; ni += 1
+        if pre + "conv_3.weight" in P:
+            res = F.conv2d(res, P[pre + "conv_3.weight"], P[pre + "conv_3.bias"])
+            res = inorm(res, *enc_stats(res)) * P[pre + "instance_norm_3.weight"].view(1, -1, 1, 1) + P[pre + "instance_norm_3.bias"].view(1, -1, 1, 1)
+        x = F.avg_pool2d(F.leaky_relu(x + res, 0.2), 2, 2)
+    z = x.reshape(x.shape[0], -1) @ P["new_final.weight"].t() + P["new_final.bias"] if "new_final.weight" in P else None
+    return x, z

@@ -1,0 +1,85 @@
+"""Encoder variants E_Blur and E_PG (a10): oracle vs reference golden (CPU), HIP vs golden (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden, ROOT
+from tests.golden import recipe as R
+from oracle import ref_torch as O
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu(); b = torch.as_tensor(np.asarray(b)).float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def blur_params(E):
+    sd = R.fill_encoder({k: list(v.shape) for k, v in E.state_dict().items()}, seed=61)
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = E.state_dict()[k].clone()
+    return sd
+
+
+def pg_params(E):
+    sd = R.fill_encoder({k: list(v.shape) for k, v in E.state_dict().items()}, seed=62)
+    for k in sd:
+        if "instance_norm_3.weight" in k:
+            sd[k] = R.randn("pg." + k, tuple(sd[k].shape), 62, 0.2, 1.0)
+    return sd
+
+
+def test_state_dicts_and_oracles():
+    from dge_amd.encoder_variants import BlurBE, PGBE
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "encvar_keys.json")))
+    sd = BlurBE(startf=16, maxf=512, layer_count=9).state_dict()
+    assert list(sd.keys()) == list(k["E_Blur_1024_16_9"].keys()) and all(list(sd[n].shape) == k["E_Blur_1024_16_9"][n] for n in sd)
+    sd = PGBE(startf=64, maxf=512, layer_count=7, pggan=True).state_dict()
+    assert set(sd.keys()) == set(k["E_PG_256_64_7"].keys()) and all(list(sd[n].shape) == k["E_PG_256_64_7"][n] for n in sd)
+    assert len(k["E_Blur_1024_16_9"]) == 110 and len(k["E_PG_256_64_7"]) == 57
+    # oracle vs the reference's outputs
+    g = golden("encblur_small.npz")
+    P = blur_params(BlurBE(startf=16, maxf=64, layer_count=6))
+    assert abs(R.checksum(P) - float(g["state_checksum"])) < 1e-6 * float(g["state_checksum"])
+    noises = [R.randn(f"eb.noise{i}", tuple(s), 61) for i, s in enumerate(g["noise_shapes"].tolist())]
+    x, w = O.enc_blur_forward(P, R.randn("eb.img", (2, 3, 128, 128), 61, 0.5), noises, [bool(v) for v in g["fused"]])
+    assert relerr(x, g["x"]) < 2e-4 and relerr(w, g["w"]) < 2e-4
+    g = golden("encpg_small.npz")
+    P = pg_params(PGBE(startf=32, maxf=512, layer_count=5, pggan=True))
+    assert abs(R.checksum(P) - float(g["state_checksum"])) < 1e-6 * float(g["state_checksum"])
+    noises = [R.randn(f"ep.noise{i}", tuple(s), 62) for i, s in enumerate(g["noise_shapes"].tolist())]
+    x, z = O.encpg_forward(P, R.randn("ep.img", (2, 3, 64, 64), 62, 0.5), noises, 5)
+    assert relerr(x, g["trunk"]) < 2e-4 and relerr(z, g["head"]) < 2e-4
+    assert float(g["ret0"]) == 0 and float(g["ret1"]) == 0        # quirk Q5: the reference returns (0, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_hip_e_blur_vs_reference_golden(cd):
+    from dge_amd.encoder_variants import BlurBE
+    g = golden("encblur_small.npz")
+    E = BlurBE(startf=16, maxf=64, layer_count=6, compute_dtype=cd).cuda()
+    E.load_state_dict(blur_params(E))
+    assert [int(b.fused_scale) for b in E.decode_block] == g["fused"].tolist()
+    noises = [R.randn(f"eb.noise{i}", tuple(s), 61).cuda() for i, s in enumerate(g["noise_shapes"].tolist())]
+    x, w = E(R.randn("eb.img", (2, 3, 128, 128), 61, 0.5).cuda(), noises=noises)
+    tol = 3e-4 if cd == "f32" else 5e-2
+    assert relerr(w, g["w"]) < tol and relerr(x, g["x"]) < tol, (relerr(w, g["w"]), relerr(x, g["x"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_hip_e_pg_vs_reference_golden(cd):
+    from dge_amd.encoder_variants import PGBE
+    g = golden("encpg_small.npz")
+    E = PGBE(startf=32, maxf=512, layer_count=5, pggan=True, compute_dtype=cd).cuda()
+    E.load_state_dict(pg_params(E))
+    noises = [R.randn(f"ep.noise{i}", tuple(s), 62).cuda() for i, s in enumerate(g["noise_shapes"].tolist())]
+    img = R.randn("ep.img", (2, 3, 64, 64), 62, 0.5).cuda()
+    tol = 3e-4 if cd == "f32" else 5e-2
+    assert relerr(E.trunk(img, noises), g["trunk"]) < tol
+    zero, z = E(img, noises=noises)
+    assert float(zero) == 0 and relerr(z, g["head"]) < tol

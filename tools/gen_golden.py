@@ -449,7 +449,46 @@ def gen_pggan():
     save_npz("pggan_small.npz", image=r["image"], z=r["z"], state_checksum=np.array(R.checksum(sd)))
 
 
-SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step, "sg1": gen_sg1, "pggan": gen_pggan}
+# --------------------------------------------------------------------------- encoder variants
+def gen_encvar():
+    import model.E.E_Blur as EB
+    import model.E.E_PG as EP
+    keys = {"E_Blur_1024_16_9": shapes_of(EB.BE(startf=16, maxf=512, layer_count=9).state_dict()),
+            "E_PG_256_64_7": shapes_of(EP.BE(startf=64, maxf=512, layer_count=7, pggan=True).state_dict())}
+    with open(os.path.join(OUT, "encvar_keys.json"), "w") as f:
+        json.dump(keys, f)
+    # E_Blur: 6 blocks on a 128x128 input; blocks 0-3 take the stride-2 transform_kernel path (ctor resolution >= 128)
+    E = EB.BE(startf=16, maxf=64, layer_count=6)
+    sd = R.fill_encoder(shapes_of(E.state_dict()), seed=61)
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = E.state_dict()[k].clone()
+    E.load_state_dict(sd)
+    img = R.randn("eb.img", (2, 3, 128, 128), 61, 0.5)
+    with torch.no_grad(), _NoiseFeeder("eb", 61) as nf:
+        x, w = E(img)
+    save_npz("encblur_small.npz", x=x, w=w, noise_shapes=np.array([list(s_) for s_ in nf.log]), state_checksum=np.array(R.checksum(sd)),
+             fused=np.array([int(b.fused_scale) for b in E.decode_block]))
+    # E_PG: 5 blocks on 64x64 (startf 32 -> 512 channels at 4x4, as new_final expects 512*16 inputs)
+    E = EP.BE(startf=32, maxf=512, layer_count=5, pggan=True)
+    sd = R.fill_encoder(shapes_of(E.state_dict()), seed=62)
+    for k in sd:
+        if "instance_norm_3.weight" in k:
+            sd[k] = R.randn("pg." + k, tuple(sd[k].shape), 62, 0.2, 1.0)
+    E.load_state_dict(sd)
+    img = R.randn("ep.img", (2, 3, 64, 64), 62, 0.5)
+    feats = {}
+    h1 = E.decode_block[4].register_forward_hook(lambda m_, i, o: feats.__setitem__("trunk", o[0].detach().clone()))
+    h2 = E.new_final.register_forward_hook(lambda m_, i, o: feats.__setitem__("head", o.detach().clone()))
+    with torch.no_grad(), _NoiseFeeder("ep", 62) as nf:
+        r = E(img)
+    h1.remove(); h2.remove()
+    save_npz("encpg_small.npz", trunk=feats["trunk"], head=feats["head"], ret0=r[0], ret1=r[1],
+             noise_shapes=np.array([list(s_) for s_ in nf.log]), state_checksum=np.array(R.checksum(sd)))
+
+
+SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step, "sg1": gen_sg1, "pggan": gen_pggan,
+            "encvar": gen_encvar}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
