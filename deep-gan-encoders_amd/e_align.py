@@ -35,6 +35,9 @@ class EAlignStep:
         self.reference_noise = reference_noise      # True: CPU-generated noise in the reference's order (Q6)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        # DGE_FORCE_DIST=1 exercises the collective code path on a 1-rank group (single-GPU validation of the DDP wiring)
+        import os
+        self.dist_on = self.world > 1 or (os.environ.get("DGE_FORCE_DIST") == "1" and dist.is_initialized())
         self.exact_ddp = exact_ddp
         self.dev = next(E.parameters()).device
         self._flat = None
@@ -43,7 +46,7 @@ class EAlignStep:
     # ------------------------------------------------------------------ DDP gradient exchange
     def _sync_grads(self):
         """All-reduce (sum) of every encoder gradient as one flat bucket; p.grad become views."""
-        if self.world == 1:
+        if not getattr(self, "dist_on", self.world > 1):
             return None
         ps = [p for p in self.E.parameters() if p.grad is not None]
         n = sum(p.numel() for p in ps)
@@ -82,7 +85,7 @@ class EAlignStep:
         const2, w2 = E(imgs1, noises=noises)
         imgs2 = G.synthesis(w2)["image"]
 
-        gctx = losses.GlobalBatch(self.world) if (self.world > 1 and self.exact_ddp) else None
+        gctx = losses.GlobalBatch(self.world) if (self.dist_on and self.exact_ddp) else None
         loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, global_batch=gctx)
         self.opt.zero_grad()
         loss_tsa.backward(retain_graph=True)

@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
         for p in lin.parameters():
             p.fill_(0.5)
     st = EAlignStep.__new__(EAlignStep)
-    st.E, st.world, st.rank, st.exact_ddp, st.dev, st._flat = lin, world, rank, True, torch.device("cpu"), None
+    st.E, st.world, st.rank, st.exact_ddp, st.dev, st._flat, st.dist_on = lin, world, rank, True, torch.device("cpu"), None, True
     for p in lin.parameters():
         p.grad = torch.full_like(p, float(rank + 1))
     gs = st._sync_grads()
