@@ -18,7 +18,7 @@ class ConvDesc(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
         ("ksize", C.c_int), ("up", C.c_int), ("in_s2d", C.c_int), ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int),
         ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float), ("add_scale", C.c_float),
-        ("dtype", C.c_int), ("in_up2", C.c_int), ("stats_slots", C.c_int),
+        ("dtype", C.c_int), ("in_up2", C.c_int), ("in_relu", C.c_int), ("stats_slots", C.c_int),
     ]
 
 
@@ -69,6 +69,10 @@ SIGNATURES = {
     "dge_affine_compose": [_P, _P, _P, _P, _P, _I, _I, _P],
     "dge_lerp_layers": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
     "dge_pixelnorm_nhwc": [_P, _P, C.c_long, _I, _F, _I, _P],
+    "dge_cbn_affine": [_P, _P, _I, _P, _P, _F, _P, _P, _I, _I, _P],
+    "dge_slice_up": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dge_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dge_rgb_tanh": [_P, _P, _I, _I, _I, _I, _P],
     "dge_version": [],
 }
 

@@ -1,0 +1,119 @@
+// BigGAN-deep support kernels (reference model/biggan_generator.py): conditional batch norm as a
+// per-(b,c) affine, skip-path channel drop + nearest upsample, self-attention, final tanh.
+// The convolutions / dense layers run on conv_igemm / linear_kernel.
+#include "common.h"
+#include "../../include/dge_hip.h"
+
+// a = (1 + scale[b,c]) / sqrt(var[c] + eps) ; b = offset[b,c] - mean[c]*a          (:127-150)
+__global__ void cbn_affine_kernel(const float* __restrict__ scale, const float* __restrict__ offset, int ld,
+                                  const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                  float* __restrict__ a, float* __restrict__ bq, int B, int C) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const int b = idx / C, c = idx % C;
+    const float av = (1.f + scale[(size_t)b * ld + c]) / sqrtf(var[c] + eps);
+    a[idx] = av;
+    bq[idx] = offset[(size_t)b * ld + c] - mean[c] * av;
+}
+
+// y[b,oy,ox,c] = x[b,oy>>up,ox>>up,c] for c < Cout
+template <typename T>
+__global__ void slice_up_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int Cin, int Cout, int up) {
+    constexpr int EP = Elem<T>::PER16;
+    const int OH = H << up, OW = W << up, cpt = Cout / EP;
+    const long n = (long)B * OH * OW * cpt;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n) return;
+    const int ch = idx % cpt; long r = idx / cpt; const int ox = r % OW; r /= OW; const int oy = r % OH; const int b = r / OH;
+    *(uint4*)(y + (((size_t)b * OH + oy) * OW + ox) * Cout + ch * EP) =
+        *(const uint4*)(x + (((size_t)b * H + (oy >> up)) * W + (ox >> up)) * Cin + ch * EP);
+}
+
+// One wavefront per query.  Scores: lanes own keys m = lane, lane+64, ... (query row held in LDS);
+// softmax by wave reductions; output: lanes own DV/64-channel slices and walk all keys (probabilities in LDS).
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q, const T* __restrict__ K, const T* __restrict__ V,
+                                                         T* __restrict__ O, int B, int N, int M, int D, int DV) {
+    extern __shared__ float sm[];                       // per wave: q[D] + p[M]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* qs = sm + wave * (D + M);
+    float* ps = qs + D;
+    const long qi = (long)blockIdx.x * 4 + wave;
+    if (qi >= (long)B * N) return;
+    const int b = qi / N;
+    const T* qp = Q + (size_t)qi * D;
+    for (int d = lane; d < D; d += 64) qs[d] = Elem<T>::ld(qp + d);
+    __builtin_amdgcn_wave_barrier();
+    const T* Kb = K + (size_t)b * M * D;
+    float mx = -INFINITY;
+    for (int m = lane; m < M; m += 64) {
+        const T* kp = Kb + (size_t)m * D;
+        float s = 0.f;
+        for (int d = 0; d < D; d++) s += qs[d] * Elem<T>::ld(kp + d);
+        ps[m] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int m = lane; m < M; m += 64) { const float e = __expf(ps[m] - mx); ps[m] = e; sum += e; }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.f / sum;
+    const T* Vb = V + (size_t)b * M * DV;
+    T* op = O + (size_t)qi * DV;
+    for (int c0 = lane; c0 < DV; c0 += 64) {
+        float acc = 0.f;
+        for (int m = 0; m < M; m++) acc += ps[m] * Elem<T>::ld(Vb + (size_t)m * DV + c0);
+        Elem<T>::st(op + c0, acc * inv);
+    }
+}
+
+template <typename T>
+__global__ void rgb_tanh_kernel(const T* __restrict__ x, float* __restrict__ img, int B, int HW, int C) {
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= (long)B * HW) return;
+    const int b = idx / HW, p = idx % HW;
+    const T* xp = x + (size_t)idx * C;
+#pragma unroll
+    for (int c = 0; c < 3; c++) img[((size_t)b * 3 + c) * HW + p] = tanhf(Elem<T>::ld(xp + c));
+}
+
+// =================================================================== C ABI
+extern "C" int dge_cbn_affine(const float* scale, const float* offset, int ld, const float* mean, const float* var, float eps,
+                              float* a, float* b, int B, int C, hipStream_t s) {
+    hipLaunchKernelGGL(cbn_affine_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, scale, offset, ld, mean, var, eps, a, b, B, C);
+    DGE_LAUNCH_CHECK("cbn_affine");
+    return 0;
+}
+
+extern "C" int dge_slice_up(const void* x, void* y, int B, int H, int W, int Cin, int Cout, int up, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(Cout % ep == 0 && Cin % ep == 0 && Cout <= Cin && (up == 0 || up == 1), "slice_up: bad arguments");
+    const long n = (long)B * (H << up) * (W << up) * (Cout / ep);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(slice_up_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, Cin, Cout, up);
+    else hipLaunchKernelGGL(slice_up_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, Cin, Cout, up);
+    DGE_LAUNCH_CHECK("slice_up");
+    return 0;
+}
+
+extern "C" int dge_attention(const void* q, const void* k, const void* v, void* o, int B, int N, int M, int D, int DV, int dtype,
+                             hipStream_t s) {
+    const size_t shm = (size_t)4 * (D + M) * sizeof(float);
+    DGE_CHECK(shm <= 64 * 1024, "attention: %d keys x %d dims do not fit the LDS score buffer", M, D);
+    const long nq = (long)B * N;
+    dim3 grid((unsigned)((nq + 3) / 4));
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(attention_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, B, N, M, D, DV);
+    else hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), shm, s, (const float*)q, (const float*)k, (const float*)v, (float*)o, B, N, M, D, DV);
+    DGE_LAUNCH_CHECK("attention");
+    return 0;
+}
+
+extern "C" int dge_rgb_tanh(const void* x, float* img, int B, int HW, int C, int dtype, hipStream_t s) {
+    DGE_CHECK(C >= 3, "rgb_tanh: need at least 3 channels");
+    const long n = (long)B * HW;
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(rgb_tanh_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, img, B, HW, C);
+    else hipLaunchKernelGGL(rgb_tanh_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)x, img, B, HW, C);
+    DGE_LAUNCH_CHECK("rgb_tanh");
+    return 0;
+}

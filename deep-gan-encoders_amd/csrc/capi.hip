@@ -21,6 +21,7 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(!d->in_up2 || (!d->in_s2d && d->H % 2 == 0 && d->W % 2 == 0), "conv2d: in_up2 needs even H, W and no in_s2d");
     DGE_CHECK(!d->in_s2d || d->Cin % 4 == 0, "conv2d: in_s2d needs Cin %% 4 == 0");
     DGE_CHECK(!d->dot_src || d->stats, "conv2d: dot_src needs a stats buffer");
+    DGE_CHECK(!d->in_relu || d->in_scale || d->in_shift, "conv2d: in_relu is applied together with the prologue affine");
     DGE_CHECK(!d->noise || d->noise_w, "conv2d: noise without noise_w");
     ConvParams p;
     p.x = d->x; p.w = d->w_packed; p.y = d->y; p.addend = d->addend; p.dot_src = d->dot_src;
@@ -29,7 +30,7 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
     p.Ntot_valid = d->up ? 4 * d->Cout : d->Cout;
     p.Ntot = dge_packed_n(p.Ntot_valid);
-    p.up = d->up; p.in_s2d = d->in_s2d; p.in_up2 = d->in_up2;
+    p.up = d->up; p.in_s2d = d->in_s2d; p.in_up2 = d->in_up2; p.in_relu = d->in_relu;
     const int OH = d->up ? 2 * d->H : d->H, OW = d->up ? 2 * d->W : d->W;
     p.noise_bstride = d->noise_batch > 1 ? OH * OW : 0;
     p.noise_w_stride = d->noise_w_per_channel ? 1 : 0;

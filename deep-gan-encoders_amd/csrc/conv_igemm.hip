@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                     float f[EP16];
                     unpack16(v, f, (T*)nullptr);
 #pragma unroll
-                    for (int e = 0; e < EP16; e++) f[e] = f[e] * asc[e] + ash[e];
+                    for (int e = 0; e < EP16; e++) { f[e] = f[e] * asc[e] + ash[e]; if (p.in_relu) f[e] = fmaxf(f[e], 0.f); }
                     v = pack16(f, (T*)nullptr);
                 }
                 *(uint4*)(ldsA + hy * C::RPITCH + hx * C::PSTR + achunk * 16) = v;

@@ -21,6 +21,7 @@ struct ConvParams {
     int Ntot_valid;           // unpadded N
     int up;                   // 1: depth-to-space x2 store of the 4 folded phases
     int in_s2d;               // 1: x is [B,2H,2W,Cin/4], read space-to-depth (adjoint of `up`)
+    int in_relu;              // 1: ReLU after the prologue affine (BigGAN: BN -> ReLU -> conv)
     int in_up2;               // 1: x is [B,H/2,W/2,Cin], read through a nearest-neighbour x2 upsample
     int noise_bstride;        // 0 (shared noise) or OH*OW
     int noise_w_stride;       // 0 or 1

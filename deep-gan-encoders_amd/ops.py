@@ -103,7 +103,7 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None, in_up2=False):
+           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout]."""
     B, H, W, Cin = x.shape
     if in_s2d:            # x is the fine grid [B,2H,2W,C]; logical input is [B,H,W,4C]
@@ -128,6 +128,7 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d.stats_slots = nslot
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
     d.ksize, d.up, d.in_s2d, d.in_up2 = ksize, 1 if up else 0, 1 if in_s2d else 0, 1 if in_up2 else 0
+    d.in_relu = 1 if in_relu else 0
     d.noise_batch = 1 if noise is None else noise.shape[0]
     d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
     d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt
@@ -352,3 +353,45 @@ def pixelnorm_nhwc(x, eps=1e-8):
     y = torch.empty_like(x)
     check(lib().dge_pixelnorm_nhwc(_p(x), _p(y), B * H * W, Cc, float(eps), dtype_of(x), _stream()), "dge_pixelnorm_nhwc")
     return y
+
+
+# ------------------------------------------------------------------ BigGAN ops
+def cbn_affine(scale, offset, mean, var, eps):
+    """scale/offset: [B,C] (or [1,C] batch-shared); mean/var: [C] -> a, b [B,C]"""
+    B, Cc = scale.shape
+    a = torch.empty((B, Cc), dtype=torch.float32, device=scale.device)
+    b = torch.empty_like(a)
+    check(lib().dge_cbn_affine(_f32(scale), _f32(offset), Cc, _f32(mean.contiguous()), _f32(var.contiguous()), float(eps),
+                               _p(a), _p(b), B, Cc, _stream()), "dge_cbn_affine")
+    return a, b
+
+
+def slice_up(x, cout, up):
+    B, H, W, Cin = x.shape
+    f = 2 if up else 1
+    y = torch.empty((B, H * f, W * f, cout), dtype=x.dtype, device=x.device)
+    check(lib().dge_slice_up(_p(x), _p(y), B, H, W, Cin, cout, 1 if up else 0, dtype_of(x), _stream()), "dge_slice_up")
+    return y
+
+
+def attention(q, k, v):
+    """q [B,N,D], k [B,M,D], v [B,M,DV] -> [B,N,DV] (softmax over the M keys, no scaling)"""
+    B, N, D = q.shape
+    M, DV = k.shape[1], v.shape[2]
+    o = torch.empty((B, N, DV), dtype=q.dtype, device=q.device)
+    check(lib().dge_attention(_p(q), _p(k), _p(v), _p(o), B, N, M, D, DV, dtype_of(q), _stream()), "dge_attention")
+    return o
+
+
+def maxpool2(x):
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+    check(lib().dge_maxpool2(_p(x), _p(y), B, H, W, Cc, dtype_of(x), _stream()), "dge_maxpool2")
+    return y
+
+
+def rgb_tanh(x):
+    B, H, W, Cc = x.shape
+    img = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    check(lib().dge_rgb_tanh(_p(x), _p(img), B, H * W, Cc, dtype_of(x), _stream()), "dge_rgb_tanh")
+    return img

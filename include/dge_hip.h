@@ -71,6 +71,7 @@ typedef struct dge_conv_desc {
     float bias_scale, gain, add_scale;
     int dtype;
     int in_up2;               /* 1: x is [B,H/2,W/2,Cin] read through a nearest x2 upsample (upscale2d, model/stylegan1/net.py:37-43) */
+    int in_relu;              /* 1: ReLU after the prologue affine (BigGAN BN -> ReLU -> conv, model/biggan_generator.py:178-196) */
     int stats_slots;          /* >=1: workgroups spread their statistics atomics over this many copies (combine with dge_sum_slots) */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
@@ -212,6 +213,19 @@ int dge_lerp_layers(const float* w, const float* avg, int avg_stride, const floa
 /* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */
 /* pixel-wise feature normalisation over the channel axis of an NHWC tensor (PixelNormLayer :207-216) */
 int dge_pixelnorm_nhwc(const void* x, void* y, long npix, int C, float eps, int dtype, dge_stream_t stream);
+
+/* ---- BigGAN-deep (model/biggan_generator.py) ----------------------------------------------- */
+/* BigGANBatchNorm :127-150 as a per-(b,c) affine: a = (1 + scale[b,c]) / sqrt(var[c]+eps), b = offset[b,c] - mean[c]*a
+ * (scale/offset row stride 0 = batch-shared, for the non-conditional final BN pass weight-1 and bias) */
+int dge_cbn_affine(const float* scale, const float* offset, int ld, const float* mean, const float* var, float eps, float* a,
+                   float* b, int B, int C, dge_stream_t stream);
+/* y[b,oy,ox,c] = x[b,oy>>up,ox>>up,c], c < Cout <= Cin   (skip path of GenBlock :197-201: drop channels + nearest x2) */
+int dge_slice_up(const void* x, void* y, int B, int H, int W, int Cin, int Cout, int up, int dtype, dge_stream_t stream);
+/* O[b,n,:] = sum_m softmax_m(Q[b,n,:].K[b,m,:]) V[b,m,:]   (SelfAttn :75-97; Q [B,N,D], K [B,M,D], V [B,M,DV], O [B,N,DV]) */
+int dge_attention(const void* q, const void* k, const void* v, void* o, int B, int N, int M, int D, int DV, int dtype,
+                  dge_stream_t stream);
+/* img[b,c,p] = tanh(x[b,p,c]) for c < 3   (Generator.forward :251-255; x NHWC with >= 3 channels) */
+int dge_rgb_tanh(const void* x, float* img, int B, int HW, int C, int dtype, dge_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -417,3 +417,65 @@ def encpg_forward(P, img, noises, L):
         x = F.avg_pool2d(F.leaky_relu(x + res, 0.2), 2, 2)
     z = x.reshape(x.shape[0], -1) @ P["new_final.weight"].t() + P["new_final.bias"] if "new_final.weight" in P else None
     return x, z
+
+
+# ----------------------------------------------------------------------------- BigGAN-deep
+def bg_sn_weight(P, name):
+    """torch.nn.utils.spectral_norm in eval mode: weight_orig / (u . W v)."""
+    w = P[name + ".weight_orig"]
+    wm = w.reshape(w.shape[0], -1)
+    return w / torch.dot(P[name + ".weight_u"], torch.mv(wm, P[name + ".weight_v"]))
+
+
+def bg_bn(P, name, x, trunc, cond, eps, n_stats=51):
+    """BigGANBatchNorm.forward model/biggan_generator.py:127-150."""
+    coef, idx = math.modf(trunc / (1.0 / (n_stats - 1)))
+    idx = int(idx)
+    rm, rv = P[name + ".running_means"], P[name + ".running_vars"]
+    mean = rm[idx] * coef + rm[idx + 1] * (1 - coef) if coef != 0.0 else rm[idx]
+    var = rv[idx] * coef + rv[idx + 1] * (1 - coef) if coef != 0.0 else rv[idx]
+    xn = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps)
+    if name + ".scale.weight_orig" in P:
+        w = 1 + cond @ bg_sn_weight(P, name + ".scale").t()
+        b = cond @ bg_sn_weight(P, name + ".offset").t()
+        return xn * w[:, :, None, None] + b[:, :, None, None]
+    return xn * P[name + ".weight"].view(1, -1, 1, 1) + P[name + ".bias"].view(1, -1, 1, 1)
+
+
+def bg_generator(P, cfg, z, onehot, trunc):
+    """BigGAN.forward :296-304 + Generator.forward :232-256 + GenBlock :175-203 + SelfAttn :75-97 (eval mode)."""
+    eps = cfg["eps"]
+    cond = torch.cat((z, onehot @ P["embeddings.weight"].t()), dim=1)
+    ch = cfg["channel_width"]
+    x = cond @ bg_sn_weight(P, "generator.gen_z").t() + P["generator.gen_z.bias"]
+    x = x.view(-1, 4, 4, 16 * ch).permute(0, 3, 1, 2).contiguous()
+    li = 0
+    for i, (up, cin, cout) in enumerate(cfg["layers"]):
+        if i == cfg["attention_layer_position"]:
+            pre = f"generator.layers.{li}."
+            B, C, H, W = x.shape
+            theta = F.conv2d(x, bg_sn_weight(P, pre + "snconv1x1_theta")).view(B, C // 8, H * W)
+            phi = F.max_pool2d(F.conv2d(x, bg_sn_weight(P, pre + "snconv1x1_phi")), 2).view(B, C // 8, H * W // 4)
+            attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
+            g = F.max_pool2d(F.conv2d(x, bg_sn_weight(P, pre + "snconv1x1_g")), 2).view(B, C // 2, H * W // 4)
+            ag = torch.bmm(g, attn.permute(0, 2, 1)).view(B, C // 2, H, W)
+            x = x + P[pre + "gamma"] * F.conv2d(ag, bg_sn_weight(P, pre + "snconv1x1_o_conv"))
+            li += 1
+        pre = f"generator.layers.{li}."
+        x0 = x
+        t = F.conv2d(F.relu(bg_bn(P, pre + "bn_0", x, trunc, cond, eps)), bg_sn_weight(P, pre + "conv_0"), P[pre + "conv_0.bias"])
+        t = F.relu(bg_bn(P, pre + "bn_1", t, trunc, cond, eps))
+        if up:
+            t = F.interpolate(t, scale_factor=2, mode="nearest")
+        t = F.conv2d(t, bg_sn_weight(P, pre + "conv_1"), P[pre + "conv_1.bias"], padding=1)
+        t = F.conv2d(F.relu(bg_bn(P, pre + "bn_2", t, trunc, cond, eps)), bg_sn_weight(P, pre + "conv_2"), P[pre + "conv_2.bias"], padding=1)
+        t = F.conv2d(F.relu(bg_bn(P, pre + "bn_3", t, trunc, cond, eps)), bg_sn_weight(P, pre + "conv_3"), P[pre + "conv_3.bias"])
+        if cin != cout:
+            x0 = x0[:, :x0.shape[1] // 2]
+        if up:
+            x0 = F.interpolate(x0, scale_factor=2, mode="nearest")
+        x = t + x0
+        li += 1
+    x = F.relu(bg_bn(P, "generator.bn", x, trunc, None, eps))
+    x = F.conv2d(x, bg_sn_weight(P, "generator.conv_to_rgb"), P["generator.conv_to_rgb.bias"], padding=1)
+    return torch.tanh(x[:, :3]), cond

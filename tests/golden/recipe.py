@@ -87,3 +87,37 @@ def fill_encoder(shapes: dict, seed: int) -> dict:
 
 def checksum(sd: dict) -> float:
     return float(sum(v.double().abs().sum().item() for v in sd.values()))
+
+
+def fill_biggan(shapes: dict, seed: int) -> dict:
+    """BigGAN-deep state (reference model/biggan_generator.py).  Spectral-norm u/v vectors are
+    brought close to the leading singular pair by 5 deterministic power iterations so that
+    sigma = u.Wv is O(1) (random u,v would give sigma ~ 0 and overflowing weights)."""
+    out = {}
+    for k, shp in shapes.items():
+        if k.endswith("running_vars"):
+            out[k] = randn(k, shp, seed, 0.2, 1.0).abs() + 0.3
+        elif k.endswith("running_means"):
+            out[k] = randn(k, shp, seed, 0.3)
+        elif k.endswith("weight_u") or k.endswith("weight_v"):
+            v = randn(k, shp, seed)
+            out[k] = v / v.norm()
+        elif k.endswith("gamma"):
+            out[k] = torch.tensor([0.7])
+        elif k.endswith(".bias"):
+            out[k] = randn(k, shp, seed, 0.1)
+        elif k.endswith("bn.weight"):
+            out[k] = randn(k, shp, seed, 0.2, 1.0)
+        else:
+            fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else 1
+            out[k] = randn(k, shp, seed, 1.0 / np.sqrt(max(fan_in, 1)))
+    for k in list(out):
+        if k.endswith("weight_orig"):
+            base = k[: -len("weight_orig")]
+            w = out[k].reshape(out[k].shape[0], -1)
+            u, v = out[base + "weight_u"], out[base + "weight_v"]
+            for _ in range(5):
+                v = torch.mv(w.t(), u); v = v / v.norm()
+                u = torch.mv(w, v); u = u / u.norm()
+            out[base + "weight_u"], out[base + "weight_v"] = u, v
+    return out

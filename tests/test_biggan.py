@@ -1,0 +1,73 @@
+"""BigGAN-deep generator: oracle vs reference golden (CPU), HIP path vs golden (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import golden, ROOT
+from tests.golden import recipe as R
+from oracle import ref_torch as O
+
+SMALL = dict(output_dim=64, z_dim=128, class_embed_dim=128, channel_width=32, num_classes=1000,
+             layers=[[True, 16, 8], [False, 8, 8], [True, 8, 4], [True, 4, 2], [True, 2, 1]],
+             attention_layer_position=3, eps=1e-4, n_stats=51)
+DEEP256 = dict(output_dim=256, z_dim=128, class_embed_dim=128, channel_width=128, num_classes=1000,
+               layers=[[False, 16, 16], [True, 16, 16], [False, 16, 16], [True, 16, 8], [False, 8, 8], [True, 8, 8],
+                       [False, 8, 8], [True, 8, 4], [False, 4, 4], [True, 4, 2], [False, 2, 2], [True, 2, 1]],
+               attention_layer_position=8, eps=1e-4, n_stats=51)
+
+
+fill = R.fill_biggan
+
+
+def relerr(a, b):
+    a = a.detach().float().cpu(); b = torch.as_tensor(np.asarray(b)).float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def inputs():
+    z = R.randn("bg.z", (2, 128), 71, 0.4)
+    onehot = torch.zeros(2, 1000); onehot[:, 207] = 1.0
+    return z, onehot
+
+
+def test_state_dict_and_oracle():
+    from dge_amd.biggan_generator import BigGAN, BigGANConfig
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "biggan_keys.json")))["deep256"]
+    sd = BigGAN(BigGANConfig.from_dict(DEEP256)).state_dict()
+    assert len(k) == 602 and set(sd.keys()) == set(k.keys())
+    assert all(list(sd[n].shape) == k[n] for n in sd)
+    g = golden("biggan_small.npz")
+    G = BigGAN(BigGANConfig.from_dict(SMALL))
+    P = fill({n: list(v.shape) for n, v in G.state_dict().items()}, 71)
+    assert abs(R.checksum(P) - float(g["state_checksum"])) < 1e-6 * float(g["state_checksum"])
+    z, onehot = inputs()
+    for trunc, key in ((0.4, "image"), (0.5, "image_t05"), (0.37, "image_t037")):
+        img, cond = O.bg_generator(P, SMALL, z, onehot, trunc)
+        assert relerr(img, g[key]) < 2e-4, (key, relerr(img, g[key]))
+    assert relerr(cond, g["cond"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_hip_biggan_vs_reference_golden(cd):
+    from dge_amd.biggan_generator import BigGAN, BigGANConfig
+    g = golden("biggan_small.npz")
+    G = BigGAN(BigGANConfig.from_dict(SMALL), compute_dtype=cd).cuda()
+    G.load_state_dict(fill({n: list(v.shape) for n, v in G.state_dict().items()}, 71))
+    G.eval()
+    z, onehot = inputs()
+    tol = 5e-4 if cd == "f32" else 6e-2
+    for trunc, key in ((0.4, "image"), (0.5, "image_t05"), (0.37, "image_t037")):
+        img, cond = G(z.cuda(), onehot.cuda(), trunc)
+        assert relerr(img, g[key]) < tol, (key, relerr(img, g[key]))
+    assert relerr(cond, g["cond"]) < 1e-6
+    with pytest.raises(AssertionError):
+        G(z.cuda(), onehot.cuda(), 0.0)                    # biggan_generator.py:297
+    # train mode (the reference never calls .eval(): SURVEY Q2): the power iteration moves the u/v buffers
+    G.train()
+    img, _ = G(z.cuda(), onehot.cuda(), 0.4)
+    assert relerr(img, g["image_train"]) < tol
+    assert relerr(G.state_dict()["generator.gen_z.weight_u"], g["train_u_gen_z"]) < 1e-4

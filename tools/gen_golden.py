@@ -487,11 +487,49 @@ def gen_encvar():
              noise_shapes=np.array([list(s_) for s_ in nf.log]), state_checksum=np.array(R.checksum(sd)))
 
 
+# --------------------------------------------------------------------------- BigGAN-deep
+BIGGAN_SMALL_CFG = dict(output_dim=64, z_dim=128, class_embed_dim=128, channel_width=32, num_classes=1000,
+                        layers=[[True, 16, 8], [False, 8, 8], [True, 8, 4], [True, 4, 2], [True, 2, 1]],
+                        attention_layer_position=3, eps=1e-4, n_stats=51)
+BIGGAN_DEEP256_CFG = dict(output_dim=256, z_dim=128, class_embed_dim=128, channel_width=128, num_classes=1000,
+                          layers=[[False, 16, 16], [True, 16, 16], [False, 16, 16], [True, 16, 8], [False, 8, 8], [True, 8, 8],
+                                  [False, 8, 8], [True, 8, 4], [False, 4, 4], [True, 4, 2], [False, 2, 2], [True, 2, 1]],
+                          attention_layer_position=8, eps=1e-4, n_stats=51)
+
+
+def gen_biggan():
+    _stub("boto3"); _stub("botocore"); _stub("botocore.exceptions", ClientError=Exception)
+    _stub("requests"); 
+    from model.biggan_generator import BigGAN
+    from model.utils.biggan_config import BigGANConfig
+    keys = {"deep256": shapes_of(BigGAN(BigGANConfig.from_dict(BIGGAN_DEEP256_CFG)).state_dict())}
+    with open(os.path.join(OUT, "biggan_keys.json"), "w") as f:
+        json.dump(keys, f)
+    G = BigGAN(BigGANConfig.from_dict(BIGGAN_SMALL_CFG))
+    sd = R.fill_biggan(shapes_of(G.state_dict()), seed=71)
+    G.load_state_dict(sd)
+    G.eval()
+    z = R.randn("bg.z", (2, 128), 71, 0.4)
+    onehot = torch.zeros(2, 1000); onehot[:, 207] = 1.0
+    with torch.no_grad():
+        img, cond = G(z, onehot, 0.4)
+    out = {"image": img, "cond": cond, "state_checksum": np.array(R.checksum(sd))}
+    with torch.no_grad():
+        out["image_t05"], _ = G(z, onehot, 0.5)
+        out["image_t037"], _ = G(z, onehot, 0.37)      # interpolated statistics rows (coef != 0)
+    # train mode: one power iteration per forward mutates weight_u / weight_v (quirk Q2)
+    G.train()
+    with torch.no_grad():
+        out["image_train"], _ = G(z, onehot, 0.4)
+    out["train_u_gen_z"] = G.state_dict()["generator.gen_z.weight_u"].clone()
+    save_npz("biggan_small.npz", **out)
+
+
 SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step, "sg1": gen_sg1, "pggan": gen_pggan,
-            "encvar": gen_encvar}
+            "encvar": gen_encvar, "biggan": gen_biggan}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
-    for s in todo:
-        print("==", s)
-        SECTIONS[s]()
+    for s_ in todo:
+        print("==", s_)
+        SECTIONS[s_]()
