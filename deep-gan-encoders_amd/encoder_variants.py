@@ -208,3 +208,103 @@ class PGBE(nn.Module):
             return torch.tensor(0), torch.tensor(0)
         z = ops.linear(x.reshape(x.shape[0], -1).contiguous(), self.new_final.weight.detach(), self.new_final.bias.detach())
         return torch.tensor(0), z
+
+
+# ----------------------------------------------------------------------------------- E_BIG
+class _PlainConv(nn.Module):
+    """torch.nn.Conv2d(channels, outputs, 1) parameter holder (E_BIG's FromRGB is not an lreq layer, E_BIG.py:84-92)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(cout, cin, 1, 1) * (1.0 / cin) ** 0.5)
+        self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class _FromRGBPlain(nn.Module):
+    def __init__(self, channels, outputs):
+        super().__init__()
+        self.from_rgb = _PlainConv(channels, outputs)
+
+
+class BigBEBlock(nn.Module):
+    def __init__(self, inputs, outputs, latent_size, has_second_conv=True):
+        super().__init__()
+        from .biggan_generator import BigGANBatchNorm
+        self.has_second_conv, self.inputs, self.outputs = has_second_conv, inputs, outputs
+        self.noise_weight_1 = nn.Parameter(torch.zeros(1, inputs, 1, 1))
+        self.bias_1 = nn.Parameter(torch.zeros(1, inputs, 1, 1))
+        self.batch_norm_1 = BigGANBatchNorm(inputs, condition_vector_dim=256, n_stats=51, eps=1e-12, conditional=True)
+        self.conv_1 = ln.Conv2d(inputs, inputs, 3, 1, 1, bias=False)
+        self.noise_weight_2 = nn.Parameter(torch.zeros(1, outputs, 1, 1))
+        self.bias_2 = nn.Parameter(torch.zeros(1, outputs, 1, 1))
+        self.batch_norm_2 = BigGANBatchNorm(inputs, condition_vector_dim=256, n_stats=51, eps=1e-12, conditional=True)
+        if has_second_conv:
+            self.conv_2 = ln.Conv2d(inputs, outputs, 3, 1, 1, bias=False)
+        if inputs != outputs:
+            self.batch_norm_3 = BigGANBatchNorm(inputs, condition_vector_dim=256, n_stats=51, eps=1e-12, conditional=True)
+            self.conv_3 = ln.Conv2d(inputs, outputs, 1, 1, 0)
+
+
+class BigBE(nn.Module):
+    """E_BIG.BE (model/E/E_BIG.py:93-227): conditional-BN encoder for BigGAN; forward(x, cond_vector) -> (c_v [B,256], z [B,128])."""
+
+    def __init__(self, startf=16, maxf=512, layer_count=9, latent_size=512, channels=3, pggan=False, biggan=False, compute_dtype="bf16"):
+        super().__init__()
+        _dt(compute_dtype)
+        self.maxf, self.startf, self.latent_size, self.layer_count, self.compute_dtype = maxf, startf, latent_size, layer_count, compute_dtype
+        self.decode_block = nn.ModuleList()
+        self.FromRGB = _FromRGBPlain(channels, startf)
+        inputs, outputs = startf, startf * 2
+        for i in range(layer_count):
+            self.decode_block.append(BigBEBlock(inputs, outputs, latent_size, i + 1 != layer_count))
+            inputs, outputs = min(maxf, inputs * 2), min(maxf, outputs * 2)
+        self.biggan = biggan
+        if biggan:
+            self.new_final_1 = ln.Linear(8192, 256, gain=1)
+            self.new_final_2 = ln.Linear(256, 128, gain=1)
+
+    @torch.no_grad()
+    def trunk(self, img, cond_vector, noises=None, truncation=0.4):
+        dt = _dt(self.compute_dtype)
+        dev = img.device
+        B, _, R, _ = img.shape
+        training = self.training
+        cond = cond_vector.float().contiguous()
+        if noises is None:
+            noises = draw_noises(self, B, R, dev)
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        fr = self.FromRGB.from_rgb
+        x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, None)
+        ni = 0
+        for j, blk in enumerate(self.decode_block):
+            Cc, C2, H = blk.inputs, blk.outputs, R >> j
+            a1, b1 = blk.batch_norm_1.affine(truncation, cond, training)
+            x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=a1, in_shift=b1,
+                            noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_1.detach().reshape(-1),
+                            bias=blk.bias_1.detach().reshape(-1), act=ops.ACT_LRELU)
+            ni += 1
+            if not blk.has_second_conv:
+                x = x1
+                break
+            a2, b2 = blk.batch_norm_2.affine(truncation, cond, training)
+            x2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=a2, in_shift=b2,
+                            noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_2.detach().reshape(-1),
+                            bias=blk.bias_2.detach().reshape(-1), act=ops.ACT_LRELU)
+            ni += 1
+            if Cc != C2:
+                a3, b3 = blk.batch_norm_3.affine(truncation, cond, training)
+                res = ops.conv2d(x, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, in_scale=a3, in_shift=b3, bias=blk.conv_3.bias.detach())
+                x2 = ops.blur_noise_act(x2, None, None, None, blur=False)          # the second leaky_relu of E_BIG.py:163
+            else:
+                res = x
+            x = ops.blend(x2, z=ops.blend(res, pool=True), pool=True, alpha=1.0, beta=1.0)   # avg_pool2d(x + residual)
+        return ops.nhwc_to_nchw(x)
+
+    @torch.no_grad()
+    def forward(self, img, cond_vector, block_num=9, noises=None):
+        x = self.trunk(img, cond_vector, noises)
+        if not self.biggan:
+            raise RuntimeError("E_BIG.BE.forward needs biggan=True (the reference raises UnboundLocalError otherwise, E_BIG.py:223-227)")
+        c_v = ops.linear(x.reshape(x.shape[0], -1).contiguous(), self.new_final_1.weight.detach(), self.new_final_1.bias.detach())
+        z = ops.linear(c_v, self.new_final_2.weight.detach(), self.new_final_2.bias.detach())
+        return c_v, z

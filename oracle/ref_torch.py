@@ -479,3 +479,24 @@ def bg_generator(P, cfg, z, onehot, trunc):
     x = F.relu(bg_bn(P, "generator.bn", x, trunc, None, eps))
     x = F.conv2d(x, bg_sn_weight(P, "generator.conv_to_rgb"), P["generator.conv_to_rgb.bias"], padding=1)
     return torch.tanh(x[:, :3]), cond
+
+
+def encbig_forward(P, img, cond, noises, L, trunc=0.4):
+    """E_BIG.BE.forward (model/E/E_BIG.py:129-169,212-227), eval-mode spectral norm."""
+    x = F.leaky_relu(F.conv2d(img, P["FromRGB.from_rgb.weight"], P["FromRGB.from_rgb.bias"]), 0.2)
+    ni = 0
+    for j in range(L):
+        pre = f"decode_block.{j}."
+        res = x
+        x = F.conv2d(bg_bn(P, pre + "batch_norm_1", x, trunc, cond, 1e-12), P[pre + "conv_1.weight"], padding=1)
+        x = F.leaky_relu(x + P[pre + "noise_weight_1"] * noises[ni] + P[pre + "bias_1"], 0.2); ni += 1
+        if j == L - 1:
+            break
+        x = F.conv2d(bg_bn(P, pre + "batch_norm_2", x, trunc, cond, 1e-12), P[pre + "conv_2.weight"], padding=1)
+        x = F.leaky_relu(x + P[pre + "noise_weight_2"] * noises[ni] + P[pre + "bias_2"], 0.2); ni += 1
+        if pre + "conv_3.weight" in P:
+            res = F.conv2d(bg_bn(P, pre + "batch_norm_3", res, trunc, cond, 1e-12), P[pre + "conv_3.weight"], P[pre + "conv_3.bias"])
+            x = F.leaky_relu(x, 0.2)
+        x = F.avg_pool2d(x + res, 2, 2)
+    c_v = x.reshape(x.shape[0], -1) @ P["new_final_1.weight"].t() + P["new_final_1.bias"]
+    return x, c_v, c_v @ P["new_final_2.weight"].t() + P["new_final_2.bias"]

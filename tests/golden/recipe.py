@@ -121,3 +121,12 @@ def fill_biggan(shapes: dict, seed: int) -> dict:
                 u = torch.mv(w, v); u = u / u.norm()
             out[base + "weight_u"], out[base + "weight_v"] = u, v
     return out
+
+
+def fill_encbig(shapes: dict, seed: int) -> dict:
+    """E_BIG.BE state: lreq/plain convs like fill_encoder, conditional-BN parts like fill_biggan."""
+    bn = {k: v for k, v in shapes.items() if "batch_norm" in k}
+    rest = {k: v for k, v in shapes.items() if "batch_norm" not in k}
+    out = fill_encoder(rest, seed)
+    out.update(fill_biggan(bn, seed))
+    return {k: out[k] for k in shapes}

@@ -83,3 +83,34 @@ def test_hip_e_pg_vs_reference_golden(cd):
     assert relerr(E.trunk(img, noises), g["trunk"]) < tol
     zero, z = E(img, noises=noises)
     assert float(zero) == 0 and relerr(z, g["head"]) < tol
+
+
+# ---------------------------------------------------------------------------- E_BIG
+def test_e_big_state_dict_and_oracle():
+    from dge_amd.encoder_variants import BigBE
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "encbig_keys.json")))["E_BIG_256_64_7"]
+    sd = BigBE(startf=64, maxf=512, layer_count=7, biggan=True).state_dict()
+    assert len(k) == 189 and set(sd.keys()) == set(k.keys()) and all(list(sd[n].shape) == k[n] for n in sd)
+    g = golden("encbig_small.npz")
+    E = BigBE(startf=32, maxf=512, layer_count=5, biggan=True)
+    P = R.fill_encbig({n: list(v.shape) for n, v in E.state_dict().items()}, 81)
+    assert abs(R.checksum(P) - float(g["state_checksum"])) < 1e-6 * float(g["state_checksum"])
+    noises = [R.randn(f"ebg.noise{i}", tuple(s), 81) for i, s in enumerate(g["noise_shapes"].tolist())]
+    x, c_v, z = O.encbig_forward(P, R.randn("ebg.img", (2, 3, 64, 64), 81, 0.5), R.randn("ebg.cond", (2, 256), 81, 0.5), noises, 5)
+    assert relerr(x, g["trunk"]) < 2e-4 and relerr(c_v, g["c_v"]) < 2e-4 and relerr(z, g["z"]) < 2e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_hip_e_big_vs_reference_golden(cd):
+    from dge_amd.encoder_variants import BigBE
+    g = golden("encbig_small.npz")
+    E = BigBE(startf=32, maxf=512, layer_count=5, biggan=True, compute_dtype=cd).cuda()
+    E.load_state_dict(R.fill_encbig({n: list(v.shape) for n, v in E.state_dict().items()}, 81))
+    E.eval()
+    noises = [R.randn(f"ebg.noise{i}", tuple(s), 81).cuda() for i, s in enumerate(g["noise_shapes"].tolist())]
+    img, cond = R.randn("ebg.img", (2, 3, 64, 64), 81, 0.5).cuda(), R.randn("ebg.cond", (2, 256), 81, 0.5).cuda()
+    tol = 3e-4 if cd == "f32" else 5e-2
+    assert relerr(E.trunk(img, cond, noises), g["trunk"]) < tol
+    c_v, z = E(img, cond, noises=noises)
+    assert relerr(c_v, g["c_v"]) < tol and relerr(z, g["z"]) < tol

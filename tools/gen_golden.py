@@ -528,6 +528,29 @@ def gen_biggan():
 SECTIONS = {"s2": gen_s2, "enc": gen_enc, "loss": gen_loss, "adam": gen_adam, "step": gen_step, "sg1": gen_sg1, "pggan": gen_pggan,
             "encvar": gen_encvar, "biggan": gen_biggan}
 
+
+def gen_encbig():
+    import model.E.E_BIG as EBG
+    keys = {"E_BIG_256_64_7": shapes_of(EBG.BE(startf=64, maxf=512, layer_count=7, biggan=True).state_dict())}
+    with open(os.path.join(OUT, "encbig_keys.json"), "w") as f:
+        json.dump(keys, f)
+    E = EBG.BE(startf=32, maxf=512, layer_count=5, biggan=True)      # 64x64 input -> [B,512,4,4] -> 8192 features
+    sd = R.fill_encbig(shapes_of(E.state_dict()), seed=81)
+    E.load_state_dict(sd)
+    E.eval()
+    img = R.randn("ebg.img", (2, 3, 64, 64), 81, 0.5)
+    cond = R.randn("ebg.cond", (2, 256), 81, 0.5)
+    feats = {}
+    h = E.decode_block[4].register_forward_hook(lambda m_, i, o: feats.__setitem__("trunk", o[0].detach().clone()))
+    with torch.no_grad(), _NoiseFeeder("ebg", 81) as nf:
+        c_v, z = E(img, cond)
+    h.remove()
+    save_npz("encbig_small.npz", trunk=feats["trunk"], c_v=c_v, z=z, noise_shapes=np.array([list(s_) for s_ in nf.log]),
+             state_checksum=np.array(R.checksum(sd)))
+
+
+SECTIONS["encbig"] = gen_encbig
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
