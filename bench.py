@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=2, help="images per GPU (reference default, E_align_s2.py:308)")
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU: 8 = the batch of the reference ablation scripts (ablation_utils/Cat256/E_align_case_1.py:306); E_align_s2.py:308 defaults to 2")
     ap.add_argument("--img-size", type=int, default=1024)
     ap.add_argument("--start-features", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])

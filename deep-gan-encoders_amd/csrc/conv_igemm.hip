@@ -435,7 +435,8 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
     { const char* e = getenv("DGE_CONV_BN"); if (e) bn = atoi(e); }
     const int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
     const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
-    const bool small = (p.H <= 8 && p.W <= 8) || work < 256L * 256;
+    bool small = (p.H <= 8 && p.W <= 8) || work < 256L * 256;
+    { const char* e = getenv("DGE_CONV_SMALL"); if (e) small = atoi(e) != 0; }
 #define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
     if (small) {           // 8x8 pixel tiles, narrower N tiles: more workgroups for the low-resolution layers
         if (bn >= 64) { if (kc == K0) GO(8, 8, 64, K0, 2, 2); GO(8, 8, 64, K1, 2, 2); }
