@@ -22,6 +22,8 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(!d->in_s2d || d->Cin % 4 == 0, "conv2d: in_s2d needs Cin %% 4 == 0");
     DGE_CHECK(!d->dot_src || d->stats, "conv2d: dot_src needs a stats buffer");
     DGE_CHECK(!d->in_relu || d->in_scale || d->in_shift, "conv2d: in_relu is applied together with the prologue affine");
+    DGE_CHECK(d->gain > 0.f, "conv2d: gain must be positive (it is folded through the activation)");
+    DGE_CHECK((((uintptr_t)d->in_scale | (uintptr_t)d->in_shift) & 15) == 0, "conv2d: in_scale/in_shift must be 16-byte aligned");
     DGE_CHECK(!d->noise || d->noise_w, "conv2d: noise without noise_w");
     ConvParams p;
     p.x = d->x; p.w = d->w_packed; p.y = d->y; p.addend = d->addend; p.dot_src = d->dot_src;

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     float* ldsN = (float*)(lds + C::LDS_BYTES - C::N_BYTES);   // noise tile, lives until the epilogue
     const unsigned ldsB_off = lds_offset_of(ldsB);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps tile/DMA index math on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
     int bid = blockIdx.x;
     const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
@@ -155,37 +156,52 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
 
     Regs<C::NA_PER> areg;
     float asc[EP16], ash[EP16];                        // affine of the chunk held in areg
+    unsigned inmask = 0;                               // bit i: halo item i lies inside the image
+
+    // Source geometry of the fused read modes, folded into shifts so the per-item address math is
+    // branch-free: plain (sl=sh=0), in_up2 (nearest x2: source pixel = (y>>1, x>>1)), in_s2d
+    // (space-to-depth: logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid).
+    const int sl = p.in_s2d ? 1 : 0, sh = p.in_up2 ? 1 : 0;
+    const int Ws = (p.W << sl) >> sh;
+    const T* __restrict__ Xb = X + (size_t)b * ((p.H << sl) >> sh) * Ws * cphys;   // in-image offsets fit 32 bits
 
     // ---- input halo tile: global -> registers (zero outside the image)
     auto load_a = [&](int kc) {
         const int cbase = kc * KC;
         int ph = 0, cb = cbase;
         if (p.in_s2d) { ph = cbase / cphys; cb = cbase - ph * cphys; }
+        const int ay = ph >> 1, ax = ph & 1;
+        const int coff = cb + achunk * EP16;
         if (affine) {
             const int ci = b * p.Cin + cbase + achunk * EP16;
+            if (p.in_scale) {
 #pragma unroll
-            for (int e = 0; e < EP16; e++) {
-                asc[e] = p.in_scale ? p.in_scale[ci + e] : 1.f;
-                ash[e] = p.in_shift ? p.in_shift[ci + e] : 0.f;
+                for (int e4 = 0; e4 < EP16 / 4; e4++) *(float4*)&asc[e4 * 4] = *(const float4*)(p.in_scale + ci + e4 * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EP16; e++) asc[e] = 1.f;
+            }
+            if (p.in_shift) {
+#pragma unroll
+                for (int e4 = 0; e4 < EP16 / 4; e4++) *(float4*)&ash[e4 * 4] = *(const float4*)(p.in_shift + ci + e4 * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EP16; e++) ash[e] = 0.f;
             }
         }
+        inmask = 0;
         StaticFor<C::NA_PER>::run([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int idx = tid + i * 256;
+            const int pix = idx / C::CH;
+            const int hx = pix % C::HW, hy = pix / C::HW;
+            const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
+            const bool inside = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W) &
+                                (C::NA_ITEMS % 256 == 0 || idx < C::NA_ITEMS);
+            const int sy = ((gy << sl) >> sh) + ay, sx = ((gx << sl) >> sh) + ax;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (C::NA_ITEMS % 256 == 0 || idx < C::NA_ITEMS) {
-                const int pix = idx / C::CH;
-                const int hx = pix % C::HW, hy = pix / C::HW;
-                const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                    if (p.in_up2)     // upscale2d (nearest x2) fused into the read: pixel (y,x) <- source (y/2, x/2)
-                        v = *(const uint4*)(X + ((size_t)(b * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * p.Cin + cbase + achunk * EP16);
-                    else if (p.in_s2d)     // logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid
-                        v = *(const uint4*)(X + ((size_t)(b * 2 * p.H + 2 * gy + (ph >> 1)) * (2 * p.W) + 2 * gx + (ph & 1)) * cphys + cb + achunk * EP16);
-                    else
-                        v = *(const uint4*)(X + ((size_t)(b * p.H + gy) * p.W + gx) * p.Cin + cbase + achunk * EP16);
-                }
-            }
+            if (inside) v = *(const uint4*)(Xb + (sy * Ws + sx) * cphys + coff);
+            inmask |= (inside ? 1u : 0u) << i;
             areg.template get<i>() = v;
         });
     };
@@ -198,12 +214,15 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                 const int pix = idx / C::CH;
                 const int hx = pix % C::HW, hy = pix / C::HW;
                 uint4 v = areg.template get<i>();
-                const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
-                if (affine && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {     // padding stays zero
+                if (affine && ((inmask >> i) & 1u)) {     // padding stays zero
                     float f[EP16];
                     unpack16(v, f, (T*)nullptr);
 #pragma unroll
-                    for (int e = 0; e < EP16; e++) { f[e] = f[e] * asc[e] + ash[e]; if (p.in_relu) f[e] = fmaxf(f[e], 0.f); }
+                    for (int e = 0; e < EP16; e++) f[e] = f[e] * asc[e] + ash[e];
+                    if (p.in_relu) {
+#pragma unroll
+                        for (int e = 0; e < EP16; e++) f[e] = fmaxf(f[e], 0.f);
+                    }
                     v = pack16(f, (T*)nullptr);
                 }
                 *(uint4*)(ldsA + hy * C::RPITCH + hx * C::PSTR + achunk * 16) = v;
@@ -305,6 +324,14 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     // In DOT mode (data gradients) the per-channel scale is applied post, on the staged raw value.
     const bool post_stats = p.stats && (DOT || ADD);
     float* __restrict__ STATS = p.stats ? p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * p.Cout * 2 : nullptr;
+    // activation as max(v, slope*v) (slope in [0,1]); the gain (> 0, checked by the launcher) is folded
+    // into scale / noise weight / bias because every supported activation is positively homogeneous
+    const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
+    const bool tile_full = (y0 + TH <= p.H) && (x0 + TW <= p.W);
+    const int lh = lane >> 5, l31 = lane & 31;
+    T* __restrict__ Yb = Y + (size_t)b * OH * OW * p.Cout;           // in-image offsets fit 32 bits
+    const T* __restrict__ ADDb = ADD ? ADD + (size_t)b * OH * OW * p.Cout : nullptr;
+    const T* __restrict__ DOTb = DOT ? DOT + (size_t)b * OH * OW * p.Cout : nullptr;
     if (!(p.dbg & 4))
     StaticFor<C::NT>::run([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -313,11 +340,11 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
         const int phase = p.up ? n0 / p.Cout : 0;
         const int o0 = p.up ? n0 % p.Cout : n0;
         const int py = phase >> 1, px = phase & 1;
-        const int o = o0 + (lane & 31);
+        const int o = o0 + l31;
         const bool ovalid = o < p.Cout;
-        const float osc = (p.out_scale && ovalid && !DOT) ? p.out_scale[b * p.Cout + o] : 1.f;
-        const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale : 0.f;
-        const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] : 0.f;
+        const float osc = ((p.out_scale && ovalid && !DOT) ? p.out_scale[b * p.Cout + o] : 1.f) * p.gain;
+        const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale * p.gain : 0.f;
+        const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] * p.gain : 0.f;
         float ssum = 0.f, ssq = 0.f;
         // post-side per-lane channel vector (channels o0 + chq*EP16 .. +EP16)
         const int chq = lane % CPR;
@@ -328,23 +355,39 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
             posc[e] = (DOT && p.out_scale && cvalid) ? p.out_scale[b * p.Cout + o0 + chq * EP16 + e] : 1.f;
             ps0[e] = 0.f; ps1[e] = 0.f;
         }
+        float* estw = (float*)(est + 4 * lh * C::ESTR) + l31;                     // + ((r&3) + 8(r>>2)) rows
+        const float* nzb = ldsN + phase * C::BM + wm * C::WTM + 4 * lh;          // + i*32 + 8(r>>2) + (r&3)
         StaticFor<C::MT>::run([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const f32x16_t a = acc[i][j];
-            StaticFor<16>::run([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int m = wm * C::WTM + i * 32 + ml;
-                float v = a[r] * osc;
-                if (p.noise) v += nw * ldsN[phase * C::BM + m];
-                v += bia;
-                v = act_apply(v, p.act) * p.gain;
-                if (p.stats && !post_stats) {
-                    const int gy = y0 + m / TW, gx = x0 + m % TW;
-                    if (gy < p.H && gx < p.W) { ssum += v; ssq += v * v; }
+            float nz[16], val[16];
+            if (p.noise) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) *(float4*)&nz[q * 4] = *(const float4*)(nzb + i * 32 + q * 8);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) nz[r] = 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float v = fmaf(a[r], osc, fmaf(nw, nz[r], bia));
+                val[r] = fmaxf(v, v * slope);
+            }
+            if (p.stats && !post_stats) {
+                if (tile_full) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) { ssum += val[r]; ssq += val[r] * val[r]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int m = wm * C::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const bool pv = (y0 + m / TW < p.H) & (x0 + m % TW < p.W);
+                        ssum += pv ? val[r] : 0.f; ssq += pv ? val[r] * val[r] : 0.f;
+                    }
                 }
-                *((float*)(est + ml * C::ESTR) + (lane & 31)) = v;
-            });
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) estw[((r & 3) + 8 * (r >> 2)) * (C::ESTR / 4)] = val[r];
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < 32 / PPP; q++) {
@@ -352,22 +395,22 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                 const int m = wm * C::WTM + i * 32 + ml;
                 const int gy = y0 + m / TW, gx = x0 + m % TW;
                 const int oy = p.up ? 2 * gy + py : gy, ox = p.up ? 2 * gx + px : gx;
-                if (gy < p.H && gx < p.W && cvalid) {
+                if ((gy < p.H) & (gx < p.W) & cvalid) {
                     float f[EP16];
 #pragma unroll
                     for (int e4 = 0; e4 < EP16 / 4; e4++)
                         *(uint4*)&f[e4 * 4] = *(const uint4*)(est + ml * C::ESTR + chq * EP16 * 4 + e4 * 16);
-                    const size_t off = ((size_t)(b * OH + oy) * OW + ox) * p.Cout + o0 + chq * EP16;
+                    const int off = (oy * OW + ox) * p.Cout + o0 + chq * EP16;
                     if (DOT || ADD) {
                         if (DOT) {
                             float d[EP16];
-                            unpack16(*(const uint4*)(DOT + off), d, (T*)nullptr);
+                            unpack16(*(const uint4*)(DOTb + off), d, (T*)nullptr);
 #pragma unroll
                             for (int e = 0; e < EP16; e++) { ps0[e] += f[e] * d[e]; ps1[e] += f[e]; f[e] *= posc[e]; }
                         }
                         if (ADD) {
                             float ad[EP16];
-                            unpack16(*(const uint4*)(ADD + off), ad, (T*)nullptr);
+                            unpack16(*(const uint4*)(ADDb + off), ad, (T*)nullptr);
 #pragma unroll
                             for (int e = 0; e < EP16; e++) f[e] += p.add_scale * ad[e];
                         }
@@ -376,7 +419,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                             for (int e = 0; e < EP16; e++) { ps0[e] += f[e]; ps1[e] += f[e] * f[e]; }
                         }
                     }
-                    *(uint4*)(Y + off) = pack16(f, (T*)nullptr);
+                    *(uint4*)(Yb + off) = pack16(f, (T*)nullptr);
                 }
             }
             __builtin_amdgcn_wave_barrier();
