@@ -102,7 +102,8 @@ struct ConvCfg {
     static_assert(B_BYTES % 1024 == 0 && BN % 16 == 0 && (BN / RP) % CH == 0, "weight stage must be whole 1 KiB pieces");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
     // workgroups per CU the LDS footprint allows (1..3) = waves per SIMD to ask the register allocator for
-    static constexpr int MINW = LDS_BYTES <= 53 * 1024 ? 3 : (LDS_BYTES <= 80 * 1024 ? 2 : 1);
+    // (a 128-wide N tile holds 128 accumulator registers per lane: never ask for more than 2 waves/SIMD there)
+    static constexpr int MINW = (LDS_BYTES <= 53 * 1024 && MT * NT < 8) ? 3 : (LDS_BYTES <= 80 * 1024 ? 2 : 1);
 };
 
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
@@ -263,45 +264,64 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the untracked weight DMAs
     __syncthreads();
 
-    for (int s = 0; s < ((p.dbg & 8) ? 0 : nstages); s++) {
-        const int kc = s / KS, row = s - kc * KS;
-        const int sbuf = s % C::NBUF;
-        const int sn = s + C::NBUF - 1;                        // stage whose weights are requested now
-        if (sn < nstages && !(p.dbg & 1)) dma_b(sn / KS, sn % KS, sn % C::NBUF);   // ring slot last read in stage s-1
-        if (row == 0 && kc + 1 < nchunks && !(p.dbg & 1)) load_a(kc + 1);          // consumed after the last row of this chunk
-        const unsigned char* aa = ldsA + row * C::RPITCH;
-        const unsigned char* bb = ldsB + sbuf * C::B_BYTES;
-        if (!(p.dbg & 2))
+    // One K chunk = KS stages (kernel rows), unrolled so that `row` is a compile-time constant; the
+    // last chunk is a separate instantiation (LAST) so that the halo prefetch of the next chunk is
+    // unconditional in the steady-state loop (a conditional prefetch turns the staging registers
+    // into loop-carried copies and costs 2x their count in VGPRs).
+    auto chunk = [&](int kc, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        StaticFor<KS>::run([&](auto rowc) {
+            constexpr int row = decltype(rowc)::value;
+            const int s = kc * KS + row;
+            const int sbuf = s % C::NBUF;
+            const int sn = s + C::NBUF - 1;                        // stage whose weights are requested now
+            if (sn < nstages && !(p.dbg & 1)) dma_b(sn / KS, sn % KS, sn % C::NBUF);   // ring slot last read in stage s-1
+            if (row == 0 && !LAST) load_a(kc + 1);                 // consumed after the last row of this chunk
+            const unsigned char* aa = ldsA + row * C::RPITCH;
+            const unsigned char* bb = ldsB + sbuf * C::B_BYTES;
+            if (!(p.dbg & 2)) {
+                // Software-pipelined fragment loads: the LDS reads of step q+1 are issued before the
+                // MFMAs of step q, so their latency hides behind MT*NT matrix instructions instead of
+                // being exposed in front of every pair of them (a step = one 32-byte K slice of one tap).
+                constexpr int KSL = C::KCB / 32, NSTEP = KS * KSL;
+                uint4 af[2][C::MT], bf[2][C::NT];
+                auto frag = [&](int q, uint4 (&a)[C::MT], uint4 (&bq)[C::NT]) {
+                    const int t = q / KSL, ks = q % KSL;
 #pragma unroll
-        for (int t = 0; t < KS; t++) {
+                    for (int i = 0; i < C::MT; i++) a[i] = *(const uint4*)(aa + aoff[i] + t * C::PSTR + ks * 32);
 #pragma unroll
-            for (int ks = 0; ks < C::KCB / 32; ks++) {
-                uint4 af[C::MT], bf[C::NT];
+                    for (int j = 0; j < C::NT; j++)
+                        bq[j] = *(const uint4*)(bb + t * BN * C::KCB + bbase[j] + (((ks * 2 + (lane >> 5)) ^ bsw[j]) << 4));
+                };
+                frag(0, af[0], bf[0]);
+                StaticFor<NSTEP>::run([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if (q + 1 < NSTEP) frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
 #pragma unroll
-                for (int i = 0; i < C::MT; i++) af[i] = *(const uint4*)(aa + aoff[i] + t * C::PSTR + ks * 32);
+                    for (int i = 0; i < C::MT; i++)
 #pragma unroll
-                for (int j = 0; j < C::NT; j++)
-                    bf[j] = *(const uint4*)(bb + t * BN * C::KCB + bbase[j] + (((ks * 2 + (lane >> 5)) ^ bsw[j]) << 4));
-#pragma unroll
-                for (int i = 0; i < C::MT; i++)
-#pragma unroll
-                    for (int j = 0; j < C::NT; j++) Mma<T>::run(af[i], bf[j], acc[i][j]);
+                        for (int j = 0; j < C::NT; j++) Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                });
             }
-        }
-        // Stage s+1's weights must have landed; DMA groups requested after it may stay in flight.
-        // vmcnt retires in order, so allowing (groups still wanted in flight) x DPW outstanding ops is
-        // exact for the DMAs and conservative w.r.t. the ordinary halo loads interleaved with them.
-        {
-            int fly = nstages - 2 - s; fly = fly < 0 ? 0 : (fly > C::NBUF - 2 ? C::NBUF - 2 : fly);
-            if (C::DPW == 0 || fly == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(C::DPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * C::DPW) : "memory");
-        }
-        __syncthreads();                                       // ... for every wave: stage closed
-        if (row == KS - 1 && kc + 1 < nchunks && !(p.dbg & 16)) {               // chunk boundary: replace the halo tile
-            store_a();
-            __syncthreads();
-        }
+            // Stage s+1's weights must have landed; DMA groups requested after it may stay in flight.
+            // vmcnt retires in order, so allowing (groups still wanted in flight) x DPW outstanding ops is
+            // exact for the DMAs and conservative w.r.t. the ordinary halo loads interleaved with them.
+            {
+                int fly = nstages - 2 - s; fly = fly < 0 ? 0 : (fly > C::NBUF - 2 ? C::NBUF - 2 : fly);
+                if (C::DPW == 0 || fly == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(C::DPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * C::DPW) : "memory");
+            }
+            __syncthreads();                                       // ... for every wave: stage closed
+            if (row == KS - 1 && !LAST) {                          // chunk boundary: replace the halo tile
+                store_a();
+                __syncthreads();
+            }
+        });
+    };
+    if (!(p.dbg & 8)) {
+        for (int kc = 0; kc + 1 < nchunks; kc++) chunk(kc, std::false_type{});
+        chunk(nchunks - 1, std::true_type{});
     }
     // LDS is re-used as the epilogue transpose buffer from here (all reads done: barrier above)
 
