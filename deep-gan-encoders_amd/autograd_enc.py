@@ -36,7 +36,7 @@ def encoder_forward(E, img, noises=None, save=False):
     if noises is None:
         noises = draw_noises(E, B, R, dev)
     cache = E.__dict__.setdefault("_pack_cache", {})
-    zeros = lambda c: torch.zeros((B, c, 2), dtype=torch.float32, device=dev)
+    zeros = lambda c: ops.zeros((B, c, 2), dev)
     fr = E.FromRGB.from_rgb
     stats = zeros(E.startf)
     x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats)

@@ -56,18 +56,18 @@ def encoder_backward(E, saved, g_w):
         if not last:
             if g_out is None:
                 raise RuntimeError("non-final encoder block without an output gradient")
-            red2 = torch.zeros((C2, 2), dtype=torch.float32, device=dev)
+            red2 = ops.zeros((C2, 2), dev)
             g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2)
             grads[pre + "bias_2"] = red2[:, 0].reshape(1, C2, 1, 1)
             grads[pre + "noise_weight_2"] = red2[:, 1].reshape(1, C2, 1, 1)
-            gW2 = torch.zeros_like(blk.conv_2.weight)
+            gW2 = ops.zeros(tuple(blk.conv_2.weight.shape), dev)
             ops.conv_wgrad(g_pre2, x1, gW2, rec["sc2"], rec["sh2"])
             grads[pre + "conv_2.weight"] = gW2
-            dots2 = torch.zeros((B, Cc, 2), dtype=torch.float32, device=dev)
+            dots2 = ops.zeros((B, Cc, 2), dev)
             g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots2, dot_src=x1)
             if has3:
                 grads[pre + "conv_3.bias"] = ops.chan_sum(g_out, 0.889)
-                gW3 = torch.zeros_like(blk.conv_3.weight)
+                gW3 = ops.zeros(tuple(blk.conv_3.weight.shape), dev)
                 ops.conv_wgrad(g_out, rec["xp"], gW3)
                 grads[pre + "conv_3.weight"] = ops.scale_(gW3, 0.889)
                 extra = ops.conv2d(g_out, _packed(cache, blk.conv_3, dt, ops.PACK_DGRAD), Cc, 1, gain=0.889)
@@ -79,14 +79,14 @@ def encoder_backward(E, saved, g_w):
                 raise RuntimeError("the final encoder block's activation output carries no gradient in E_align")
             g_y2, dots2 = None, None
         coef2 = ops.in_bwd_coef(dots2, gms2, rec["musig2"], rec["sc2"], rec["sh2"], N)
-        red1 = torch.zeros((Cc, 2), dtype=torch.float32, device=dev)
+        red1 = ops.zeros((Cc, 2), dev)
         g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1)
         grads[pre + "bias_1"] = red1[:, 0].reshape(1, Cc, 1, 1)
         grads[pre + "noise_weight_1"] = red1[:, 1].reshape(1, Cc, 1, 1)
-        gW1 = torch.zeros_like(blk.conv_1.weight)
+        gW1 = ops.zeros(tuple(blk.conv_1.weight.shape), dev)
         ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
         grads[pre + "conv_1.weight"] = gW1
-        dots1 = torch.zeros((B, Cc, 2), dtype=torch.float32, device=dev)
+        dots1 = ops.zeros((B, Cc, 2), dev)
         g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD), Cc, 3, stats=dots1, dot_src=x)
         coef1 = ops.in_bwd_coef(dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
         g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)

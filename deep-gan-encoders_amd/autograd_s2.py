@@ -64,7 +64,7 @@ def synthesis_backward(mod, wp, saved, g_image):
     B = wp.shape[0]
     dev = wp.device
     nl = mod.num_layers
-    g_wp = torch.zeros((B, nl, mod.w_space_dim), dtype=torch.float32, device=dev)
+    g_wp = ops.zeros((B, nl, mod.w_space_dim), dev)
     layers = saved["layers"]
     dt = ops.dtype_of(saved["const"])
     g_img = g_image.float().contiguous()
@@ -79,7 +79,7 @@ def synthesis_backward(mod, wp, saved, g_image):
         L = getattr(mod, f"layer{i}")
         rec = layers[i]
         # ---- backward through noise/bias/act/demod of layer i
-        R = torch.zeros((B, L.out_c, 3), dtype=torch.float32, device=dev)
+        R = ops.zeros((B, L.out_c, 3), dev)
         g_y = ops.modconv_bwd_prep(g_x, rec["y"], rec["d"], rec["noise"], L.gain, R)
         x_in = saved["const"] if i == 0 else layers[i - 1]["y"]
         # toRGB gradient of the previous (even) layer joins through the epilogue addend
@@ -92,7 +92,7 @@ def synthesis_backward(mod, wp, saved, g_image):
             ops.linear_t(g_srgb, Op.style.weight.detach(), g_wp[:, i], scale=Op.style.wscale, accumulate=True)
             if kp > 0:
                 g_img = ops.up2_bwd(g_img)
-        st = torch.zeros((B, L.in_c, 2), dtype=torch.float32, device=dev)
+        st = ops.zeros((B, L.in_c, 2), dev)
         g_xprev = ops.conv2d(g_y, _dgrad_weight(L, dt), L.in_c, 3, in_s2d=L.up, out_scale=rec["s"], addend=addend,
                              add_scale=1.0, stats=st, dot_src=x_in)
         # ---- style / demodulation gradients -> g_wp[:, i]

@@ -496,7 +496,8 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
         if (blocks128 < 512) bn = 64;
     }
     { const char* e = getenv("DGE_CONV_BN"); if (e) bn = atoi(e); }
-    const int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
+    int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
+    { const char* e = getenv("DGE_CONV_KC"); if (e) kc = atoi(e); }
     const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
     bool small = (p.H <= 8 && p.W <= 8) || work < 256L * 256;
     { const char* e = getenv("DGE_CONV_SMALL"); if (e) small = atoi(e) != 0; }

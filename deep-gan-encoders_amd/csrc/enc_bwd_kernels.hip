@@ -14,6 +14,38 @@
 // registers from one aligned window (v_alignbit for dx=1, register renaming for dx=2), so one
 // window read feeds 3 MFMAs.  Each wave owns two tile rows and ALL taps (9 accumulator tiles), the
 // g fragment of a row is reused by its 9 taps; waves never exchange data and flush with f32 atomics.
+// Flush of the per-wave 32x32 accumulator tiles of all taps: the 4 waves' partial sums are combined in
+// LDS and staged as [o][i][tap] -- the layout of dW -- so that consecutive lanes add to consecutive
+// addresses (one f32 atomic per output element per workgroup, 64 contiguous floats per wave instruction;
+// lane-strided atomics on the 36-byte tap pitch were 10x slower than the whole MFMA phase).
+// `smem` must hold (4*1024 + 1024*NTAP) floats.
+template <int NTAP>
+__device__ __forceinline__ void wgrad_flush(const f32x16_t (&acc)[NTAP], float* smem, float* __restrict__ dW, int o0, int i0,
+                                            int Co, int Ci, int tid, int lane, int wave) {
+    float* red = smem;
+    float* stage = smem + 4096;
+#pragma unroll
+    for (int t = 0; t < NTAP; t++) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) red[wave * 1024 + r * 64 + lane] = acc[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int e = tid + q * 256;                  // e = r*64 + lane'
+            const int r = e >> 6, ln = e & 63;
+            const int ol = (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), il = ln & 31;
+            stage[(ol * 32 + il) * NTAP + t] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+        }
+    }
+    __syncthreads();
+    const int ni = (Ci - i0 < 32 ? Ci - i0 : 32) * NTAP;  // valid floats of one o row of this tile (contiguous in dW)
+    for (int idx = tid; idx < 1024 * NTAP; idx += 256) {
+        const int ol = idx / (32 * NTAP), j = idx - ol * (32 * NTAP);
+        if (o0 + ol < Co && j < ni) atomicAdd(dW + ((size_t)(o0 + ol) * Ci + i0) * NTAP + j, stage[idx]);
+    }
+}
+
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g, const T* __restrict__ X,
                                                           const float* __restrict__ sc, const float* __restrict__ sh,
@@ -27,7 +59,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
     constexpr int XROW = 24 * 2 / ES >= 24 ? 24 : 24;     // x^T: elements per halo row (>= HW + 2, 16-B multiple)
     constexpr int XPIT = HH * XROW + 16 / ES;            // x^T: elements per channel
     constexpr int LG_BYTES = 32 * GPIT * ES, LX_BYTES = 32 * XPIT * ES;
-    constexpr int SM_BYTES = (LG_BYTES + LX_BYTES) > 16384 ? (LG_BYTES + LX_BYTES) : 16384;
+    constexpr int FL_BYTES = (4096 + 1024 * NTAP) * 4;      // flush staging (wgrad_flush)
+    constexpr int SM_BYTES = (LG_BYTES + LX_BYTES) > FL_BYTES ? (LG_BYTES + LX_BYTES) : FL_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[SM_BYTES];
     T* lg = (T*)smem;
     T* lx = (T*)(smem + LG_BYTES);
@@ -156,24 +189,139 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
             }
         }
     }
-    // ---- flush: combine the 4 waves' partial tiles in LDS, then ONE f32 atomic per output element per block
-    // (atomics to the small dW array are the scarce resource: keep their count ~ blocks * Co*Ci*taps)
-    float* red = (float*)smem;                            // 4 x 1024 floats, re-uses the tile storage
+    wgrad_flush<NTAP>(acc, (float*)smem, dW, o0, i0, Co, Ci, tid, lane, wave);
+}
+
+// bf16 variant built on the gfx950 transposing LDS read.  Both tiles sit in LDS in their natural NHWC
+// order (one 64-byte row of 32 channels per pixel, written with plain 16-byte stores) and
+// ds_read_b64_tr_b16 delivers the K(=pixel)-contiguous MFMA fragments: in each 16-lane group lane i
+// points at pixel (i>>2), channels 4*(i&3)..+3 of a [4 pixel][16 channel] block and receives channel
+// (i) of the 4 pixels.  Two reads (pixels +0..3, +4..7) make the 8-deep fragment of one lane half.
+// The x window of a kernel row is read once as 12 pixels; the dx = 1, 2 fragments are register
+// shifts of it (v_alignbit / renaming), so 3 + 2 LDS reads feed 3 MFMAs.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+template <int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ X,
+                                                             const float* __restrict__ sc, const float* __restrict__ sh,
+                                                             float* __restrict__ dW, int B, int H, int W, int Co, int Ci,
+                                                             int tiles_x, int tiles_y, int ntile_groups) {
+    constexpr int TH = 8, TW = 16, HALO = KS / 2, HH = TH + 2 * HALO, HW = TW + 2 * HALO;
+    constexpr int NTAP = KS * KS;
+    constexpr int LG_BYTES = TH * TW * 64, LX_BYTES = (HH * HW + 4) * 64;     // +4 pixels: the 12-pixel window of the last row over-reads
+    constexpr int FL_BYTES = (4096 + 1024 * NTAP) * 4;      // flush staging (wgrad_flush)
+    constexpr int SM_BYTES = (LG_BYTES + LX_BYTES) > FL_BYTES ? (LG_BYTES + LX_BYTES) : FL_BYTES;
+    __shared__ __attribute__((aligned(256))) unsigned char smem[SM_BYTES];
+    __shared__ float laff[64];                          // instance-norm affine of the current sample: sc[32] | sh[32]
+    unsigned char* lg = smem;
+    unsigned char* lx = smem + LG_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_it = (Ci + 31) / 32;
+    const int o0 = (blockIdx.x / n_it) * 32, i0 = (blockIdx.x % n_it) * 32;
+    f32x16_t acc[NTAP];
 #pragma unroll
-    for (int t = 0; t < NTAP; t++) {
+    for (int t = 0; t < NTAP; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+    const int ntiles = tiles_x * tiles_y * B;
+    constexpr int NG = TH * TW * 4 / 256, NX = (HH * HW * 4 + 255) / 256;
+    const int cch = tid & 3;                             // 16-byte channel chunk of every item of this thread
+    const bool gc_ok = o0 + cch * 8 < Co, xc_ok = i0 + cch * 8 < Ci;
+    uint4 greg[NG], xreg[NX];                            // next tile, in flight while the current one is in the MFMAs
+    unsigned xin = 0;                                    // bit k: x item k lies inside the image
+    auto load_tile = [&](int tile) {
+        const int tx_i = tile % tiles_x, ty_i = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx_i * TW, y0 = ty_i * TH;
+        const bf16_t* gb = g + (size_t)b * H * W * Co + o0 + cch * 8;
+        const bf16_t* xb = X + (size_t)b * H * W * Ci + i0 + cch * 8;
+#pragma unroll
+        for (int k = 0; k < NG; k++) {
+            const int pix = (tid >> 2) + k * 64, gy = y0 + pix / TW, gx = x0 + pix % TW;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((gy < H) & (gx < W) & gc_ok) v = *(const uint4*)(gb + (gy * W + gx) * Co);
+            greg[k] = v;
+        }
+        xin = 0;
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            const int pix = (tid >> 2) + k * 64, hy = pix / HW, hx = pix % HW;
+            const int gy = y0 + hy - HALO, gx = x0 + hx - HALO;
+            const bool in = (pix < HH * HW) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W) & xc_ok;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (in) v = *(const uint4*)(xb + (gy * W + gx) * Ci);
+            xin |= (in ? 1u : 0u) << k;
+            xreg[k] = v;
+        }
+    };
+    // per-lane fragment addressing of the transposing reads
+    const int grp = lane >> 4, li = lane & 15;
+    const int frag_off = ((grp >> 1) * 8 + (li >> 2)) * 64 + (grp & 1) * 32 + (li & 3) * 8;
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_ptr;
+    auto trd = [&](const unsigned char* base, int byte_off) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_ptr)(base + byte_off));
+    };
+    int b_aff = -1;
+    if ((int)blockIdx.y < ntiles) load_tile(blockIdx.y);
+    for (int tile = blockIdx.y; tile < ntiles; tile += ntile_groups) {
+        const int b = tile / (tiles_x * tiles_y);
+        __syncthreads();                                 // previous tile's fragments are consumed
+        if (sc && b != b_aff) {                          // (block-uniform) refresh the affine table
+            if (tid < 64) {
+                const int ch = i0 + (tid & 31);
+                laff[tid] = ch < Ci ? (tid < 32 ? sc[b * Ci + ch] : sh[b * Ci + ch]) : 0.f;
+            }
+            b_aff = b;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < NG; k++) *(uint4*)(lg + (tid + k * 256) * 16) = greg[k];
+#pragma unroll
+        for (int k = 0; k < NX; k++) {
+            if (NX * 256 == HH * HW * 4 || tid + k * 256 < HH * HW * 4) {
+                uint4 v = xreg[k];
+                if (sc && ((xin >> k) & 1u)) {           // padding stays zero
+                    float f[8];
+                    unpack16(v, f, (bf16_t*)nullptr);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) f[q] = f[q] * laff[cch * 8 + q] + laff[32 + cch * 8 + q];
+                    v = pack16(f, (bf16_t*)nullptr);
+                }
+                *(uint4*)(lx + (tid + k * 256) * 16) = v;
+            }
+        }
         __syncthreads();
+        if (tile + ntile_groups < ntiles) load_tile(tile + ntile_groups);   // flies under the MFMAs
+        // ---- MFMA: wave w owns tile rows {2w, 2w+1}
 #pragma unroll
-        for (int r = 0; r < 16; r++) red[wave * 1024 + r * 64 + lane] = acc[t][r];
-        __syncthreads();
+        for (int rr = 0; rr < 2; rr++) {
+            const int row = 2 * wave + rr;
+            const unsigned char* ga = lg + row * TW * 64 + frag_off;
+            const v4s_t a0 = trd(ga, 0), a1 = trd(ga, 4 * 64);
+            const uint2 a01 = *(const uint2*)&a0, a23 = *(const uint2*)&a1;
+            const uint4 av = make_uint4(a01.x, a01.y, a23.x, a23.y);
+            const bf16x8_t a = *(const bf16x8_t*)&av;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int e = tid + q * 256;                  // e = r*64 + lane'
-            const int r = e >> 6, ln = e & 63;
-            const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), i = i0 + (ln & 31);
-            const float v = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
-            if (o < Co && i < Ci) atomicAdd(dW + ((size_t)o * Ci + i) * NTAP + t, v);
+            for (int dy = 0; dy < KS; dy++) {
+                const unsigned char* xa = lx + (row + dy) * HW * 64 + frag_off;
+                const v4s_t q0 = trd(xa, 0), q1 = trd(xa, 4 * 64);
+                const uint2 w01 = *(const uint2*)&q0, w23 = *(const uint2*)&q1;
+                const uint4 v0 = make_uint4(w01.x, w01.y, w23.x, w23.y);
+                if constexpr (KS == 3) {
+                    const v4s_t q2 = trd(xa, 8 * 64);
+                    const uint32_t w4 = (*(const uint2*)&q2).x;
+                    const uint4 b1 = make_uint4(__builtin_amdgcn_alignbit(v0.y, v0.x, 16), __builtin_amdgcn_alignbit(v0.z, v0.y, 16),
+                                                __builtin_amdgcn_alignbit(v0.w, v0.z, 16), __builtin_amdgcn_alignbit(w4, v0.w, 16));
+                    const uint4 b2 = make_uint4(v0.y, v0.z, v0.w, w4);
+                    acc[dy * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8_t*)&v0, acc[dy * 3 + 0], 0, 0, 0);
+                    acc[dy * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8_t*)&b1, acc[dy * 3 + 1], 0, 0, 0);
+                    acc[dy * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8_t*)&b2, acc[dy * 3 + 2], 0, 0, 0);
+                } else {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, *(const bf16x8_t*)&v0, acc[0], 0, 0, 0);
+                }
+            }
         }
     }
+    wgrad_flush<NTAP>(acc, (float*)smem, dW, o0, i0, Co, Ci, tid, lane, wave);
 }
 
 // ------------------------------------------------------------------ activation backward (+pool adjoint)
@@ -368,7 +516,10 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     int groups = 512 / noi; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;   // few, long-running workgroups: one atomic flush each
     dim3 grid(noi, groups);
 #define WG(T, KS) hipLaunchKernelGGL((conv_wgrad_kernel<T, KS>), grid, dim3(256), 0, s, (const T*)g, (const T*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups)
-    if (dtype == DGE_BF16) { if (ksize == 3) WG(bf16_t, 3); else WG(bf16_t, 1); }
+    if (dtype == DGE_BF16) {
+        if (ksize == 3) hipLaunchKernelGGL((conv_wgrad_tr_kernel<3>), grid, dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups);
+        else hipLaunchKernelGGL((conv_wgrad_tr_kernel<1>), grid, dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups);
+    }
     else { if (ksize == 3) WG(float, 3); else WG(float, 1); }
 #undef WG
     DGE_LAUNCH_CHECK("conv_wgrad");

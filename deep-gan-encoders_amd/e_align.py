@@ -70,6 +70,8 @@ class EAlignStep:
     def step(self, iteration, z=None, noises=None):
         G, E = self.G, self.E
         B = self.batch_size
+        from . import ops
+        ops.zero_arena_begin(self.dev)       # one memset for all of this step's accumulation buffers
         set_seed(iteration % 30000)
         if z is None:
             # every rank draws the same global z and takes its slice
@@ -98,6 +100,7 @@ class EAlignStep:
         loss_mtv.backward()
         gs = self._sync_grads()
         self.opt.step(grad_scale=gs)
+        ops.zero_arena_end()
         self.last = dict(imgs1=imgs1, imgs2=imgs2, w1=w1, w2=w2, const2=const2, loss_tsa=loss_tsa.detach(),
                          info_img=info_img, loss_w=loss_w.detach(), info_w=info_w)
         return self.last

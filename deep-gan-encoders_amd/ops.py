@@ -13,6 +13,44 @@ PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP = 0, 1, 2, 3, 
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag) per conv launch
 
 
+class _ZeroArena:
+    """Pre-zeroed float32 scratch for the many small accumulation targets of one training step
+    (statistics slots, reduction outputs, weight-gradient buffers).  One memset per step replaces
+    a fill launch per buffer.  Tensors handed out are views: they stay valid until the arena is
+    re-armed by the next `zero_arena_begin()`."""
+
+    def __init__(self):
+        self.buf, self.off, self.high, self.active = None, 0, 0, False
+
+
+_ARENA = _ZeroArena()
+
+
+def zero_arena_begin(device, nbytes=512 << 20):
+    a = _ARENA
+    if a.buf is None or a.buf.device != torch.device(device) or a.buf.numel() * 4 < nbytes:
+        a.buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=device)
+    else:
+        a.buf[:a.high].zero_()
+    a.off, a.high, a.active = 0, 0, True
+
+
+def zero_arena_end():
+    _ARENA.active = False
+
+
+def zeros(shape, device):
+    """float32 zeros; served from the step arena when one is armed, else a plain allocation."""
+    a = _ARENA
+    n = int(math.prod(shape))
+    if a.active and a.buf.device == torch.device(device) and a.off + n <= a.buf.numel():
+        t = a.buf[a.off:a.off + n].view(shape)
+        a.off = (a.off + n + 63) & ~63
+        a.high = max(a.high, a.off)
+        return t
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def tdtype(dtype):
     return torch.bfloat16 if dtype == BF16 else torch.float32
 
@@ -123,7 +161,7 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         nblk = ((H + 15) // 16) * ((W + 15) // 16) * B
         nslot = max(1, min(64, nblk // 16))
         if nslot > 1:
-            partial = torch.zeros((nslot,) + tuple(stats.shape), dtype=torch.float32, device=x.device)
+            partial = zeros((nslot,) + tuple(stats.shape), x.device)
     d.bias, d.noise, d.noise_w, d.stats = _f32(bias), _f32(noise), _f32(noise_w), _f32(partial if partial is not None else stats)
     d.stats_slots = nslot
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
@@ -241,7 +279,7 @@ def linear_t(x, w, y, mul=None, scale=1.0, accumulate=False, incx=1, incy=1, ldx
 def torgb_bwd(gimg, x, wrgb, style, wscale):
     B, H, W, Cc = x.shape
     gx = torch.empty_like(x)
-    gs = torch.zeros((B, Cc), dtype=torch.float32, device=x.device)
+    gs = zeros((B, Cc), x.device)
     check(lib().dge_torgb_bwd(_f32(gimg), _p(x), _f32(wrgb), _f32(style), _p(gx), _p(gs), B, H * W, Cc, float(wscale),
                               dtype_of(x), _stream()), "dge_torgb_bwd")
     return gx, gs
@@ -290,14 +328,14 @@ def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=Non
 
 def chan_sum(x, scale=1.0):
     B, H, W, Cc = x.shape
-    out = torch.zeros((Cc,), dtype=torch.float32, device=x.device)
+    out = zeros((Cc,), x.device)
     check(lib().dge_chan_sum(_p(x), _p(out), B, H * W, Cc, float(scale), dtype_of(x), _stream()), "dge_chan_sum")
     return out
 
 
 def fromrgb_bwd(gx, x0, img):
     B, H, W, Cc = x0.shape
-    out = torch.zeros((Cc, 4), dtype=torch.float32, device=x0.device)
+    out = zeros((Cc, 4), x0.device)
     check(lib().dge_fromrgb_bwd(_p(gx), _p(x0), _f32(img.contiguous()), _p(out), B, H * W, Cc, dtype_of(x0), _stream()),
           "dge_fromrgb_bwd")
     return out
