@@ -53,7 +53,7 @@ SIGNATURES = {
     "dge_torgb_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "dge_up2_bwd": [_P, _P, _I, _I, _I, _P],
     "dge_conv_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dge_act_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],
+    "dge_act_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_in_bwd_coef": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dge_in_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dge_chan_sum": [_P, _P, _I, _I, _I, _F, _I, _P],

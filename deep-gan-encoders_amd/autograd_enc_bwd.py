@@ -56,7 +56,7 @@ def encoder_backward(E, saved, g_w):
         if not last:
             if g_out is None:
                 raise RuntimeError("non-final encoder block without an output gradient")
-            red2 = ops.zeros((C2, 2), dev)
+            red2 = ops.zeros((C2, 3 if has3 else 2), dev)     # third column: sum of g_out = conv_3.bias gradient / 0.889
             g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2)
             grads[pre + "bias_2"] = red2[:, 0].reshape(1, C2, 1, 1)
             grads[pre + "noise_weight_2"] = red2[:, 1].reshape(1, C2, 1, 1)
@@ -66,7 +66,7 @@ def encoder_backward(E, saved, g_w):
             dots2 = ops.zeros((B, Cc, 2), dev)
             g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots2, dot_src=x1)
             if has3:
-                grads[pre + "conv_3.bias"] = ops.chan_sum(g_out, 0.889)
+                grads[pre + "conv_3.bias"] = red2[:, 2] * 0.889
                 gW3 = ops.zeros(tuple(blk.conv_3.weight.shape), dev)
                 ops.conv_wgrad(g_out, rec["xp"], gW3)
                 grads[pre + "conv_3.weight"] = ops.scale_(gW3, 0.889)

@@ -327,19 +327,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const bf16_t* __rest
 // ------------------------------------------------------------------ activation backward (+pool adjoint)
 // a = lrelu(pre) saved.  g_pre[b,p,c] = scale * g_up[b,q(p),c] * lrelu'(a)   (q = p/2 per axis when pool)
 // red[c,:] (pre-zeroed, summed over the whole batch) += { sum g_pre, sum g_pre*noise[b,p] }
-template <typename T>
+template <typename T, int NS>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gup, const T* __restrict__ a,
                                                        const float* __restrict__ noise, T* __restrict__ gpre,
                                                        float* __restrict__ red_out, int H, int W, int C, int pool, float scale, float slope) {
     constexpr int EP = Elem<T>::PER16;
-    __shared__ float red[256 * 2 * EP];
+    __shared__ float red[256 * NS * EP];
     const int b = blockIdx.y;
     const int cpt = C / EP, ppi = 256 / cpt;
     const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
     const int HW = H * W, UW = pool ? W / 2 : W, UHW = pool ? HW / 4 : HW;
-    float s[2][EP];
+    const float raw_w = pool ? 0.25f : 1.f;              // every gup element is visited by its 4 children
+    float s[NS][EP];
 #pragma unroll
-    for (int e = 0; e < EP; e++) s[0][e] = s[1][e] = 0.f;
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < EP; e++) s[k][e] = 0.f;
     for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
         const int p = p0 + slot;
         if (slot < ppi && p < HW) {
@@ -350,13 +353,14 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gup,
             const float nz = noise ? noise[(size_t)b * HW + p] : 0.f;
 #pragma unroll
             for (int e = 0; e < EP; e++) {
+                if constexpr (NS == 3) s[2][e] += raw_w * g[e];
                 g[e] = scale * g[e] * (av[e] > 0.f ? 1.f : slope);
                 s[0][e] += g[e]; s[1][e] += g[e] * nz;
             }
             *(uint4*)(gpre + ((size_t)b * HW + p) * C + chunk * EP) = pack16(g, (T*)nullptr);
         }
     }
-    if (red_out) block_chan_flush<EP, 2>(s, cpt, ppi, red_out, C, red);
+    if (red_out) block_chan_flush<EP, NS>(s, cpt, ppi, red_out, C, red);
 }
 
 // ------------------------------------------------------------------ instance-norm + statistics backward
@@ -526,13 +530,16 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     return 0;
 }
 
-extern "C" int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int B, int H, int W, int C,
-                           int pool, float scale, float slope, int dtype, hipStream_t s) {
+extern "C" int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int red_cols, int B, int H,
+                           int W, int C, int pool, float scale, float slope, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "act_bwd: unsupported channel count %d", C);
+    DGE_CHECK(red_cols == 2 || red_cols == 3, "act_bwd: red_cols must be 2 or 3 (got %d)", red_cols);
     dim3 grid(sgrid(H * W, 256 / (C / ep)), B);
-    if (dtype == DGE_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gup, (const bf16_t*)a, noise, (bf16_t*)gpre, red, H, W, C, pool, scale, slope);
-    else hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gup, (const float*)a, noise, (float*)gpre, red, H, W, C, pool, scale, slope);
+#define AB(T, NS) hipLaunchKernelGGL((act_bwd_kernel<T, NS>), grid, dim3(256), 0, s, (const T*)gup, (const T*)a, noise, (T*)gpre, red, H, W, C, pool, scale, slope)
+    if (dtype == DGE_BF16) { if (red_cols == 3) AB(bf16_t, 3); else AB(bf16_t, 2); }
+    else { if (red_cols == 3) AB(float, 3); else AB(float, 2); }
+#undef AB
     DGE_LAUNCH_CHECK("act_bwd");
     return 0;
 }

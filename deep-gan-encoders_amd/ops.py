@@ -305,8 +305,8 @@ def conv_wgrad(g, x, dw, in_scale=None, in_shift=None):
 def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2):
     B, H, W, Cc = a.shape
     gpre = torch.empty_like(a)
-    check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(red), B, H, W, Cc, 1 if pool else 0, float(scale),
-                            float(slope), dtype_of(a), _stream()), "dge_act_bwd")
+    check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(red), 2 if red is None else red.shape[-1], B, H, W, Cc,
+                            1 if pool else 0, float(scale), float(slope), dtype_of(a), _stream()), "dge_act_bwd")
     return gpre
 
 

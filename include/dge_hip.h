@@ -168,9 +168,11 @@ int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, dge_stream_t
 /* dw[o][i][tap] (f32, OIHW like the parameter, pre-zeroed) += sum_{b,p} g[b,p,o] * (x*in_scale+in_shift)[b,p+tap,i] */
 int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H, int W,
                    int cout, int cin, int ksize, int dtype, dge_stream_t stream);
-/* gpre = scale * gup[q(p)] * (a > 0 ? 1 : slope) (q = 2x2 pooling parent when pool); red[c,2] += {sum gpre, sum gpre*noise} */
-int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int B, int H, int W, int C, int pool,
-                float scale, float slope, int dtype, dge_stream_t stream);
+/* gpre = scale * gup[q(p)] * (a > 0 ? 1 : slope) (q = 2x2 pooling parent when pool);
+   red[c,red_cols] += {sum gpre, sum gpre*noise [, sum over the gup grid of gup]}   (red_cols = 2 or 3; the third column is the
+   bias gradient of a parallel 1x1 branch fed by the same gup, reference E.py conv_3) */
+int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int red_cols, int B, int H, int W, int C,
+                int pool, float scale, float slope, int dtype, dge_stream_t stream);
 /* coefficients (A,Bc,Cc)[B,C,3] of the instance-norm + (mean,std) backward; see DESIGN.md */
 int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh, float* coef,
                     int B, int C, int npix, dge_stream_t stream);
