@@ -52,7 +52,7 @@ template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KS,
                                    int Ntot, int mode, float scale) {
     const int ntap = KS * KS;
-    const int Kdim = (mode == 2) ? Cout : (mode == 3 ? 4 * Cout : Cin);
+    const int Kdim = (mode == 2) ? Cout : ((mode == 3 || mode == 5) ? 4 * Cout : Cin);
     const long total = (long)ntap * Ntot * Kdim;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int k = idx % Kdim;
@@ -67,6 +67,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             if (n < 4 * Cout) v = upfold_weight(w, n % Cout, k, Cin, n / Cout, tap);
         } else if (mode == 4) {
             if (n < 4 * Cout) v = sg1_up_weight(w, k, n % Cout, Cout, n / Cout, tap);
+        } else if (mode == 5) {
+            if (n < Cin) v = sg1_up_weight(w, n, k % Cout, Cout, k / Cout, 8 - tap);
         } else {
             if (n < Cin) v = upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap);
         }
@@ -222,11 +224,11 @@ extern "C" int dge_lerp_layers(const float* w, const float* avg, int avg_stride,
 
 extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
                                     float scale, hipStream_t s) {
-    DGE_CHECK(mode >= 0 && mode <= 4, "pack: bad mode %d", mode);
-    DGE_CHECK((mode != 1 && mode != 3 && mode != 4) || ksize == 3, "pack: up fold needs a 3x3 kernel");
+    DGE_CHECK(mode >= 0 && mode <= 5, "pack: bad mode %d", mode);
+    DGE_CHECK((mode != 1 && mode < 3) || ksize == 3, "pack: up fold needs a 3x3 kernel");
     const int nvalid = (mode == 1 || mode == 4) ? 4 * cout : (mode >= 2 ? cin : cout);
     const int ntot = dge_packed_n(nvalid);
-    const int kdim = mode == 2 ? cout : (mode == 3 ? 4 * cout : cin);
+    const int kdim = mode == 2 ? cout : ((mode == 3 || mode == 5) ? 4 * cout : cin);
     const long total = (long)ksize * ksize * ntot * kdim;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == DGE_BF16)

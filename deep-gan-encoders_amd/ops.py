@@ -9,7 +9,7 @@ from ._lib import lib, check, ConvDesc, DgeError
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
-PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP = 0, 1, 2, 3, 4
+PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP, PACK_SG1_UP_DGRAD = 0, 1, 2, 3, 4, 5
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag) per conv launch
 
 
@@ -90,10 +90,10 @@ def packed_n(n):
 def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
     """w: [Cout,Cin,k,k] f32 (reference layout) -> packed [k*k, Npad, K] tensor of `dtype`."""
     cout, cin, k, _ = w.shape
-    if mode == PACK_SG1_UP:          # ConvTranspose2d parameter layout [Cin, Cout, k, k]
+    if mode in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):          # ConvTranspose2d parameter layout [Cin, Cout, k, k]
         cin, cout = cout, cin
-    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD) else cout)
-    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode == PACK_UPFOLD_DGRAD else cin)
+    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cout)
+    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cin)
     out = torch.empty((k * k, packed_n(nvalid), kdim), dtype=tdtype(dtype), device=w.device)
     check(lib().dge_pack_conv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, k, mode, dtype, float(scale),
                                      _stream()), "dge_pack_conv_weight")
@@ -433,3 +433,30 @@ def rgb_tanh(x):
     img = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
     check(lib().dge_rgb_tanh(_p(x), _p(img), B, H * W, Cc, dtype_of(x), _stream()), "dge_rgb_tanh")
     return img
+
+
+def sg1_in_bwd_coef(dots, sc, sh, style, npix):
+    """-> (coef [B,C,3], gstyle [B,2C]) of the instance-norm + style_mod backward (dge_sg1_in_bwd_coef)."""
+    B, Cc = sc.shape
+    coef = torch.empty((B, Cc, 3), dtype=torch.float32, device=sc.device)
+    gstyle = torch.empty((B, 2 * Cc), dtype=torch.float32, device=sc.device)
+    check(lib().dge_sg1_in_bwd_coef(_f32(dots), _f32(sc), _f32(sh), _f32(style), _p(coef), _p(gstyle), B, Cc, int(npix), _stream()),
+          "dge_sg1_in_bwd_coef")
+    return coef, gstyle
+
+
+def dot_stats(g, x):
+    B, H, W, Cc = x.shape
+    st = zeros((B, Cc, 2), x.device)
+    check(lib().dge_dot_stats(_p(g), _p(x), _p(st), B, H * W, Cc, dtype_of(x), _stream()), "dge_dot_stats")
+    return st
+
+
+def nearest_up2_bwd(ghi, x=None):
+    """Adjoint of the nearest x2 upsample; with x also the dot statistics (sum g*x, sum g) [B,C,2]."""
+    B, H2, W2, Cc = ghi.shape
+    glow = torch.empty((B, H2 // 2, W2 // 2, Cc), dtype=ghi.dtype, device=ghi.device)
+    st = zeros((B, Cc, 2), ghi.device) if x is not None else None
+    check(lib().dge_nearest_up2_bwd(_p(ghi), _p(x), _p(glow), _f32(st), B, H2 // 2, W2 // 2, Cc, dtype_of(ghi), _stream()),
+          "dge_nearest_up2_bwd")
+    return glow, st

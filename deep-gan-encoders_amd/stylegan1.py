@@ -102,60 +102,14 @@ class Generator(nn.Module):
     def decode(self, styles, lod, noise=0, noises=None):
         """styles [B, 2*layer_count, latent]; `noises`: optional list of N(0,1) tensors in the
         reference's draw order (2 per block; the very first has batch 1 because the block input
-        is the batch-1 const, net.py:148)."""
-        dt = _dt(self.compute_dtype)
-        dev = styles.device
-        B = styles.shape[0]
-        styles = styles.float().contiguous()
-        zeros = lambda c: torch.zeros((B, c, 2), dtype=torch.float32, device=dev)
-        ni = 0
-
-        def noise_for(bn, res):
-            nonlocal ni
-            if noises is not None:
-                t = noises[ni].to(dev).float().reshape(-1, res, res).contiguous()
-            else:
-                t = torch.randn(bn, res, res, device=dev)
-            ni += 1
-            return t
-
-        x = ops.nchw_to_nhwc(self.const.detach(), B, dt)
-        a = b = None                       # pending instance-norm + style_mod affine of x
-        for i in range(lod + 1):
-            blk = self.decode_block[i]
-            Cc = blk.outputs
-            res = 4 << i
-            st = zeros(Cc)
-            if blk.has_first_conv:
-                if blk.fused_scale:
-                    t = ops.conv2d(x, blk._packed(blk.conv_1, dt, ops.PACK_SG1_UP), Cc, 3, up=True, in_scale=a, in_shift=b)
-                else:
-                    t = ops.conv2d(x, blk._packed(blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=a, in_shift=b, in_up2=True)
-                y = ops.blur_noise_act(t, noise_for(B, res), blk.noise_weight_1.detach().reshape(-1), blk.bias_1.detach().reshape(-1),
-                                       blur=True, stats=st)
-            else:
-                y = ops.blur_noise_act(x, noise_for(1, res), blk.noise_weight_1.detach().reshape(-1), blk.bias_1.detach().reshape(-1),
-                                       blur=False, stats=st)
-            _, sc, sh = ops.stats_finalize(st, res * res)
-            s1 = ops.linear(styles[:, 2 * i], blk.style_1.weight.detach(), blk.style_1.bias.detach())
-            a, b = ops.affine_compose(sc, sh, s1)
-            st2 = zeros(Cc)
-            x = ops.conv2d(y, blk._packed(blk.conv_2, dt, ops.PACK_FWD), Cc, 3, in_scale=a, in_shift=b,
-                           noise=noise_for(B, res), noise_w=blk.noise_weight_2.detach().reshape(-1),
-                           bias=blk.bias_2.detach().reshape(-1), act=ops.ACT_LRELU, stats=st2)
-            _, sc, sh = ops.stats_finalize(st2, res * res)
-            s2 = ops.linear(styles[:, 2 * i + 1], blk.style_2.weight.detach(), blk.style_2.bias.detach())
-            a, b = ops.affine_compose(sc, sh, s2)
-        xm = ops.blend(x, sc=a, sh=b)      # materialise the last style_mod for the 1x1 toRGB
-        rgb = self.to_rgb[lod].to_rgb
-        ones = torch.ones((B, x.shape[3]), dtype=torch.float32, device=dev)
-        return ops.torgb(xm, rgb.weight.detach().reshape(3, -1), ones, rgb.bias.detach(), None, 1.0)
+        is the batch-1 const, net.py:148).  Differentiable w.r.t. `styles` (autograd_sg1)."""
+        from .autograd_sg1 import DecodeFunction
+        return DecodeFunction.apply(self, styles, lod, noises)
 
     def forward(self, styles, lod, blend=1, remove_blob=False, noises=None):
         if remove_blob or blend != 1:
             raise NotImplementedError("only the decode() path (blend == 1, remove_blob=False) is on the E_align hot path")
-        with torch.no_grad():
-            return self.decode(styles, lod, 1, noises=noises)
+        return self.decode(styles, lod, 1, noises=noises)
 
 
 class MappingBlock(nn.Module):

@@ -37,6 +37,7 @@ typedef struct ihipStream_t* dge_stream_t;   /* == hipStream_t */
 #define DGE_PACK_DGRAD 2    /* [tap][Cin][Cout], taps flipped                     */
 #define DGE_PACK_UPFOLD_DGRAD 3 /* [tap][Cin][4*Cout]: adjoint of DGE_PACK_UPFOLD  */
 #define DGE_PACK_SG1_UP 4    /* w is [Cin][Cout][3][3] (ConvTranspose2d 3,s2,p1 + transform_kernel, lreq.py:129-131) -> [tap][4*Cout][Cin] */
+#define DGE_PACK_SG1_UP_DGRAD 5 /* same parameter layout -> [tap][Cin][4*Cout]: adjoint of DGE_PACK_SG1_UP */
 
 const char* dge_last_error(void);
 int dge_version(void);
@@ -211,6 +212,19 @@ int dge_affine_compose(const float* sc, const float* sh, const float* style, flo
 /* out[b,l,:] = avg[l*avg_stride + :] + (w[b,:] - avg[...]) * coefs[l]   (Mapping.forward lerp, :459-466) */
 int dge_lerp_layers(const float* w, const float* avg, int avg_stride, const float* coefs, float* out, int B, int L, int D,
                     dge_stream_t stream);
+
+/* StyleGAN1 synthesis data gradient (DecodeBlock.forward :141-169 differentiated w.r.t. the styles; the generator's own
+ * parameters get no gradients, E_align_s2.py trains the encoder only):
+ * coefficients (A,Bc,Cc)[B,C,3] of g_y = A*g_u + Bc*y + Cc for u = style_mod(InstanceNorm(y)) (:153-156, :32-34) from
+ * dots [B,C,2] = (sum g_u*y, sum g_u), and the style gradient gstyle [B,2C] = [g_s0 | g_s1]. */
+int dge_sg1_in_bwd_coef(const float* dots, const float* sc, const float* sh, const float* style, float* coef, float* gstyle,
+                        int B, int C, int npix, dge_stream_t stream);
+/* stats [B,C,2] (pre-zeroed) += (sum_p g*x, sum_p g) for NHWC g, x */
+int dge_dot_stats(const void* g, const void* x, float* stats, int B, int HW, int C, int dtype, dge_stream_t stream);
+/* adjoint of upscale2d (nearest x2, :37-43): glow [B,H,W,C] = 2x2 block sums of ghi [B,2H,2W,C]; optional dot statistics
+ * of glow against x [B,H,W,C] as in dge_dot_stats */
+int dge_nearest_up2_bwd(const void* ghi, const void* x, void* glow, float* stats, int B, int H, int W, int C, int dtype,
+                        dge_stream_t stream);
 
 /* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */
 /* pixel-wise feature normalisation over the channel axis of an NHWC tensor (PixelNormLayer :207-216) */

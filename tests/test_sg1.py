@@ -112,3 +112,57 @@ def test_hip_mapping_vs_reference_golden():
     coefs = torch.where(layer_idx < 6, 0.7 * torch.ones(1, 12, 1), torch.ones(1, 12, 1))
     w = M(R.randn("sg1m.z", (3, 512), 42), coefs_m=coefs)
     assert relerr(w, g["mapping_w"]) < 1e-5
+
+
+def l2rel(a, b):
+    a = a.detach().float().cpu(); b = torch.as_tensor(np.asarray(b)).float()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_oracle_style_gradient_vs_reference_golden():
+    """Pins the oracle's differentiated synthesis (autograd through the restatement) on the reference's own gradient."""
+    g = golden("sg1_small.npz")
+    gg = golden("sg1_grad.npz")
+    P = small_params()
+    for tag, lod, prefix, nn_ in (("", 5, "sg1", 12), ("_lod3", 3, "sg1b", 8)):
+        styles = R.randn("sg1.styles", (2, 12, 512), 6).requires_grad_(True)
+        noises = [R.randn(f"{prefix}.noise{i}", tuple(s), 6) for i, s in enumerate(g["noise_shapes"].tolist()[:nn_])]
+        img = O.sg1_generator(P, styles, lod, noises)
+        gimg = R.randn("sg1.gimg" + tag, tuple(img.shape), 7)
+        loss = (img * gimg).sum()
+        loss.backward()
+        assert abs(float(loss) - float(gg["loss" + tag])) < 2e-4 * abs(float(gg["loss" + tag])) + 1e-3
+        assert l2rel(styles.grad, gg["g_styles" + tag]) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_hip_style_gradient_vs_reference_golden(cd):
+    """d(image)/d(styles) of the HIP pipeline (hand-written backward, autograd_sg1) against the reference's autograd:
+    covers the fused transposed-conv block (128^2), the upscale2d+conv blocks and the constant-input block."""
+    import dge_amd.stylegan1 as S
+    g = golden("sg1_small.npz")
+    gg = golden("sg1_grad.npz")
+    G = S.Generator(startf=32, maxf=64, layer_count=6, latent_size=512, compute_dtype=cd).cuda()
+    G.load_state_dict(small_params())
+    for tag, lod, prefix, nn_ in (("", 5, "sg1", 12), ("_lod3", 3, "sg1b", 8)):
+        styles = R.randn("sg1.styles", (2, 12, 512), 6).cuda().requires_grad_(True)
+        noises = [R.randn(f"{prefix}.noise{i}", tuple(s), 6) for i, s in enumerate(g["noise_shapes"].tolist()[:nn_])]
+        img = G.forward(styles, lod, noises=noises)
+        gimg = R.randn("sg1.gimg" + tag, tuple(img.shape), 7).cuda()
+        (img.float() * gimg).sum().backward()
+        want = torch.as_tensor(gg["g_styles" + tag])
+        got = styles.grad.float().cpu()
+        err = l2rel(got, want)
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
+        if cd == "f32":
+            # 2e-3 at lod 5.  At lod 3 ONE of the 32768 pre-activations of block 2 is within f32 rounding of zero
+            # (|pre| < 1e-5) and carries a large gradient: its leaky-relu slope flips between the CPU and the GPU
+            # evaluation order and moves the gradient by 1.7 % (every stage matches autograd to 1e-6 when fed the
+            # same mask, see tools/probes/dbg_sg1.py) -- hence the looser bound there.
+            assert err < (2e-3 if lod == 5 else 3e-2) and cos > 0.9995, (tag, cos, err)
+        else:        # bf16 activations/gradients: judged on direction and norm
+            assert cos > 0.995 and err < 0.1, (tag, cos, err)
+        # layers above the decoded level receive no gradient
+        if 2 * (lod + 1) < got.shape[1]:
+            assert float(got[:, 2 * (lod + 1):].abs().max()) == 0.0

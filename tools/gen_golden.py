@@ -551,6 +551,32 @@ def gen_encbig():
 
 SECTIONS["encbig"] = gen_encbig
 
+def gen_sg1grad():
+    """Gradient of a seeded linear functional of the StyleGAN1 image w.r.t. the styles (the quantity the
+    E_align loop back-propagates through Gs, E_align_s2.py:158,204), same generator/inputs/noise as gen_sg1."""
+    import model.stylegan1.net as SG1
+    G = SG1.Generator(startf=32, maxf=64, layer_count=6, latent_size=512, channels=3)
+    sd = R.fill_encoder(shapes_of(G.state_dict()), seed=41)
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = G.state_dict()[k].clone()
+        if k == "const":
+            sd[k] = R.randn("sg1.const", tuple(sd[k].shape), 41)
+    G.load_state_dict(sd)
+    out = {}
+    for tag, lod, prefix in (("", 5, "sg1"), ("_lod3", 3, "sg1b")):
+        styles = R.randn("sg1.styles", (2, 12, 512), 6).requires_grad_(True)
+        with _NoiseFeeder(prefix, 6):
+            img = G.forward(styles, lod)
+        gimg = R.randn("sg1.gimg" + tag, tuple(img.shape), 7)
+        (img * gimg).sum().backward()
+        out["g_styles" + tag] = styles.grad
+        out["loss" + tag] = (img * gimg).sum().detach()
+    save_npz("sg1_grad.npz", **out)
+
+
+SECTIONS["sg1grad"] = gen_sg1grad
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
