@@ -26,10 +26,46 @@ def set_seed(seed):
         torch.cuda.manual_seed_all(seed)
 
 
+class _StyleGAN2Adapter:
+    """mtype 2: generator(z, trunc...) -> dict, generator.synthesis(wp) -> dict (E_align_s2.py:110-115,160)"""
+
+    def __init__(self, generator):
+        self.G = generator
+
+    def sample(self, z, noises=None):
+        r = self.G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+        return r["image"], r["wp"]
+
+    def synth(self, w, noises=None):
+        return self.G.synthesis(w)["image"]
+
+
+class _StyleGAN1Adapter:
+    """mtype 1: w1 = Gm(z, coefs_m=coefs); imgs = Gs.forward(w, lod) with lod = log2(img_size)-2 (E_align_s2.py:27-41,105-108,158)"""
+
+    def __init__(self, Gs, Gm):
+        self.G, self.Gm = Gs, Gm
+        n = 2 * Gs.layer_count
+        layer_idx = torch.arange(n)[None, :, None]
+        ones = torch.ones(layer_idx.shape, dtype=torch.float32)
+        self.coefs = torch.where(layer_idx < n // 2, 0.7 * ones, ones)      # truncation psi on the first half of the layers
+        self.lod = Gs.layer_count - 1
+
+    def sample(self, z, noises=None):
+        w1 = self.Gm(z, coefs_m=self.coefs)
+        return self.G.forward(w1, self.lod, noises=noises), w1
+
+    def synth(self, w, noises=None):
+        return self.G.forward(w, self.lod, noises=noises)
+
+
 class EAlignStep:
     def __init__(self, generator, E, lpips_model, lr=0.0015, beta_1=0.0, batch_size=2, z_dim=512,
-                 reference_noise=False, exact_ddp=True):
+                 reference_noise=False, exact_ddp=True, mapping=None):
+        """`generator`: StyleGAN2Generator (mtype 2), or the StyleGAN1 synthesis network Gs together with
+        `mapping` = Gm (mtype 1)."""
         self.G, self.E, self.lpips = generator, E, lpips_model
+        self.gen = _StyleGAN1Adapter(generator, mapping) if mapping is not None else _StyleGAN2Adapter(generator)
         self.opt = LREQAdam([{"params": E.parameters()}], lr=lr, betas=(beta_1, 0.99), weight_decay=0)
         self.batch_size, self.z_dim = batch_size, z_dim
         self.reference_noise = reference_noise      # True: CPU-generated noise in the reference's order (Q6)
@@ -67,7 +103,9 @@ class EAlignStep:
         return None if self.exact_ddp else torch.full((1,), 1.0 / self.world, device=self.dev)
 
     # ------------------------------------------------------------------ one iteration
-    def step(self, iteration, z=None, noises=None):
+    def step(self, iteration, z=None, noises=None, gen_noises=(None, None)):
+        """`noises`: optional encoder noise tensors; `gen_noises`: optional (first, second) generator noise lists for
+        generators that draw noise per call (StyleGAN1) -- both only for parity runs against captured reference noise."""
         G, E = self.G, self.E
         B = self.batch_size
         from . import ops
@@ -79,13 +117,12 @@ class EAlignStep:
             z = zg[self.rank * B:(self.rank + 1) * B]
         z = z.to(self.dev)
         with torch.no_grad():
-            result_all = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
-            imgs1, w1 = result_all["image"], result_all["wp"]
+            imgs1, w1 = self.gen.sample(z, gen_noises[0])
         if noises is None and self.reference_noise:
             from .autograd_enc import draw_noises
             noises = [n.to(self.dev) for n in draw_noises(E, B, imgs1.shape[2], "cpu")]
         const2, w2 = E(imgs1, noises=noises)
-        imgs2 = G.synthesis(w2)["image"]
+        imgs2 = self.gen.synth(w2, gen_noises[1])
 
         gctx = losses.GlobalBatch(self.world) if (self.dist_on and self.exact_ddp) else None
         loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, global_batch=gctx)
@@ -125,17 +162,48 @@ def build_models(img_size=1024, start_features=16, compute_dtype="bf16", device=
     return G, E, LP
 
 
+def build_models_sg1(img_size=256, start_features=64, compute_dtype="bf16", device="cuda", lpips=True, seed=0):
+    """Models of BASELINE config 2 (StyleGAN1, E_align_s2.py:27-46) with seeded random-init weights."""
+    from .stylegan1 import Generator, Mapping
+    from .encoder import BE
+    from .lpips import LPIPS
+    torch.manual_seed(seed)
+    L = int(math.log2(img_size) - 1)
+    Gs = Generator(startf=start_features, maxf=512, layer_count=L, latent_size=512, channels=3, compute_dtype=compute_dtype).to(device)
+    Gm = Mapping(num_layers=2 * L, mapping_layers=8, latent_size=512, dlatent_size=512, mapping_fmaps=512).to(device)
+    for p in list(Gs.parameters()) + list(Gm.parameters()):
+        p.requires_grad_(False)
+    with torch.no_grad():
+        for name, p in Gs.named_parameters():
+            if "noise_weight" in name:
+                p.fill_(0.05)
+    Gm.buffer1 = torch.randn(2 * L, 512) * 0.1
+    E = BE(startf=start_features, maxf=512, layer_count=L, compute_dtype=compute_dtype).to(device)
+    LP = LPIPS(compute_dtype=compute_dtype).to(device) if lpips else None
+    return Gs, Gm, E, LP
+
+
 def train(tensor_writer=None, args=None):
     """Reference E_align_s2.train() for --mtype 2 (flags: E_align_s2.py:304-318)."""
-    if args.mtype != 2:
-        raise NotImplementedError("only --mtype 2 (StyleGAN2) is wired into the training loop in this round")
-    G, E, LP = build_models(args.img_size, args.start_features, getattr(args, "compute_dtype", "bf16"))
-    if args.checkpoint_dir_GAN:
-        ckpt = torch.load(args.checkpoint_dir_GAN, map_location="cpu")
-        G.load_state_dict(ckpt["generator_smooth"] if "generator_smooth" in ckpt else ckpt["generator"])
+    cd = getattr(args, "compute_dtype", "bf16")
+    if args.mtype == 2:
+        G, E, LP = build_models(args.img_size, args.start_features, cd)
+        Gm = None
+        if args.checkpoint_dir_GAN:
+            ckpt = torch.load(args.checkpoint_dir_GAN, map_location="cpu")
+            G.load_state_dict(ckpt["generator_smooth"] if "generator_smooth" in ckpt else ckpt["generator"])
+    elif args.mtype == 1:
+        G, Gm, E, LP = build_models_sg1(args.img_size, args.start_features, cd)
+        if args.checkpoint_dir_GAN:                 # E_align_s2.py:30-35: a directory holding the three files
+            G.load_state_dict(torch.load(args.checkpoint_dir_GAN + "Gs_dict.pth", map_location="cpu"))
+            Gm.load_state_dict(torch.load(args.checkpoint_dir_GAN + "Gm_dict.pth", map_location="cpu"))
+            Gm.buffer1 = torch.load(args.checkpoint_dir_GAN + "./center_tensor.pt", map_location="cpu")
+    else:
+        raise NotImplementedError("--mtype 1 (StyleGAN1) and 2 (StyleGAN2) are wired into the training loop; "
+                                  "PGGAN/BigGAN generators are forward-only in this build")
     if args.checkpoint_dir_E is not None:
         E.load_state_dict(torch.load(args.checkpoint_dir_E, map_location="cpu"))
-    st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim)
+    st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm)
     for iteration in range(args.iterations):
         r = st.step(iteration)
         if iteration % 100 == 0:

@@ -577,6 +577,86 @@ def gen_sg1grad():
 
 SECTIONS["sg1grad"] = gen_sg1grad
 
+
+def gen_step_sg1():
+    """One full E_align_s2 iteration for --mtype 1 (StyleGAN1: Gm -> Gs.forward -> E -> Gs.forward, E_align_s2.py:27-46,
+    105-108,157-158) of the REFERENCE at reduced size (res 64, 5 blocks), two iterations, every noise tensor captured."""
+    import warnings
+    import model.stylegan1.net as SG1
+    import model.E.E as EE
+    import training_utils as TU
+    from model.utils.custom_adam import LREQAdam
+    from oracle import lpips_ref as LR
+
+    L = 5
+    Gs = SG1.Generator(startf=16, maxf=64, layer_count=L, latent_size=512, channels=3)
+    sd = R.fill_encoder(shapes_of(Gs.state_dict()), seed=43)
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = Gs.state_dict()[k].clone()
+        if k == "const":
+            sd[k] = R.randn("sg1step.const", tuple(sd[k].shape), 43)
+    Gs.load_state_dict(sd)
+    Gm = SG1.Mapping(num_layers=2 * L, mapping_layers=8, latent_size=512, dlatent_size=512, mapping_fmaps=512)
+    Gm.load_state_dict({k: R.randn("sg1step.m." + k, tuple(v.shape), 44, 0.05 if k.endswith("weight") else 0.01)
+                        for k, v in Gm.state_dict().items()})
+    Gm.buffer1 = R.randn("sg1step.buffer1", (2 * L, 512), 44, 0.5)
+    Gm.eval()
+    layer_idx = torch.arange(2 * L)[np.newaxis, :, np.newaxis]
+    ones = torch.ones(layer_idx.shape, dtype=torch.float32)
+    coefs = torch.where(layer_idx < L, 0.7 * ones, ones)
+    E = EE.BE(startf=16, maxf=64, layer_count=L)
+    E.load_state_dict(R.fill_encoder(shapes_of(E.state_dict()), seed=31))
+    LP = LR.seeded_params(0)
+    lp = lambda a, b: LR.lpips(LP, a, b)
+    opt = LREQAdam([{"params": E.parameters()}], lr=0.0015, betas=(0.0, 0.99), weight_decay=0)
+    out = {}
+    B = 2
+    lod = L - 1
+    for it in range(2):
+        z = R.randn(f"sg1step.z{it}", (B, 512), 1)
+        with _NoiseFeeder(f"sg1step.it{it}", 1) as nf:
+            with torch.no_grad():
+                w1 = Gm(z, coefs_m=coefs)
+                imgs1 = Gs.forward(w1, lod)
+            const2, w2 = E(imgs1)
+            imgs2 = Gs.forward(w2, lod)
+        if it == 0:
+            out["noise_shapes"] = np.array([list(s_) + [0] * (4 - len(s_)) for s_ in nf.log])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            l_i, i_i = TU.space_loss(imgs1, imgs2, lpips_model=lp)
+            m1 = imgs1[:, :, :, imgs1.shape[3] // 8:-imgs1.shape[3] // 8]
+            m2 = imgs2[:, :, :, imgs2.shape[3] // 8:-imgs2.shape[3] // 8]
+            l_m, i_m = TU.space_loss(m1, m2, lpips_model=lp)
+            o = imgs1.shape[2] // 8 + imgs1.shape[2] // 32
+            s1, s2 = imgs1[:, :, o:-o, o:-o], imgs2[:, :, o:-o, o:-o]
+            l_s, i_s = TU.space_loss(s1, s2, lpips_model=lp)
+            loss_tsa = l_i + l_m * 5 + l_s * 9
+            opt.zero_grad()
+            loss_tsa.backward(retain_graph=True)
+            opt.step()
+            l_w, i_w = TU.space_loss(w1, w2, image_space=False)
+            loss_mtv = l_w * 0.01
+            opt.zero_grad()
+            loss_mtv.backward()
+            opt.step()
+        flat = lambda inf: [inf[0][0], inf[0][1], inf[0][2], inf[1], inf[2], inf[3], inf[4]]
+        out[f"it{it}_imgs1"] = imgs1
+        out[f"it{it}_w1"] = w1
+        out[f"it{it}_w2"] = w2.detach()
+        out[f"it{it}_imgs2"] = imgs2.detach()
+        out[f"it{it}_losses"] = np.array([float(loss_tsa), float(l_i), float(l_m), float(l_s), float(l_w)])
+        out[f"it{it}_info"] = np.array([flat(i_i), flat(i_m), flat(i_s), flat(i_w)])
+        out[f"it{it}_param_checksum"] = np.array(R.checksum(E.state_dict()))
+        for k in ("decode_block.0.conv_1.weight", "decode_block.2.conv_2.weight", "decode_block.4.inver_mod2.weight",
+                  "decode_block.1.bias_1", "FromRGB.from_rgb.weight"):
+            out[f"it{it}_after_phase2:{k}"] = E.state_dict()[k].clone()
+    save_npz("step_sg1.npz", **out)
+
+
+SECTIONS["step_sg1"] = gen_step_sg1
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
