@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU: 8 = the batch of the reference ablation scripts (ablation_utils/Cat256/E_align_case_1.py:306); E_align_s2.py:308 defaults to 2")
+    ap.add_argument("--mtype", type=int, default=2, choices=[1, 2], help="2 = StyleGAN2 (headline, BASELINE config 3); 1 = StyleGAN1 "
+                    "(BASELINE config 2: run with --img-size 256 --start-features 64)")
     ap.add_argument("--img-size", type=int, default=1024)
     ap.add_argument("--start-features", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -78,11 +80,17 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     import dge_amd
     from dge_amd import ops
-    from dge_amd.e_align import EAlignStep, build_models
+    from dge_amd.e_align import EAlignStep, build_models, build_models_sg1
 
-    G, E, LP = build_models(a.img_size, a.start_features, a.dtype, dev, seed=0)
-    G.train()                       # the reference never calls .eval() on G
-    st = EAlignStep(G, E, LP, batch_size=a.batch)
+    if a.mtype == 2:
+        G, E, LP = build_models(a.img_size, a.start_features, a.dtype, dev, seed=0)
+        G.train()                       # the reference never calls .eval() on G
+        st = EAlignStep(G, E, LP, batch_size=a.batch)
+        gname = f"StyleGAN2-{a.img_size} G (train mode)"
+    else:
+        G, Gm, E, LP = build_models_sg1(a.img_size, a.start_features, a.dtype, dev, seed=0)
+        st = EAlignStep(G, E, LP, batch_size=a.batch, mapping=Gm)
+        gname = f"StyleGAN1-{a.img_size} Gs+Gm"
 
     def sync():
         if world > 1:
@@ -103,24 +111,31 @@ def main():
         dt = float(t)
     imgs = a.batch * world * a.steps
     out = {
-        "metric": "encoder-train images/sec (E_align_s2 step, StyleGAN2 FFHQ-1024)", "value": imgs / dt, "unit": "images/sec",
+        "metric": "encoder-train images/sec (E_align_s2 step, StyleGAN2 FFHQ-1024)" if (a.mtype == 2 and a.img_size == 1024)
+                  else f"encoder-train images/sec (E_align_s2 step, --mtype {a.mtype} at {a.img_size})",
+        "value": imgs / dt, "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"E_align_s2 two-phase step, StyleGAN2-{a.img_size} G (train mode) + E.BE(startf={a.start_features}, "
+        "config": {"workload": f"E_align_s2 two-phase step, {gname} + E.BE(startf={a.start_features}, "
                                f"L={E.layer_count}) + LPIPS-VGG16 (seeded stand-in weights), batch {a.batch}/GPU",
                    "global_batch": a.batch * world, "img_size": a.img_size, "parallelism": f"dp{world}"},
     }
 
     # ---- G-synthesis ms/img (second half of the BASELINE metric), eval-mode synthesis(wp)
     with torch.no_grad():
-        wp = torch.randn(a.batch, G.num_layers, 512, device=dev)
+        if a.mtype == 2:
+            wp = torch.randn(a.batch, G.num_layers, 512, device=dev)
+            synth = lambda: G.synthesis(wp)
+        else:
+            wp = torch.randn(a.batch, 2 * G.layer_count, 512, device=dev)
+            synth = lambda: G.forward(wp, G.layer_count - 1)
         for _ in range(2):
-            G.synthesis(wp)
+            synth()
         sync()
         t0 = time.time()
         n = 10
         for _ in range(n):
-            G.synthesis(wp)
+            synth()
         sync()
         out["synthesis_ms_per_img"] = (time.time() - t0) / n / a.batch * 1e3
 

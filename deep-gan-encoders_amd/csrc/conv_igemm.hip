@@ -357,22 +357,30 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
         constexpr int j = decltype(jc)::value;
         const int n0 = bn0 + wn * C::WTN + j * 32;          // first N of this 32-wide tile
         if (n0 >= p.Ntot_valid) return;                     // wave-uniform
-        const int phase = p.up ? n0 / p.Cout : 0;
-        const int o0 = p.up ? n0 % p.Cout : n0;
-        const int py = phase >> 1, px = phase & 1;
-        const int o = o0 + l31;
-        const bool ovalid = o < p.Cout;
+        // up mode: N = (phase, channel).  A 32-wide tile lies inside one phase when Cout % 32 == 0 (tile-uniform
+        // phase); with Cout == 16 (StyleGAN1 FFHQ-1024 top block) it spans two, so phase/channel are per lane.
+        const bool split = p.up && (p.Cout & 31);
+        int phase = p.up ? n0 / p.Cout : 0;                 // "pre" side: this lane's channel n0 + l31
+        int o = (p.up ? n0 % p.Cout : n0) + l31;
+        const int chq = lane % CPR;
+        int phase_c = phase;                                // "post" side: this lane's chunk n0 + chq*EP16 ..
+        int oc = (p.up ? n0 % p.Cout : n0) + chq * EP16;
+        bool ovalid = o < p.Cout, cvalid = oc < p.Cout;
+        if (split) {
+            const int n = n0 + l31, nc = n0 + chq * EP16;
+            phase = n / p.Cout; o = n - phase * p.Cout; ovalid = n < p.Ntot_valid;
+            phase_c = nc / p.Cout; oc = nc - phase_c * p.Cout; cvalid = nc < p.Ntot_valid;
+            if (!ovalid) phase = 0;
+        }
+        const int py = phase_c >> 1, px = phase_c & 1;
         const float osc = ((p.out_scale && ovalid && !DOT) ? p.out_scale[b * p.Cout + o] : 1.f) * p.gain;
         const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale * p.gain : 0.f;
         const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] * p.gain : 0.f;
         float ssum = 0.f, ssq = 0.f;
-        // post-side per-lane channel vector (channels o0 + chq*EP16 .. +EP16)
-        const int chq = lane % CPR;
-        const bool cvalid = o0 + chq * EP16 < p.Cout;
         float posc[EP16], ps0[EP16], ps1[EP16];
 #pragma unroll
         for (int e = 0; e < EP16; e++) {
-            posc[e] = (DOT && p.out_scale && cvalid) ? p.out_scale[b * p.Cout + o0 + chq * EP16 + e] : 1.f;
+            posc[e] = (DOT && p.out_scale && cvalid) ? p.out_scale[b * p.Cout + oc + e] : 1.f;
             ps0[e] = 0.f; ps1[e] = 0.f;
         }
         float* estw = (float*)(est + 4 * lh * C::ESTR) + l31;                     // + ((r&3) + 8(r>>2)) rows
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
 #pragma unroll
                     for (int e4 = 0; e4 < EP16 / 4; e4++)
                         *(uint4*)&f[e4 * 4] = *(const uint4*)(est + ml * C::ESTR + chq * EP16 * 4 + e4 * 16);
-                    const int off = (oy * OW + ox) * p.Cout + o0 + chq * EP16;
+                    const int off = (oy * OW + ox) * p.Cout + oc;
                     if (DOT || ADD) {
                         if (DOT) {
                             float d[EP16];
@@ -458,8 +466,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
 #pragma unroll
                 for (int msk = CPR; msk < 64; msk <<= 1) { ps0[e] += __shfl_xor(ps0[e], msk, 64); ps1[e] += __shfl_xor(ps1[e], msk, 64); }
                 if (lane < CPR && cvalid) {
-                    atomicAdd(STATS + ((size_t)b * p.Cout + o0 + chq * EP16 + e) * 2, ps0[e]);
-                    atomicAdd(STATS + ((size_t)b * p.Cout + o0 + chq * EP16 + e) * 2 + 1, ps1[e]);
+                    atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2, ps0[e]);
+                    atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2 + 1, ps1[e]);
                 }
             }
         }
@@ -518,7 +526,7 @@ int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s) {
     DGE_CHECK(p.Cin % (32 / esize) == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, 32 / esize);
     DGE_CHECK(p.Cout % (16 / esize) == 0, "conv: Cout=%d must be a multiple of %d", p.Cout, 16 / esize);
     DGE_CHECK(p.Ntot % dge_conv_ntile(p.Ntot) == 0, "conv: packed N=%d not padded to the N tile", p.Ntot);
-    DGE_CHECK(!p.up || p.Cout % 32 == 0, "conv: up mode needs Cout %% 32 == 0 (got %d)", p.Cout);
+    DGE_CHECK(!p.up || p.Cout % 16 == 0, "conv: up mode needs Cout %% 16 == 0 (got %d)", p.Cout);
     if (dtype == DGE_BF16) return ksize == 3 ? launch_t<bf16_t, 3>(p, s) : launch_t<bf16_t, 1>(p, s);
     return ksize == 3 ? launch_t<float, 3>(p, s) : launch_t<float, 1>(p, s);
 }

@@ -170,3 +170,30 @@ def test_hip_style_gradient_vs_reference_golden(cd):
         # layers above the decoded level receive no gradient
         if 2 * (lod + 1) < got.shape[1]:
             assert float(got[:, 2 * (lod + 1):].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout", [(32, 16), (64, 32)])
+def test_fused_up_conv_and_its_data_gradient(cin, cout):
+    """ConvTranspose2d(3, stride 2, pad 1) with transform_kernel (lreq.py:129-131,145-147) as the phase-folded implicit GEMM
+    (DGE_PACK_SG1_UP) and its adjoint (DGE_PACK_SG1_UP_DGRAD, space-to-depth read), against torch on the CPU.  Cout = 16 is
+    the top block of the FFHQ-1024 generator: a 32-wide N tile then spans two output phases."""
+    import torch.nn.functional as F
+    from dge_amd import ops
+    gen = torch.Generator().manual_seed(cin + cout)
+    B, H = 2, 12
+    x = torch.randn(B, cin, H, H, generator=gen, requires_grad=True)
+    w = torch.randn(cin, cout, 3, 3, generator=gen) * 0.1
+    wp = F.pad(w, (1, 1, 1, 1))
+    w4 = wp[:, :, 1:, 1:] + wp[:, :, :-1, 1:] + wp[:, :, 1:, :-1] + wp[:, :, :-1, :-1]
+    y = F.conv_transpose2d(x, w4, stride=2, padding=1)
+    gy = torch.randn(y.shape, generator=gen)
+    (y * gy).sum().backward()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    got = ops.conv2d(xd, ops.pack_conv_weight(w.cuda(), ops.PACK_SG1_UP, ops.F32), cout, 3, up=True)
+    assert l2rel(got.permute(0, 3, 1, 2), y.detach()) < 1e-5
+    gyd = gy.permute(0, 2, 3, 1).contiguous().cuda()
+    st = torch.zeros(B, cin, 2, device="cuda")
+    gx = ops.conv2d(gyd, ops.pack_conv_weight(w.cuda(), ops.PACK_SG1_UP_DGRAD, ops.F32), cin, 3, in_s2d=True, stats=st, dot_src=xd)
+    assert l2rel(gx.permute(0, 3, 1, 2), x.grad) < 1e-5
+    assert l2rel(st[..., 0], (x.grad * x.detach()).sum((2, 3))) < 1e-4 and l2rel(st[..., 1], x.grad.sum((2, 3))) < 1e-4
