@@ -145,17 +145,29 @@ def main():
         for i in range(2):
             st.step(1000 + i)
         torch.cuda.synchronize()
-        fl, ms = 0.0, 0.0
-        for (e0, e1, flops, tag) in ops.PROFILE:
+        fl, ms, ab = 0.0, 0.0, 0.0
+        for (e0, e1, flops, tag, abytes) in ops.PROFILE:
             fl += flops
+            ab += abytes
             ms += e0.elapsed_time(e1)
         nlaunch = len(ops.PROFILE)
         ops.PROFILE = None
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = 2500.0 if a.dtype == "bf16" else 157.3
+        # HBM bytes per launch from the PMC counters: collected offline by tools/pmc_traffic.sh (separate rocprofv3 --pmc
+        # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
+        traffic, tsrc = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        if os.path.exists(tpath) and a.mtype == 2 and a.img_size == 1024 and a.batch == 8 and a.dtype == "bf16":
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic, tsrc = tj["traffic_bytes_per_launch"], "profiles/r01_conv_traffic.json"
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                           "traffic": None, "kernel": "conv_igemm_kernel<*> (all implicit-GEMM conv launches of a step)",
+                           "traffic": traffic, "traffic_source": tsrc,
+                           "kernel": "conv_igemm_kernel<*> (all implicit-GEMM conv launches of a step)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
+                           "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,
+                           "algorithmic_bytes_per_launch": ab / max(nlaunch, 1),
                            "algorithmic_gflop_per_step": fl / 2 / 1e9}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

@@ -10,7 +10,7 @@ from ._lib import lib, check, ConvDesc, DgeError
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
 PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP, PACK_SG1_UP_DGRAD = 0, 1, 2, 3, 4, 5
-PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag) per conv launch
+PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag, algorithmic_bytes) per conv launch
 
 
 class _ZeroArena:
@@ -185,7 +185,9 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
             macs = 9.0 * (Cin // 4) * cout * H * W
         else:
             macs = float(ksize * ksize) * Cin * cout * H * W
-        PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, ksize, up, in_s2d)))
+        # algorithmic bytes: every operand tensor crosses HBM once (input, output, optional addend / dot_src, packed weights)
+        abytes = sum(t.numel() * t.element_size() for t in (x, out, addend, dot_src, w_packed) if t is not None)
+        PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, ksize, up, in_s2d), abytes))
     else:
         check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
     if partial is not None:

@@ -15,7 +15,7 @@ ops.PROFILE = []
 st.step(5)
 torch.cuda.synchronize()
 rows = collections.OrderedDict()
-for e0, e1, fl, tag in ops.PROFILE:
+for e0, e1, fl, tag, _ in ops.PROFILE:
     r = rows.setdefault(tag, [0, 0.0, 0.0]); r[0] += 1; r[1] += e0.elapsed_time(e1) * 1e3; r[2] += fl
 tot = sum(r[1] for r in rows.values())
 print(f"conv launches {len(ops.PROFILE)}, total {tot/1e3:.2f} ms")
