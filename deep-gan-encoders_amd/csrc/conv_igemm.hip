@@ -73,6 +73,7 @@ __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
 
+static constexpr int cmin(int a, int b) { return a < b ? a : b; }
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
 struct ConvCfg {
     static constexpr int BM = TH * TW;
@@ -90,9 +91,15 @@ struct ConvCfg {
     static constexpr int B_PIECES = B_BYTES / 1024;          // 1 KiB wave-level LDS-DMA pieces per stage
     static constexpr int ESTR = 32 * 4 + 16;                  // epilogue staging is always f32
     static constexpr int E_BYTES = 4 * 32 * ESTR;
-    static constexpr int N_BYTES = 4 * BM * 4;                 // noise values of the tile (x4 phases in up mode)
-    // weight-stage ring: 4 deep (DMA issued 3 stages ahead) when two workgroups still fit a CU, else 2 deep
-    static constexpr int NBUF = (A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2;
+    // noise values of the tile (x4 phases in up mode; up mode has N = 4*Cout >= 64, so 32-wide N tiles never see it and
+    // keep 3 KB: that puts the 16x16x32 configuration under the 3-workgroups-per-CU LDS line)
+    static constexpr int N_BYTES = (BN >= 64 ? 4 : 1) * BM * 4;
+    // weight-stage ring.  Large pixel tiles: 4 deep (DMA issued 3 stages ahead) when two workgroups still fit a CU, else
+    // 2 deep.  Small pixel tiles serve the low-resolution layers, whose grids do not fill the chip and whose stages are
+    // short (6-12 MFMAs per wave): there the serial K loop is bound by the L2 latency of the weight stream, so the ring
+    // takes the whole LDS (one workgroup per CU) and runs up to 5 stages ahead.
+    static constexpr int NBUF_SMALL = cmin(6, cmax(2, (150 * 1024 - A_BYTES - N_BYTES) / B_BYTES));
+    static constexpr int NBUF = (BM <= 128) ? NBUF_SMALL : ((A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2);
     static constexpr int DPW = B_PIECES / 4;                   // DMA instructions every wave issues per stage (floor)
     static constexpr int LDS_BYTES = cmax(A_BYTES + NBUF * B_BYTES, E_BYTES) + N_BYTES;
     static constexpr int NA_ITEMS = HH * HW * CH, NA_PER = (NA_ITEMS + 255) / 256;
@@ -308,9 +315,12 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
             // exact for the DMAs and conservative w.r.t. the ordinary halo loads interleaved with them.
             {
                 int fly = nstages - 2 - s; fly = fly < 0 ? 0 : (fly > C::NBUF - 2 ? C::NBUF - 2 : fly);
+                static_assert(C::NBUF <= 6 && 4 * C::DPW <= 63, "vmcnt immediate");
                 if (C::DPW == 0 || fly == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(C::DPW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * C::DPW) : "memory");
+                else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * C::DPW) : "memory");
+                else if (fly == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * C::DPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * C::DPW) : "memory");
             }
             __syncthreads();                                       // ... for every wave: stage closed
             if (row == KS - 1 && !LAST) {                          // chunk boundary: replace the halo tile
@@ -504,6 +514,7 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
         if (blocks128 < 512) bn = 64;
     }
     { const char* e = getenv("DGE_CONV_BN"); if (e) bn = atoi(e); }
+    if (p.up && bn < 64) bn = 64;       // the 32-wide configurations hold a single-phase noise tile
     int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
     { const char* e = getenv("DGE_CONV_KC"); if (e) kc = atoi(e); }
     const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
@@ -511,7 +522,14 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
     { const char* e = getenv("DGE_CONV_SMALL"); if (e) small = atoi(e) != 0; }
 #define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
     if (small) {           // 8x8 pixel tiles, narrower N tiles: more workgroups for the low-resolution layers
-        if (bn >= 64) { if (kc == K0) GO(8, 8, 64, K0, 2, 2); GO(8, 8, 64, K1, 2, 2); }
+        if (bn >= 64) {
+            // 256- / 128-byte K chunks when the channel count allows: fewer stages / barriers / halo restages in the serial K
+            // loop (measured 512->512 @8^2 B=8: 41 us with 64-byte chunks, 32 us with 128, 27 us with 256)
+            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (4 * K0) == 0 && !getenv("DGE_CONV_NOK4")) GO(8, 8, 64, 4 * K0, 2, 2);
+            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (2 * K0) == 0 && !getenv("DGE_CONV_NOK2")) GO(8, 8, 64, 2 * K0, 2, 2);
+            if (kc == K0) GO(8, 8, 64, K0, 2, 2);
+            GO(8, 8, 64, K1, 2, 2);
+        }
         if (kc == K0) GO(8, 16, 32, K0, 4, 1); GO(8, 16, 32, K1, 4, 1);
     }
     if (bn == 128) { if (kc == K0) GO(16, 16, 128, K0, 2, 2); GO(16, 16, 128, K1, 2, 2); }
