@@ -492,6 +492,68 @@ __global__ __launch_bounds__(256) void fromrgb_bwd_kernel(const T* __restrict__ 
     block_chan_flush<EP, 4>(s, cpt, ppi, out, C, red);
 }
 
+// FromRGB data gradient (needed when the encoder input itself carries a gradient: embedding_img.py:88 E(imgs2)):
+// gimg[b,k,p] = sum_c W[c][k] * g_x0[b,p,c] * lrelu'(x0[b,p,c]),  k = 0..2.  One wave per 64 pixels x channel chunks:
+// thread (slot, chunk) reduces its chunk, the chunks of a pixel are combined in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void fromrgb_dgrad_kernel(const T* __restrict__ gx, const T* __restrict__ x0, const float* __restrict__ w,
+                                                             float* __restrict__ gimg, int HW, int C) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * 3];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    float wr[3][EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) wr[k][e] = w[(size_t)(chunk * EP + e) * 3 + k];
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {      // block-uniform trip count
+        const int p = p0 + slot;
+        float a[3] = {0.f, 0.f, 0.f};
+        if (slot < ppi && p < HW) {
+            const size_t o = ((size_t)b * HW + p) * C + chunk * EP;
+            float g[EP], xv[EP];
+            unpack16(*(const uint4*)(gx + o), g, (T*)nullptr);
+            unpack16(*(const uint4*)(x0 + o), xv, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                const float gp = g[e] * (xv[e] > 0.f ? 1.f : 0.2f);
+                a[0] += gp * wr[0][e]; a[1] += gp * wr[1][e]; a[2] += gp * wr[2][e];
+            }
+        }
+        red[threadIdx.x * 3 + 0] = a[0]; red[threadIdx.x * 3 + 1] = a[1]; red[threadIdx.x * 3 + 2] = a[2];
+        __syncthreads();
+        if (chunk == 0 && slot < ppi && p < HW) {
+            float t[3] = {0.f, 0.f, 0.f};
+            for (int c = 0; c < cpt; c++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) t[k] += red[(slot * cpt + c) * 3 + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) gimg[((size_t)b * 3 + k) * HW + p] = t[k];
+        }
+        __syncthreads();
+    }
+}
+
+// upscale2d (nearest x2) materialised: y[b,2y+dy,2x+dx,c] = scale * x[b,y,x,c]
+template <typename T>
+__global__ __launch_bounds__(256) void nearest_up2_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, float scale, long total16) {
+    constexpr int EP = Elem<T>::PER16;
+    const int cpt = C / EP;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total16; idx += (long)gridDim.x * 256) {
+        const int chunk = idx % cpt;
+        const long pix = idx / cpt;                       // output pixel index over [B,2H,2W]
+        const int ox = pix % (2 * W), oy = (pix / (2 * W)) % (2 * H);
+        const long b = pix / ((long)4 * H * W);
+        float v[EP];
+        unpack16(*(const uint4*)(x + ((b * H + (oy >> 1)) * W + (ox >> 1)) * C + chunk * EP), v, (T*)nullptr);
+#pragma unroll
+        for (int e = 0; e < EP; e++) v[e] *= scale;
+        *(uint4*)(y + pix * C + chunk * EP) = pack16(v, (T*)nullptr);
+    }
+}
+
 // dense layer parameter gradients: gW[o][i] (+)= sum_b gy[b][o]*x[b][i];  gb[o] (+)= sum_b gy[b][o]
 __global__ void dense_wgrad_kernel(const float* __restrict__ gy, int ldgy, const float* __restrict__ x, int ldx,
                                    float* __restrict__ gW, float* __restrict__ gb, int B, int O, int I, int accumulate) {
@@ -579,6 +641,27 @@ extern "C" int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img,
     if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gx, (const bf16_t*)x0, img, out4, HW, C);
     else hipLaunchKernelGGL(fromrgb_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gx, (const float*)x0, img, out4, HW, C);
     DGE_LAUNCH_CHECK("fromrgb_bwd");
+    return 0;
+}
+
+extern "C" int dge_fromrgb_dgrad(const void* gx, const void* x0, const float* w, float* gimg, int B, int HW, int C, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(CHAN_OK(C, ep), "fromrgb_dgrad: unsupported channel count %d", C);
+    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_dgrad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gx, (const bf16_t*)x0, w, gimg, HW, C);
+    else hipLaunchKernelGGL(fromrgb_dgrad_kernel<float>, grid, dim3(256), 0, s, (const float*)gx, (const float*)x0, w, gimg, HW, C);
+    DGE_LAUNCH_CHECK("fromrgb_dgrad");
+    return 0;
+}
+
+extern "C" int dge_nearest_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0, "nearest_up2: channels must be a multiple of %d", ep);
+    const long total16 = (long)B * 4 * H * W * (C / ep);
+    const unsigned grid = (unsigned)((total16 + 255) / 256 > 65535 ? 65535 : (total16 + 255) / 256);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(nearest_up2_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, scale, total16);
+    else hipLaunchKernelGGL(nearest_up2_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, H, W, C, scale, total16);
+    DGE_LAUNCH_CHECK("nearest_up2");
     return 0;
 }
 

@@ -58,63 +58,13 @@ class BlurBE(nn.Module):
             inputs, outputs = min(maxf, inputs * 2), min(maxf, outputs * 2)
             resolution /= 2
 
-    @torch.no_grad()
     def forward(self, img, block_num=9, noises=None):
-        dt = _dt(self.compute_dtype)
-        dev = img.device
-        B, _, R, _ = img.shape
-        if noises is None:
-            noises = draw_noises(self, B, R, dev)
-            # fused-scale blocks draw their second noise at half resolution
-            ni = 0
-            for j, blk in enumerate(self.decode_block):
-                ni += 1
-                if blk.has_last_conv:
-                    if blk.fused_scale:
-                        r = (R >> j) // 2
-                        noises[ni] = torch.randn(B, 1, r, r, device=dev)
-                    ni += 1
-        cache = self.__dict__.setdefault("_pack_cache", {})
-        zeros = lambda c: torch.zeros((B, c, 2), dtype=torch.float32, device=dev)
-        fr = self.FromRGB.from_rgb
-        stats = zeros(self.startf)
-        x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats)
-        ws, ni = [], 0
-        for j, blk in enumerate(self.decode_block):
-            Cc, C2, H = blk.inputs, blk.outputs, R >> j
-            last = not blk.has_last_conv
-            musig1, sc1, sh1 = ops.stats_finalize(stats, H * H)
-            w1 = ops.linear(musig1, blk.inver_mod1.weight.detach(), blk.inver_mod1.bias.detach())
-            n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
-            st1 = zeros(Cc)
-            x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
-                            noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
-                            act=ops.ACT_LRELU, stats=st1)
-            musig2, sc2, sh2 = ops.stats_finalize(st1, H * H)
-            w2 = ops.linear(musig2, blk.inver_mod2.weight.detach(), blk.inver_mod2.bias.detach())
-            nstats = zeros(C2) if not last else None
-            if not last:
-                y2 = ops.blur_noise_act(ops.blend(x1, sc=sc2, sh=sh2), None, None, None, blur=True, act=False)   # blur(IN2(x1))
-                wpk = _packed(cache, blk.conv_2, dt, ops.PACK_FWD)
-                n2 = noises[ni]; ni += 1
-                nw2, b2 = blk.noise_weight_2.detach().reshape(-1), blk.bias_2.detach().reshape(-1)
-                if blk.fused_scale:        # conv(s2, transform_kernel) == pool(conv); noise/bias/lrelu at half resolution
-                    t = ops.blend(ops.conv2d(y2, wpk, C2, 3), pool=True)
-                    x2 = ops.blur_noise_act(t, n2.reshape(B, H // 2, H // 2).contiguous(), nw2, b2, blur=False)
-                else:
-                    a2 = ops.conv2d(y2, wpk, C2, 3, noise=n2.reshape(B, H, H).contiguous(), noise_w=nw2, bias=b2, act=ops.ACT_LRELU)
-                    x2 = ops.blend(a2, pool=True)
-                xp = ops.blend(x, pool=True)
-                if Cc != C2:
-                    out = ops.conv2d(xp, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(),
-                                     gain=0.889, addend=x2, add_scale=0.111, stats=nstats)
-                else:
-                    out = ops.blend(x2, z=xp, alpha=0.111, beta=0.889, stats=nstats)
-            else:
-                out = ops.blend(x1, z=x, sc=sc2, sh=sh2, alpha=0.111, beta=0.889)
-            ws = [w2, w1] + ws
-            x, stats = out, nstats
-        return ops.nhwc_to_nchw(x), torch.stack(ws, dim=1)
+        """img [B,3,R,R] -> (x [B,C,4,4], w [B,2*layer_count,512]); differentiable w.r.t. the parameters AND the image
+        (autograd_encblur: embedding_img.py:86-127 back-propagates through both outputs and through the input)."""
+        if block_num != 9:
+            raise ValueError("progressive block_num != 9 is not used by the reference's scripts")
+        from .autograd_encblur import BlurEncoderFunction
+        return BlurEncoderFunction.apply(self, img, noises, *list(self.parameters()))
 
 
 # ----------------------------------------------------------------------------------- E_PG

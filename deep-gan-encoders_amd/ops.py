@@ -462,3 +462,19 @@ def nearest_up2_bwd(ghi, x=None):
     check(lib().dge_nearest_up2_bwd(_p(ghi), _p(x), _p(glow), _f32(st), B, H2 // 2, W2 // 2, Cc, dtype_of(ghi), _stream()),
           "dge_nearest_up2_bwd")
     return glow, st
+
+
+def fromrgb_dgrad(gx, x0, w):
+    """Gradient of FromRGB w.r.t. its input image -> [B,3,H,W] f32."""
+    B, H, W, Cc = x0.shape
+    gimg = torch.empty((B, 3, H, W), dtype=torch.float32, device=x0.device)
+    check(lib().dge_fromrgb_dgrad(_p(gx), _p(x0), _f32(w.reshape(Cc, 3).contiguous()), _p(gimg), B, H * W, Cc, dtype_of(x0), _stream()),
+          "dge_fromrgb_dgrad")
+    return gimg
+
+
+def nearest_up2(x, scale=1.0):
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
+    check(lib().dge_nearest_up2(_p(x), _p(y), B, H, W, Cc, float(scale), dtype_of(x), _stream()), "dge_nearest_up2")
+    return y

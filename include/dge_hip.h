@@ -174,6 +174,12 @@ int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const fl
    bias gradient of a parallel 1x1 branch fed by the same gup, reference E.py conv_3) */
 int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int red_cols, int B, int H, int W, int C,
                 int pool, float scale, float slope, int dtype, dge_stream_t stream);
+/* FromRGB data gradient (model/utils/net.py:231-240 differentiated w.r.t. the image; embedding_img.py:88 feeds a generated,
+ * gradient-carrying image into the encoder): gimg [B,3,HW] f32 = sum_c w[c][k] * gx[b,p,c] * lrelu'(x0[b,p,c]) */
+int dge_fromrgb_dgrad(const void* gx, const void* x0, const float* w, float* gimg, int B, int HW, int C, int dtype, dge_stream_t stream);
+/* upscale2d materialised (nearest x2, model/stylegan1/net.py:37-43) with a scale: y [B,2H,2W,C] = scale * x[B,H,W,C][y/2,x/2];
+ * with scale 0.25 it is the adjoint of avg_pool2d(2) (downscale2d / the stride-2 transform_kernel conv of E_Blur.py:35) */
+int dge_nearest_up2(const void* x, void* y, int B, int H, int W, int C, float scale, int dtype, dge_stream_t stream);
 /* coefficients (A,Bc,Cc)[B,C,3] of the instance-norm + (mean,std) backward; see DESIGN.md */
 int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh, float* coef,
                     int B, int C, int npix, dge_stream_t stream);

@@ -657,6 +657,34 @@ def gen_step_sg1():
 
 SECTIONS["step_sg1"] = gen_step_sg1
 
+def gen_encblurgrad():
+    """Gradients of the reference E_Blur.BE w.r.t. every parameter AND the input image for a seeded linear functional of
+    both outputs (x, w) -- what embedding_img.py:86-127 back-propagates.  Same model / input / noise as encblur_small.npz."""
+    import model.E.E_Blur as EB
+    E = EB.BE(startf=16, maxf=64, layer_count=6)
+    sd = R.fill_encoder(shapes_of(E.state_dict()), seed=61)
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = E.state_dict()[k].clone()
+    E.load_state_dict(sd)
+    img = R.randn("eb.img", (2, 3, 128, 128), 61, 0.5).requires_grad_(True)
+    with _NoiseFeeder("eb", 61):
+        x, w = E(img)
+    gx, gw = R.randn("eb.gx", tuple(x.shape), 63), R.randn("eb.gw", tuple(w.shape), 63)
+    loss = (x * gx).sum() + (w * gw).sum()
+    loss.backward()
+    out = {"loss": loss.detach(), "g_img": img.grad}
+    for k, p_ in E.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad
+        out["norm:" + k] = g.norm()
+        out["grad:" + k] = g if g.numel() <= 40000 else g.flatten()[:4096]
+    save_npz("encblur_grad.npz", **out)
+
+
+SECTIONS["encblurgrad"] = gen_encblurgrad
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
