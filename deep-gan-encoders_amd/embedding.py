@@ -1,0 +1,80 @@
+"""Real-image inversion loop of the reference (embedding_img.py:74-170, BASELINE config 5) on the HIP path:
+StyleGAN1 synthesis Gs + E_Blur encoder, per image group the encoder is re-loaded and fine-tuned for `iterations`
+two-phase steps:
+
+    const2, w1 = E(imgs1); imgs2 = Gs.forward(w1, lod); const3, w2 = E(imgs2)                       (:86-88)
+    loss_msiv = loss_imgs + 0.125*(loss_medium + loss_small)   [both crops detached: value only]    (:92-111)
+    backward(retain_graph=True); step
+    loss_msLv = 0.01*(space_loss(w1, w2) + space_loss(const2, const3)); backward; step               (:116-127)
+
+Every gradient path of the reference is live: through Gs into w1, through the second encoder call into its input image
+(and on through Gs), through both encoder outputs (w and the 4x4 const).  `--optimizeE False` is not offered: in the
+reference it re-uses the graph of a single E(imgs1) call across iterations and fails in the second one, and the CLI flag
+(`type=bool`) cannot be switched off anyway (:190).
+"""
+import collections
+import math
+
+import torch
+
+from . import losses
+from .custom_adam import LREQAdam
+
+
+class EmbedStep:
+    def __init__(self, Gs, E, lpips_model, lr=0.01, beta_1=0.0):
+        self.Gs, self.E, self.lpips = Gs, E, lpips_model
+        self.opt = LREQAdam([{"params": E.parameters()}], lr=lr, betas=(beta_1, 0.99), weight_decay=0)
+        self.lod = Gs.layer_count - 1
+        self._ckpt = {k: v.detach().clone() for k, v in E.state_dict().items()}
+        self.last = {}
+
+    def begin_image(self):
+        """embedding_img.py:82-83: reload the encoder checkpoint and clear the optimizer state for every image group."""
+        self.E.load_state_dict(self._ckpt)
+        for p in self.E.parameters():
+            p._dge_gen = getattr(p, "_dge_gen", 0) + 1           # packed-weight caches key on this counter
+        self.opt.state = collections.defaultdict(dict)
+
+    def step(self, imgs1, noises=(None, None, None)):
+        """One iteration; `noises` = optional (E(imgs1), Gs, E(imgs2)) noise lists for parity runs."""
+        from . import ops
+        E, Gs = self.E, self.Gs
+        ops.zero_arena_begin(imgs1.device)
+        const2, w1 = E(imgs1, noises=noises[0])
+        imgs2 = Gs.forward(w1, self.lod, noises=noises[1])
+        const3, w2 = E(imgs2, noises=noises[2])
+        loss_msiv, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, weights=(1.0, 0.125, 0.125),
+                                                    grad_windows=(True, False, False))
+        self.opt.zero_grad()
+        loss_msiv.backward(retain_graph=True)
+        self.opt.step()
+        loss_w, info_w = losses.space_loss(w1, w2, image_space=False)
+        loss_c1, info_c1 = losses.space_loss(const2, const3, image_space=False)
+        loss_mslv = (loss_w + loss_c1) * 0.01
+        self.opt.zero_grad()
+        loss_mslv.backward()
+        self.opt.step()
+        ops.zero_arena_end()
+        self.last = dict(w1=w1.detach(), imgs2=imgs2.detach(), w2=w2.detach(), const2=const2.detach(), const3=const3.detach(),
+                         loss_msiv=loss_msiv.detach(), info_img=info_img, loss_w=loss_w.detach(), loss_c1=loss_c1.detach())
+        return self.last
+
+
+def build_models(img_size=1024, start_features=16, compute_dtype="bf16", device="cuda", seed=0):
+    """Models of BASELINE config 5 (StyleGAN1 FFHQ-1024 synthesis + E_Blur) with seeded random-init weights."""
+    from .stylegan1 import Generator
+    from .encoder_variants import BlurBE
+    from .lpips import LPIPS
+    torch.manual_seed(seed)
+    L = int(math.log2(img_size) - 1)
+    Gs = Generator(startf=start_features, maxf=512, layer_count=L, latent_size=512, channels=3, compute_dtype=compute_dtype).to(device)
+    for p in Gs.parameters():
+        p.requires_grad_(False)
+    with torch.no_grad():
+        for name, p in Gs.named_parameters():
+            if "noise_weight" in name:
+                p.fill_(0.05)
+    E = BlurBE(startf=start_features, maxf=512, layer_count=L, compute_dtype=compute_dtype).to(device)
+    LP = LPIPS(compute_dtype=compute_dtype).to(device)
+    return Gs, E, LP

@@ -100,7 +100,26 @@ class _ScaledGrad(torch.autograd.Function):
         return out, None, None
 
 
-def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0), global_batch=None):
+class _ScaledGrad2(torch.autograd.Function):
+    """as _ScaledGrad, for a loss whose BOTH arguments carry a gradient (latent losses of embedding_img.py:118-124)."""
+
+    @staticmethod
+    def forward(ctx, a, b, loss, ga, gb):
+        ctx.save_for_backward(ga, gb)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        outs = []
+        gof = go.contiguous().float()
+        for g in ctx.saved_tensors:
+            out = torch.empty_like(g)
+            check(lib().dge_axpy_scalar(_p(g), _p(gof), _p(out), g.numel(), 1.0, 0, _stream()), "dge_axpy_scalar")
+            outs.append(out)
+        return outs[0], outs[1], None, None, None
+
+
+def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0), global_batch=None, grad_windows=(True, True, True)):
     """loss_tsa = loss_imgs + 5*loss_medium + 9*loss_small (E_align_s2.py:185-203).
     Returns (loss [] on device, info [3,8] on device: rows full/AT1/AT2, columns
     loss, mse, mse_mean, mse_std, kl, cos, ssim, lpips).  No host synchronisation."""
@@ -110,7 +129,9 @@ def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0), glob
     g = torch.zeros_like(b) if need else None
     infos = []
     for i, win in enumerate(attention_windows(a.shape[2], a.shape[3])):
-        infos.append(_space_loss_window(a, b, win, True, lpips_model, weights[i], g, accumulate=True, gb=global_batch))
+        # grad_windows[i] False: the window enters the loss VALUE only (embedding_img.py:95-107 detaches both crops)
+        infos.append(_space_loss_window(a, b, win, True, lpips_model, weights[i], g if grad_windows[i] else None, accumulate=True,
+                                        gb=global_batch))
     info = torch.stack(infos)
     wv = torch.tensor(weights, dtype=torch.float32, device=a.device)
     loss = (info[:, 0] * wv).sum()
@@ -135,6 +156,14 @@ def space_loss(imgs1, imgs2, image_space=True, lpips_model=None, global_batch=No
         n_in = a.numel() // Bt
         out8 = _space_loss_window(a.view(1, Bt, 1, n_in), b.view(1, Bt, 1, n_in), (0, 0, 1, n_in), False, None, 1.0,
                                   g.view(1, Bt, 1, n_in) if need else None, accumulate=False, gb=global_batch)
+        if imgs1.requires_grad and torch.is_grad_enabled():
+            # the first argument carries a gradient too: 5*mse + 3*cos is symmetric, so d/da is the same kernel with
+            # the arguments exchanged (the logged-only KL term is not, and is taken from the first evaluation)
+            ga = torch.empty_like(a)
+            _space_loss_window(b.view(1, Bt, 1, n_in), a.view(1, Bt, 1, n_in), (0, 0, 1, n_in), False, None, 1.0,
+                               ga.view(1, Bt, 1, n_in), accumulate=False, gb=global_batch)
+            gbt = g if need else torch.zeros_like(b)
+            return _ScaledGrad2.apply(imgs1, imgs2, out8[0], ga, gbt), out8
     loss = out8[0]
     if need:
         loss = _ScaledGrad.apply(imgs2, loss, g)

@@ -685,6 +685,81 @@ def gen_encblurgrad():
 
 SECTIONS["encblurgrad"] = gen_encblurgrad
 
+def gen_embed():
+    """Two iterations of the reference's inversion loop body (embedding_img.py:84-127, optimizeE=True, batch 1) at reduced
+    size: StyleGAN1 Gs (5 blocks, 64x64) + E_Blur (5 blocks), seeded stand-in LPIPS, every noise tensor captured."""
+    import warnings
+    import model.stylegan1.net as SG1
+    import model.E.E_Blur as EB
+    import training_utils as TU
+    from model.utils.custom_adam import LREQAdam
+    from oracle import lpips_ref as LR
+
+    L = 5
+    Gs = SG1.Generator(startf=16, maxf=64, layer_count=L, latent_size=512, channels=3)
+    sd = R.fill_encoder(shapes_of(Gs.state_dict()), seed=43)
+    for k in sd:
+        if k.endswith("blur.weight"):
+            sd[k] = Gs.state_dict()[k].clone()
+        if k == "const":
+            sd[k] = R.randn("sg1step.const", tuple(sd[k].shape), 43)
+    Gs.load_state_dict(sd)
+    E = EB.BE(startf=16, maxf=64, layer_count=L)
+    esd = R.fill_encoder(shapes_of(E.state_dict()), seed=71)
+    for k in esd:
+        if k.endswith("blur.weight"):
+            esd[k] = E.state_dict()[k].clone()
+    E.load_state_dict(esd)
+    LP = LR.seeded_params(0)
+    lp = lambda a, b: LR.lpips(LP, a, b)
+    opt = LREQAdam([{"params": E.parameters()}], lr=0.01, betas=(0.0, 0.99), weight_decay=0)
+    imgs1 = torch.tanh(R.randn("embed.img", (1, 3, 64, 64), 72, 0.8))
+    lod = L - 1
+    out = {"imgs1": imgs1}
+    for it in range(2):
+        with _NoiseFeeder(f"embed.it{it}", 2) as nf:
+            const2, w1 = E(imgs1)
+            imgs2 = Gs.forward(w1, lod)
+            const3, w2 = E(imgs2)
+        if it == 0:
+            out["noise_shapes"] = np.array([list(s_) for s_ in nf.log])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss_imgs, _ = TU.space_loss(imgs1, imgs2, lpips_model=lp)
+            m1 = imgs1[:, :, :, imgs1.shape[3] // 8:-imgs1.shape[3] // 8].detach().clone()
+            m2 = imgs2[:, :, :, imgs2.shape[3] // 8:-imgs2.shape[3] // 8].detach().clone()
+            loss_medium, _ = TU.space_loss(m1, m2, lpips_model=lp)
+            o = imgs1.shape[2] // 8 + imgs1.shape[2] // 32
+            s1, s2 = imgs1[:, :, o:-o, o:-o].detach().clone(), imgs2[:, :, o:-o, o:-o].detach().clone()
+            loss_small, _ = TU.space_loss(s1, s2, lpips_model=lp)
+            opt.zero_grad()
+            loss_msiv = loss_imgs + (loss_medium + loss_small) * 0.125
+            loss_msiv.backward(retain_graph=True)
+            out[f"it{it}_grad1:decode_block.0.conv_1.weight"] = E.decode_block[0].conv_1.weight.grad.clone()
+            out[f"it{it}_grad1:decode_block.3.inver_mod2.weight"] = E.decode_block[3].inver_mod2.weight.grad.clone()
+            opt.step()
+            loss_w, _ = TU.space_loss(w1, w2, image_space=False)
+            loss_c1, _ = TU.space_loss(const2, const3, image_space=False)
+            opt.zero_grad()
+            loss_mslv = (loss_w + loss_c1) * 0.01
+            loss_mslv.backward()
+            out[f"it{it}_grad2:decode_block.0.conv_1.weight"] = E.decode_block[0].conv_1.weight.grad.clone()
+            out[f"it{it}_grad2:decode_block.2.conv_2.weight"] = E.decode_block[2].conv_2.weight.grad.clone()
+            out[f"it{it}_grad2:decode_block.4.inver_mod1.weight"] = E.decode_block[4].inver_mod1.weight.grad.clone()
+            out[f"it{it}_grad2:FromRGB.from_rgb.weight"] = E.FromRGB.from_rgb.weight.grad.clone()
+            opt.step()
+        out[f"it{it}_w1"] = w1.detach()
+        out[f"it{it}_w2"] = w2.detach()
+        out[f"it{it}_imgs2"] = imgs2.detach()
+        out[f"it{it}_const2"] = const2.detach()
+        out[f"it{it}_const3"] = const3.detach()
+        out[f"it{it}_losses"] = np.array([float(loss_msiv), float(loss_imgs), float(loss_medium), float(loss_small), float(loss_w), float(loss_c1)])
+        out[f"it{it}_param_checksum"] = np.array(R.checksum({k: v for k, v in E.state_dict().items() if not k.endswith("blur.weight")}))
+    save_npz("embed_sg1.npz", **out)
+
+
+SECTIONS["embed"] = gen_embed
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
