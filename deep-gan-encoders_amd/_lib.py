@@ -46,7 +46,7 @@ SIGNATURES = {
     "dge_space_loss_finalize": [_P, _P, _P, _P, _F, _F, _I, _P],
     "dge_space_loss_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_axpy_scalar": [_P, _P, _P, C.c_long, _F, _I, _P],
-    "dge_lreq_adam_multi": [_I, _P, _P, _P, _P, _P, _F, _F, _P, _P],
+    "dge_lreq_adam_multi": [_I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
     "dge_modconv_bwd_prep": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dge_demod_bwd": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
     "dge_linear_t": [_P, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],

@@ -25,6 +25,38 @@ class LREQAdam(Optimizer):
             raise ValueError("weight_decay != 0 is not used on the E_align path (the reference's branch reads the "
                              "non-existent attribute p.coef, custom_adam.py:56)")
         super().__init__(params, dict(lr=lr, beta_2=beta_2, eps=eps, weight_decay=weight_decay))
+        # hipGraph mode (graph_begin): the sqrt(1 - beta2^t) factor of the k-th step() call inside the captured region is
+        # read from a device scalar that the host refreshes before every replay
+        self._graph_corr = None
+        self._graph_call = 0
+
+    def graph_begin(self, calls_per_replay, device):
+        """Call once before capturing a region that contains `calls_per_replay` step() calls."""
+        self._graph_corr = torch.ones(calls_per_replay, dtype=torch.float32, device=device)
+        self._graph_call = 0
+
+    def graph_advance(self):
+        """Before every capture / replay: advance all step counters by the region's step() calls and upload the factors.
+        Parameters that never receive gradients are not counted (they have no state), as in the reference (:35-36)."""
+        n = self._graph_corr.numel()
+        group = self.param_groups[0]
+        t0 = max([self.state[p]["step"] for p in group["params"] if p in self.state and len(self.state[p])] or [0])
+        if getattr(self, "_graph_t", None) is None:
+            self._graph_t = t0
+        vals = [math.sqrt(1 - group["beta_2"] ** (self._graph_t + k + 1)) for k in range(n)]
+        self._graph_t += n
+        # a fresh pageable host tensor per call: the copy is staged before it returns, so the host may run several
+        # replays ahead of the device without overwriting factors that have not been consumed yet
+        self._graph_corr.copy_(torch.tensor(vals, dtype=torch.float32))
+        self._graph_call = 0
+
+    def graph_reset(self):
+        """Fresh optimizer state without changing any device address (embedding_img.py:83 between images)."""
+        for st in self.state.values():
+            if len(st):
+                st["exp_avg_sq"].zero_()
+                st["step"] = 0
+        self._graph_t = 0
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
@@ -45,7 +77,10 @@ class LREQAdam(Optimizer):
                     state["step"] = 0
                     state["exp_avg_sq"] = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
                 state["step"] += 1
-                step_size = group["lr"] * math.sqrt(1 - group["beta_2"] ** state["step"])
+                if self._graph_corr is None:
+                    step_size = group["lr"] * math.sqrt(1 - group["beta_2"] ** state["step"])
+                else:
+                    step_size = group["lr"]                       # x device factor of this call
                 if hasattr(p, "lr_equalization_coef"):
                     step_size *= p.lr_equalization_coef
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
@@ -61,6 +96,10 @@ class LREQAdam(Optimizer):
             PA = (C.c_void_p * n)(*ps); GA = (C.c_void_p * n)(*gs); VA = (C.c_void_p * n)(*vs)
             NA = (C.c_long * n)(*ns); SA = (C.c_float * n)(*steps)
             gsc = C.c_void_p(grad_scale.data_ptr()) if grad_scale is not None else None
-            check(lib().dge_lreq_adam_multi(n, PA, GA, VA, NA, SA, group["beta_2"], group["eps"], gsc, _stream()),
+            smul = None
+            if self._graph_corr is not None:
+                smul = C.c_void_p(self._graph_corr.data_ptr() + 4 * self._graph_call)
+                self._graph_call += 1
+            check(lib().dge_lreq_adam_multi(n, PA, GA, VA, NA, SA, group["beta_2"], group["eps"], gsc, smul, _stream()),
                   "dge_lreq_adam_multi")
         return loss

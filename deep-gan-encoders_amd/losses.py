@@ -133,8 +133,7 @@ def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0), glob
         infos.append(_space_loss_window(a, b, win, True, lpips_model, weights[i], g if grad_windows[i] else None, accumulate=True,
                                         gb=global_batch))
     info = torch.stack(infos)
-    wv = torch.tensor(weights, dtype=torch.float32, device=a.device)
-    loss = (info[:, 0] * wv).sum()
+    loss = info[0, 0] * float(weights[0]) + info[1, 0] * float(weights[1]) + info[2, 0] * float(weights[2])   # no host->device copy
     if need:
         loss = _ScaledGrad.apply(imgs2, loss, g)
     return loss, info

@@ -85,6 +85,17 @@ class LPIPS(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def _scaling_host(self):
+        """Host copies of the ScalingLayer constants (kernel arguments); read back from the device only when the
+        buffers change -- a .tolist() per call would put a device synchronisation into every loss evaluation."""
+        sl = self.scaling_layer
+        key = (sl.shift._version, sl.shift.data_ptr(), sl.scale._version, sl.scale.data_ptr())
+        hit = self._cache.get("scaling")
+        if hit is None or hit[0] != key:
+            hit = (key, (C.c_float * 3)(*sl.shift.flatten().tolist()), (C.c_float * 3)(*sl.scale.flatten().tolist()))
+            self._cache["scaling"] = hit
+        return hit[1], hit[2]
+
     # ---------------------------------------------------------------- forward (+ gradient w.r.t. b)
     def value_and_grad(self, a, b, need_grad=True):
         """a, b: [B,3,h,w] f32 in [-1,1].  Returns (mean over the batch of LPIPS(a,b) as a [1]
@@ -93,8 +104,7 @@ class LPIPS(nn.Module):
         B, _, h, w = a.shape
         dev = a.device
         L = lib()
-        shift = (C.c_float * 3)(*self.scaling_layer.shift.flatten().tolist())
-        scale = (C.c_float * 3)(*self.scaling_layer.scale.flatten().tolist())
+        shift, scale = self._scaling_host()
         x = torch.empty((2 * B, h, w, _CPAD), dtype=ops.tdtype(dt), device=dev)
         check(L.dge_lpips_prep(_f32(a.contiguous()), _p(x[:B]), B, h * w, _CPAD, shift, scale, dt, _stream()), "dge_lpips_prep")
         check(L.dge_lpips_prep(_f32(b.contiguous()), _p(x[B:]), B, h * w, _CPAD, shift, scale, dt, _stream()), "dge_lpips_prep")

@@ -138,7 +138,14 @@ class Mapping(nn.Module):
                 x = ops.linear(x, fc.weight.detach(), fc.bias.detach(), act=ops.ACT_LRELU)
             if self.buffer1 is None:
                 return x.view(x.shape[0], 1, -1).repeat(1, self.num_layers, 1)
-            coefs = torch.as_tensor(coefs_m, dtype=torch.float32).reshape(-1)
-            if coefs.numel() == 1:
-                coefs = coefs.repeat(self.num_layers)
-            return ops.lerp_layers(x, self.buffer1.to(dev).float().reshape(-1, x.shape[1]), coefs.to(dev))
+            # device copies of the truncation centre / coefficients are cached: the reference passes CPU tensors every
+            # step (E_align_s2.py:35-41,105), re-uploading them would put two synchronising copies into each iteration
+            key = (id(self.buffer1), getattr(self.buffer1, "_version", 0), id(coefs_m), getattr(coefs_m, "_version", 0), str(dev))
+            hit = self.__dict__.get("_trunc_cache")
+            if hit is None or hit[0] != key:
+                coefs = torch.as_tensor(coefs_m, dtype=torch.float32).reshape(-1)
+                if coefs.numel() == 1:
+                    coefs = coefs.repeat(self.num_layers)
+                hit = (key, self.buffer1.to(dev).float().reshape(-1, x.shape[1]).contiguous(), coefs.to(dev).contiguous(), self.buffer1, coefs_m)
+                self.__dict__["_trunc_cache"] = hit
+            return ops.lerp_layers(x, hit[1], hit[2])

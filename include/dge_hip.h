@@ -143,10 +143,11 @@ int dge_axpy_scalar(const float* x, const float* scalar, float* y, long n, float
 /* ---- LREQAdam.step, model/utils/custom_adam.py:24-76, all tensors in one launch ------------ */
 /* host_* are HOST arrays of `ntensors` device pointers / sizes / per-tensor step sizes
  * (= lr * sqrt(1 - beta2^t) * lr_equalization_coef, :62-72).  gscale: optional device scalar the
- * gradients are multiplied by first (e.g. 1/world_size after an all-reduce-sum). */
+ * gradients are multiplied by first (e.g. 1/world_size after an all-reduce-sum).  step_mult: optional DEVICE scalar
+ * multiplied into every step size (the sqrt(1 - beta2^t) factor when the step is replayed from a captured hipGraph). */
 int dge_lreq_adam_multi(int ntensors, float* const* host_p, const float* const* host_g, float* const* host_v,
                         const long* host_n, const float* host_step, float beta2, float eps, const float* gscale,
-                        dge_stream_t stream);
+                        const float* step_mult, dge_stream_t stream);
 
 /* ---- data gradient of the StyleGAN2 synthesis network w.r.t. wp (E_align_s2.py:160,204) ---- */
 /* Backward through noise/bias/lrelu*gain/demodulation of ModulateConvBlock (:905-921):

@@ -7,20 +7,26 @@ import dge_amd
 from dge_amd.embedding import EmbedStep, build_models
 ap = argparse.ArgumentParser()
 ap.add_argument("--img-size", type=int, default=1024); ap.add_argument("--start-features", type=int, default=16)
-ap.add_argument("--iters", type=int, default=20); ap.add_argument("--batch", type=int, default=1); ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--iters", type=int, default=20); ap.add_argument("--batch", type=int, default=1); ap.add_argument("--dtype", default="bf16"); ap.add_argument("--graph", action="store_true")
 a = ap.parse_args()
 Gs, E, LP = build_models(a.img_size, a.start_features, a.dtype)
 st = EmbedStep(Gs, E, LP)
 st.begin_image()
 with torch.no_grad():
     imgs1 = Gs.forward(torch.randn(a.batch, 2 * Gs.layer_count, 512, device="cuda"), Gs.layer_count - 1).detach()
+if a.graph:
+    st.capture(imgs1)
+    run = st.replay
+else:
+    run = lambda: st.step(imgs1)
 for i in range(3):
-    st.step(imgs1)
+    run()
 torch.cuda.synchronize()
 t0 = time.time()
 for i in range(a.iters):
-    st.step(imgs1)
+    run()
 torch.cuda.synchronize()
 dt = (time.time() - t0) / a.iters
-print(f"embedding_img loop, StyleGAN1-{a.img_size} + E_Blur(startf={a.start_features}), batch {a.batch}, {a.dtype}: "
+mode = ", hipGraph replay" if a.graph else ""
+print(f"embedding_img loop, StyleGAN1-{a.img_size} + E_Blur(startf={a.start_features}), batch {a.batch}, {a.dtype}{mode}: "
       f"{dt*1e3:.1f} ms/iteration, {1/dt:.1f} it/s, 1500 iterations in {1500*dt:.0f} s")
