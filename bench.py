@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--img-size", type=int, default=1024)
     ap.add_argument("--start-features", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--graph", action="store_true", help="single GPU only: replay the step from a captured hipGraph (removes the "
+                    "host launch overhead that bounds small batches); off by default so that N=1 and N>1 run the same path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-size", type=int, default=256, help="image size of the bounded CPU-oracle sample")
@@ -97,12 +99,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.graph:
+        assert world == 1, "--graph is a single-GPU option"
+        st.capture()
+        run = lambda i: st.replay(i)
+    else:
+        run = lambda i: st.step(i)
     for i in range(a.warmup):
-        st.step(i)
+        run(i)
     sync()
     t0 = time.time()
     for i in range(a.steps):
-        st.step(a.warmup + i)
+        run(a.warmup + i)
     sync()
     dt = time.time() - t0
     if world > 1:
@@ -118,7 +126,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"E_align_s2 two-phase step, {gname} + E.BE(startf={a.start_features}, "
                                f"L={E.layer_count}) + LPIPS-VGG16 (seeded stand-in weights), batch {a.batch}/GPU",
-                   "global_batch": a.batch * world, "img_size": a.img_size, "parallelism": f"dp{world}"},
+                   "global_batch": a.batch * world, "img_size": a.img_size, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if a.graph else "eager"},
     }
 
     # ---- G-synthesis ms/img (second half of the BASELINE metric), eval-mode synthesis(wp)

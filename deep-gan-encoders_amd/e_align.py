@@ -32,8 +32,10 @@ class _StyleGAN2Adapter:
     def __init__(self, generator):
         self.G = generator
 
+    mix_mask = None          # device [L] mask: set by EAlignStep in hipGraph mode (static kernel sequence)
+
     def sample(self, z, noises=None):
-        r = self.G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+        r = self.G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False, mix_mask=self.mix_mask)
         return r["image"], r["wp"]
 
     def synth(self, w, noises=None):
@@ -102,6 +104,50 @@ class EAlignStep:
         # plain mode: local losses -> mean.
         return None if self.exact_ddp else torch.full((1,), 1.0 / self.world, device=self.dev)
 
+    # ------------------------------------------------------------------ hipGraph replay of the iteration
+    def capture(self, warmup=2):
+        """Captures one iteration into a hipGraph (single-GPU runs; the ≈1300 launches of a step cost ≈18 ms of host time,
+        which bounds the step at the reference's default batch of 2).  Host-side decisions of an iteration become device
+        inputs: z (static buffer), the style-mixing mask (StyleGAN2 train mode, same np.random draw order as the
+        reference) and Adam's sqrt(1 - beta2^t) factors.  Encoder / StyleGAN1 noise comes from torch's graph-safe
+        device generator.  `warmup` + 1 real iterations run inside this call."""
+        if self.dist_on:
+            raise RuntimeError("hipGraph capture is offered for single-process runs only (collectives are not captured)")
+        B = self.batch_size
+        self._g_z = torch.zeros(B, self.z_dim, device=self.dev)
+        if isinstance(self.gen, _StyleGAN2Adapter):
+            self.gen.mix_mask = torch.zeros(self.G.num_layers, device=self.dev)
+        self.opt.graph_begin(2, self.dev)
+        self._g_iter = 0
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._graph_inputs(self._g_iter); self._g_iter += 1
+                self.step(0, z=self._g_z)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        self._graph_inputs(self._g_iter); self._g_iter += 1
+        with torch.cuda.graph(self._graph):
+            self._g_out = self.step(0, z=self._g_z)
+        return self._g_out
+
+    def _graph_inputs(self, iteration):
+        set_seed(iteration % 30000)
+        zg = torch.randn(self.batch_size * self.world, self.z_dim)
+        self._g_z.copy_(zg[self.rank * self.batch_size:(self.rank + 1) * self.batch_size])
+        if getattr(self.gen, "mix_mask", None) is not None:
+            from .stylegan2_generator import mixing_mask
+            self.gen.mix_mask.copy_(mixing_mask(self.G.num_layers))
+        self.opt.graph_advance()
+
+    def replay(self, iteration=None):
+        it = self._g_iter if iteration is None else iteration
+        self._graph_inputs(it)
+        self._g_iter = it + 1
+        self._graph.replay()
+        return self._g_out
+
     # ------------------------------------------------------------------ one iteration
     def step(self, iteration, z=None, noises=None, gen_noises=(None, None)):
         """`noises`: optional encoder noise tensors; `gen_noises`: optional (first, second) generator noise lists for
@@ -110,7 +156,8 @@ class EAlignStep:
         B = self.batch_size
         from . import ops
         ops.zero_arena_begin(self.dev)       # one memset for all of this step's accumulation buffers
-        set_seed(iteration % 30000)
+        if z is None or not z.is_cuda:
+            set_seed(iteration % 30000)
         if z is None:
             # every rank draws the same global z and takes its slice
             zg = torch.randn(B * self.world, self.z_dim)

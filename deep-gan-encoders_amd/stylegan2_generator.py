@@ -228,6 +228,15 @@ class SynthesisModule(nn.Module):
         return synthesis_forward(self, wp, randomize_noise)
 
 
+def mixing_mask(num_layers, style_mixing_prob=0.9):
+    """Host side of the train-mode style mixing (reference :183-191), same np.random draw order: returns the [L] float
+    mask (CPU) that `StyleGAN2Generator.forward(..., mix_mask=...)` applies on the device."""
+    m = torch.zeros(num_layers, dtype=torch.float32)
+    if np.random.uniform() < style_mixing_prob:
+        m[:np.random.randint(1, num_layers)] = 1.0
+    return m
+
+
 class StyleGAN2Generator(nn.Module):
     """Reference :35-196.  Extra keyword `compute_dtype` selects 'bf16' (default) or 'f32'."""
 
@@ -267,7 +276,14 @@ class StyleGAN2Generator(nn.Module):
             if self.training and style_mixing_prob > 0:
                 new_z = torch.randn_like(z)
                 new_w = self.mapping(new_z, label)["w"]
-                if np.random.uniform() < style_mixing_prob:
+                mix_mask = _unused_kwargs.get("mix_mask")
+                if mix_mask is not None:
+                    # hipGraph-friendly form of the same mixing: the host decision (uniform < prob, cutoff) arrives as a
+                    # device mask [L] (1 for layers below the cutoff, all zero when this step does not mix), so the
+                    # kernel sequence of a step is identical for every outcome (see EAlignStep.capture / mixing_mask)
+                    wt, nwt = self.truncation(w), self.truncation(new_w)
+                    w = wt + mix_mask.view(1, -1, 1) * (nwt - wt)
+                elif np.random.uniform() < style_mixing_prob:
                     mixing_cutoff = np.random.randint(1, self.num_layers)
                     w = self.truncation(w)
                     new_w = self.truncation(new_w)

@@ -138,3 +138,60 @@ def test_two_phase_step_stylegan1_matches_reference_run():
                     if du_ref.abs().max() > 0:
                         assert ((du - du_ref).norm() / du_ref.norm()).item() < 0.08, (it, k)
         assert abs(R.checksum({k: v.cpu() for k, v in sd_e.items()}) - float(g[f"it{it}_param_checksum"])) < 1e-5 * float(g[f"it{it}_param_checksum"])
+
+
+def test_style_mixing_mask_equals_reference_control_flow():
+    """The hipGraph-friendly device mask form of the train-mode style mixing (mixing_mask + forward(mix_mask=...)) gives the
+    same wp / image as the reference's host control flow (stylegan2_generator.py:183-191) for the same np.random state."""
+    import dge_amd
+    from dge_amd.stylegan2_generator import mixing_mask
+    G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="f32").cuda()
+    G.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+    G.train()
+    z = R.randn("step.z0", (2, 512), 1).cuda()
+    new_z = R.randn("step.new_z", (2, 512), 1).cuda()
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: new_z.clone()
+    try:
+        for seed in (0, 1, 2, 3, 7):        # covers mixing at several cutoffs and (seed-dependent) the no-mix outcome
+            w_avg0 = G.truncation.w_avg.clone()
+            np.random.seed(seed)
+            a = G(z, trunc_psi=0.7, trunc_layers=8)
+            G.truncation.w_avg.copy_(w_avg0)
+            np.random.seed(seed)
+            m = mixing_mask(G.num_layers).cuda()
+            b = G(z, trunc_psi=0.7, trunc_layers=8, mix_mask=m)
+            assert relerr(b["wp"], a["wp"].cpu().numpy()) < 1e-6
+            assert relerr(b["image"], a["image"].cpu().numpy()) < 1e-5
+    finally:
+        torch.randn_like = orig
+
+
+def test_graph_replay_of_the_training_step_runs():
+    """EAlignStep.capture / replay (hipGraph of the whole two-phase step): replays advance the optimisation (parameters move,
+    w_avg EMA moves, losses finite) with z / mixing mask / Adam factors fed as device inputs."""
+    import dge_amd
+    from dge_amd.encoder import BE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.e_align import EAlignStep
+    G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="bf16").cuda()
+    G.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+    G.train()
+    for p in G.parameters():
+        p.requires_grad_(False)
+    E = BE(startf=16, maxf=64, layer_count=5, compute_dtype="bf16").cuda()
+    E.load_state_dict(R.fill_encoder(enc_shapes(16, 64, 5), seed=31))
+    LP = LPIPS(compute_dtype="bf16").cuda()
+    LP.load_state_dict(LR.seeded_params(0))
+    st = EAlignStep(G, E, LP, lr=0.0015, batch_size=2)
+    st.capture(warmup=1)
+    p0 = E.decode_block[0].conv_1.weight.detach().clone()
+    wavg0 = G.truncation.w_avg.clone()
+    losses = []
+    for it in range(3):
+        r = st.replay()
+        losses.append(float(r["loss_tsa"]))
+    assert all(np.isfinite(losses)) and float(r["loss_w"]) == float(r["loss_w"])
+    assert float((E.decode_block[0].conv_1.weight.detach() - p0).abs().max()) > 0
+    assert float((G.truncation.w_avg - wavg0).abs().max()) > 0
+    assert len(set(losses)) == 3            # a new z every replay
