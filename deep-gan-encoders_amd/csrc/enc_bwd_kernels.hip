@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gup,
             *(uint4*)(gpre + ((size_t)b * HW + p) * C + chunk * EP) = pack16(g, (T*)nullptr);
         }
     }
-    if (red_out) block_chan_flush<EP, NS>(s, cpt, ppi, red_out, C, red);
+    if (red_out) block_chan_flush<EP, NS>(s, cpt, ppi, red_out + (size_t)b * C * NS, C, red);      // per-sample partial sums
 }
 
 // ------------------------------------------------------------------ instance-norm + statistics backward
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void in_bwd_kernel(const T* __restrict__ gy, c
             *(uint4*)(gout + o) = pack16(g, (T*)nullptr);
         }
     }
-    if (red_out) block_chan_flush<EP, 2>(s, cpt, ppi, red_out, C, red);
+    if (red_out) block_chan_flush<EP, 2>(s, cpt, ppi, red_out + (size_t)b * C * 2, C, red);       // per-sample partial sums
 }
 
 // per-channel sum over batch and pixels of an NHWC tensor: out[c] += scale * sum x[b,p,c]
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, 
             for (int e = 0; e < EP; e++) s[0][e] += scale * f[e];
         }
     }
-    block_chan_flush<EP, 1>(s, cpt, ppi, out, C, red);
+    block_chan_flush<EP, 1>(s, cpt, ppi, out + (size_t)blockIdx.y * C, C, red);
 }
 
 // FromRGB backward: x0 = lrelu(W img + b).  g_pre = g_x0*lrelu'(x0);  out[o][0..2] += sum g_pre*img[c], out[o][3] += sum g_pre
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void fromrgb_bwd_kernel(const T* __restrict__ 
             }
         }
     }
-    block_chan_flush<EP, 4>(s, cpt, ppi, out, C, red);
+    block_chan_flush<EP, 4>(s, cpt, ppi, out + (size_t)b * C * 4, C, red);
 }
 
 // FromRGB data gradient (needed when the encoder input itself carries a gradient: embedding_img.py:88 E(imgs2)):
@@ -567,7 +567,7 @@ __global__ void dense_wgrad_kernel(const float* __restrict__ gy, int ldgy, const
 }
 
 // =================================================================== C ABI
-static int sgrid(int hw, int ppi) { int g = (hw + ppi - 1) / ppi; return g > 1024 ? 1024 : (g < 1 ? 1 : g); }
+static int sgrid(int hw, int ppi) { int g = (hw + ppi - 1) / ppi; return g > 256 ? 256 : (g < 1 ? 1 : g); }   // <= 256 workgroups per sample: each flushes one atomic per (channel, sum) and same-address f32 atomics retire at ~40 ns
 #define CHAN_OK(C, ep) ((C) % (ep) == 0 && (C) / (ep) <= 256 && 256 % ((C) / (ep)) == 0)
 
 extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H,

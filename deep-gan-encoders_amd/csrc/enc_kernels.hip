@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void pixelnorm_nhwc_kernel(const T* __restrict
 // =================================================================== C ABI
 static int grid_for(int hw, int ppi) {
     int g = (hw + ppi - 1) / ppi;
-    return g > 1024 ? 1024 : (g < 1 ? 1 : g);
+    return g > 256 ? 256 : (g < 1 ? 1 : g);      // see enc_bwd_kernels.hip: same-address atomics of the statistics flush
 }
 
 extern "C" int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, float* stats, int B, int HW,

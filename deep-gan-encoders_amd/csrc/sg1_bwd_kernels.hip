@@ -8,7 +8,7 @@
 
 static inline int sgrid(int npix, int ppi) {
     const int nb = (npix + ppi - 1) / ppi;
-    return nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
 }
 #define CHAN_OK(C, ep) ((C) % (ep) == 0 && (C) / (ep) <= 256 && 256 % ((C) / (ep)) == 0)
 

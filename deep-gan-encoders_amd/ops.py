@@ -51,6 +51,16 @@ def zeros(shape, device):
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
+def _sum_over_batch(partial, out=None):
+    """partial [B, ...] per-sample sums -> [...] (dge_sum_slots); accumulates into `out` when given."""
+    n = partial[0].numel()
+    acc = out is not None
+    if out is None:
+        out = torch.empty(partial.shape[1:], dtype=torch.float32, device=partial.device)
+    check(lib().dge_sum_slots(_p(partial), _p(out), partial.shape[0], n, 1 if acc else 0, _stream()), "dge_sum_slots")
+    return out
+
+
 def tdtype(dtype):
     return torch.bfloat16 if dtype == BF16 else torch.float32
 
@@ -305,10 +315,15 @@ def conv_wgrad(g, x, dw, in_scale=None, in_shift=None):
 
 
 def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2):
+    """red [C, 2|3] (pre-zeroed) receives the batch-summed reductions: the kernel writes per-sample partial sums (no
+    cross-sample contention on the atomics) that are added over the batch here."""
     B, H, W, Cc = a.shape
     gpre = torch.empty_like(a)
-    check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(red), 2 if red is None else red.shape[-1], B, H, W, Cc,
+    part = zeros((B,) + tuple(red.shape), a.device) if red is not None else None
+    check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(part), 2 if red is None else red.shape[-1], B, H, W, Cc,
                             1 if pool else 0, float(scale), float(slope), dtype_of(a), _stream()), "dge_act_bwd")
+    if red is not None:
+        _sum_over_batch(part, red)
     return gpre
 
 
@@ -323,24 +338,27 @@ def in_bwd_coef(dots, gms, musig, sc, sh, npix):
 def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=None, act=False, red=None):
     B, H, W, Cc = x.shape
     gout = torch.empty_like(x)
-    check(lib().dge_in_bwd(_p(gy), _p(x), _f32(coef), _p(extra), _f32(noise), _p(gout), _f32(red), B, H, W, Cc,
+    part = zeros((B,) + tuple(red.shape), x.device) if red is not None else None
+    check(lib().dge_in_bwd(_p(gy), _p(x), _f32(coef), _p(extra), _f32(noise), _p(gout), _f32(part), B, H, W, Cc,
                            1 if extra_pool else 0, float(extra_scale), 1 if act else 0, dtype_of(x), _stream()), "dge_in_bwd")
+    if red is not None:
+        _sum_over_batch(part, red)
     return gout
 
 
 def chan_sum(x, scale=1.0):
     B, H, W, Cc = x.shape
-    out = zeros((Cc,), x.device)
-    check(lib().dge_chan_sum(_p(x), _p(out), B, H * W, Cc, float(scale), dtype_of(x), _stream()), "dge_chan_sum")
-    return out
+    part = zeros((B, Cc), x.device)
+    check(lib().dge_chan_sum(_p(x), _p(part), B, H * W, Cc, float(scale), dtype_of(x), _stream()), "dge_chan_sum")
+    return _sum_over_batch(part)
 
 
 def fromrgb_bwd(gx, x0, img):
     B, H, W, Cc = x0.shape
-    out = zeros((Cc, 4), x0.device)
-    check(lib().dge_fromrgb_bwd(_p(gx), _p(x0), _f32(img.contiguous()), _p(out), B, H * W, Cc, dtype_of(x0), _stream()),
+    part = zeros((B, Cc, 4), x0.device)
+    check(lib().dge_fromrgb_bwd(_p(gx), _p(x0), _f32(img.contiguous()), _p(part), B, H * W, Cc, dtype_of(x0), _stream()),
           "dge_fromrgb_bwd")
-    return out
+    return _sum_over_batch(part)
 
 
 def dense_wgrad(gy, x, gw, gb=None, accumulate=False):

@@ -171,7 +171,8 @@ int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, dge_stream_t
 int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H, int W,
                    int cout, int cin, int ksize, int dtype, dge_stream_t stream);
 /* gpre = scale * gup[q(p)] * (a > 0 ? 1 : slope) (q = 2x2 pooling parent when pool);
-   red[c,red_cols] += {sum gpre, sum gpre*noise [, sum over the gup grid of gup]}   (red_cols = 2 or 3; the third column is the
+   red[b,c,red_cols] (PER-SAMPLE partial sums, pre-zeroed: workgroups of different samples never contend on an address; the
+   caller adds them over b, e.g. dge_sum_slots) += {sum gpre, sum gpre*noise [, sum over the gup grid of gup]}   (red_cols = 2 or 3; the third column is the
    bias gradient of a parallel 1x1 branch fed by the same gup, reference E.py conv_3) */
 int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int red_cols, int B, int H, int W, int C,
                 int pool, float scale, float slope, int dtype, dge_stream_t stream);
@@ -184,11 +185,14 @@ int dge_nearest_up2(const void* x, void* y, int B, int H, int W, int C, float sc
 /* coefficients (A,Bc,Cc)[B,C,3] of the instance-norm + (mean,std) backward; see DESIGN.md */
 int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh, float* coef,
                     int B, int C, int npix, dge_stream_t stream);
-/* gout = A*gy + Bc*x + Cc + extra_scale*extra[q(p)], then optional lrelu' of x with bias/noise reductions */
+/* gout = A*gy + Bc*x + Cc + extra_scale*extra[q(p)], then optional lrelu' of x with bias/noise reductions into
+ * red [B,C,2] (per-sample partial sums, pre-zeroed; summed over b by the caller) */
 int dge_in_bwd(const void* gy, const void* x, const float* coef, const void* extra, const float* noise, void* gout, float* red,
                int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, dge_stream_t stream);
+/* out [B,C] (per-sample partial sums, pre-zeroed) += scale * sum_p x[b,p,c] */
 int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, int dtype, dge_stream_t stream);
-/* out4[o][0..2] += sum g_pre*img[c], out4[o][3] += sum g_pre with g_pre = gx*lrelu'(x0)  (FromRGB, net.py:231-240) */
+/* out4[b][o][0..2] += sum g_pre*img[c], out4[b][o][3] += sum g_pre with g_pre = gx*lrelu'(x0)  (FromRGB, net.py:231-240);
+ * per-sample partial sums [B,C,4], pre-zeroed, summed over b by the caller */
 int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img, float* out4, int B, int HW, int C, int dtype,
                     dge_stream_t stream);
 /* gw[o][i] (+)= sum_b gy[b][o]*x[b][i]; gb[o] (+)= sum_b gy[b][o]   (ln.Linear parameter gradients) */
