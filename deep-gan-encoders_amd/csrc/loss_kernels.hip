@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
     S = wave_sum(S);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = S;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(ssim_sum, red[0] + red[1] + red[2] + red[3]);
+    // 32 slot copies (same-address f32 atomics serialise; thousands of workgroups end here), summed by the finaliser
+    if (threadIdx.x == 0) atomicAdd(ssim_sum + ((blockIdx.x + blockIdx.y * 7 + blockIdx.z * 13) & 31), red[0] + red[1] + red[2] + red[3]);
 }
 
 // g[q] = scale * ( G*(dmu2) + 2 b[q] G*(dE22) + a[q] G*(dE12) )[q]      (loss = 1 - mean(S): scale = -1/N)
@@ -149,7 +150,9 @@ __global__ void space_loss_finalize_kernel(const float* __restrict__ sums, const
     float kl = sums[6] / n;
     if (isnan(kl)) kl = 0.f;
     if (isinf(kl)) kl = 1.f;
-    const float ssim_l = image_space ? 1.f - ssim_sum[0] / n_pooled : 0.f;
+    float ssim_tot = 0.f;
+    if (image_space) for (int k = 0; k < 32; k++) ssim_tot += ssim_sum[k];
+    const float ssim_l = image_space ? 1.f - ssim_tot / n_pooled : 0.f;
     const float lp = (image_space && lpips) ? lpips[0] : 0.f;
     out[0] = 5.f * mse + 3.f * cosv + ssim_l + 2.f * lp;
     out[1] = mse; out[2] = dm * dm; out[3] = ds * ds; out[4] = kl; out[5] = cosv; out[6] = ssim_l; out[7] = lp;
@@ -198,7 +201,7 @@ extern "C" int dge_loss_reduce(const float* a, const float* b, float* sums7, int
                                int h, int w, hipStream_t s) {
     DGE_CHECK(y0 >= 0 && x0 >= 0 && y0 + h <= H && x0 + w <= W && h > 0 && w > 0, "loss_reduce: bad crop");
     long npix = (long)B * h * w;
-    int grid = (int)((npix + 255) / 256); if (grid > 2048) grid = 2048;
+    int grid = (int)((npix + 255) / 256); if (grid > 512) grid = 512;      // every workgroup ends with 8 same-address atomics
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, s, a, b, sums7, B, C, mk(H, W, y0, x0, h, w));
     DGE_LAUNCH_CHECK("loss_reduce");
     return 0;

@@ -157,7 +157,13 @@ __global__ __launch_bounds__(256) void lpips_head_kernel(const T* __restrict__ f
         }
     }
     dacc = wave_sum(dacc);
-    if (lane == 0 && dacc != 0.f) atomicAdd(val + b, dacc * inv_hw);
+    __shared__ float wred[4];                             // one atomic per workgroup (same-address atomics serialise)
+    if (lane == 0) wred[threadIdx.x >> 6] = dacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (wred[0] + wred[1]) + (wred[2] + wred[3]);
+        if (t != 0.f) atomicAdd(val + b, t * inv_hw);
+    }
 }
 
 // out[0] = mean_b val[b]

@@ -62,7 +62,7 @@ def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accum
         check(L.dge_crop_pool(_f32(a), _p(ap), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
         check(L.dge_crop_pool(_f32(b), _p(bp), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
         npool = float(B * Cc * hp * wp) * world
-        ssum = ops.zeros((1,), dev)
+        ssum = ops.zeros((32,), dev)          # 32 slot copies of the SSIM sum (atomics contention), added up by the finaliser
         dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if g_out is not None else None
         check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(ssum), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
         if gb is not None:

@@ -126,7 +126,7 @@ int dge_loss_reduce(const float* a, const float* b, float* sums7, int B, int C, 
                     dge_stream_t stream);
 /* crop + k x k mean (the `while H > 256: avg_pool2d(2)` loop of :81-84 collapsed) on BC planes */
 int dge_crop_pool(const float* src, float* dst, int BC, int H, int W, int y0, int x0, int h, int w, int k, dge_stream_t stream);
-/* ssim_sum (pre-zeroed) += sum of the SSIM map of a,b [BC,h,w]; dmap (optional, [3][BC][h][w]) receives dS/dmu2,
+/* ssim_sum [32] (pre-zeroed slot copies; their total is the sum, dge_space_loss_finalize adds them) += sum of the SSIM map of a,b [BC,h,w]; dmap (optional, [3][BC][h][w]) receives dS/dmu2,
  * dS/dE[b^2], dS/dE[ab] for dge_ssim_bwd, which writes g = scale * dSum/db. */
 int dge_ssim_fwd(const float* a, const float* b, float* ssim_sum, float* dmap, int BC, int h, int w, dge_stream_t stream);
 int dge_ssim_bwd(const float* a, const float* b, const float* dmap, float* g, int BC, int h, int w, float scale,
