@@ -567,7 +567,6 @@ __global__ void dense_wgrad_kernel(const float* __restrict__ gy, int ldgy, const
 }
 
 // =================================================================== C ABI
-static int sgrid(int hw, int ppi) { int g = (hw + ppi - 1) / ppi; return g > 256 ? 256 : (g < 1 ? 1 : g); }   // <= 256 workgroups per sample: each flushes one atomic per (channel, sum) and same-address f32 atomics retire at ~40 ns
 #define CHAN_OK(C, ep) ((C) % (ep) == 0 && (C) / (ep) <= 256 && 256 % ((C) / (ep)) == 0)
 
 extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H,
@@ -597,7 +596,7 @@ extern "C" int dge_act_bwd(const void* gup, const void* a, const float* noise, v
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "act_bwd: unsupported channel count %d", C);
     DGE_CHECK(red_cols == 2 || red_cols == 3, "act_bwd: red_cols must be 2 or 3 (got %d)", red_cols);
-    dim3 grid(sgrid(H * W, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(H * W, 256 / (C / ep), B), B);
 #define AB(T, NS) hipLaunchKernelGGL((act_bwd_kernel<T, NS>), grid, dim3(256), 0, s, (const T*)gup, (const T*)a, noise, (T*)gpre, red, H, W, C, pool, scale, slope)
     if (dtype == DGE_BF16) { if (red_cols == 3) AB(bf16_t, 3); else AB(bf16_t, 2); }
     else { if (red_cols == 3) AB(float, 3); else AB(float, 2); }
@@ -617,7 +616,7 @@ extern "C" int dge_in_bwd(const void* gy, const void* x, const float* coef, cons
                           float* red, int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "in_bwd: unsupported channel count %d", C);
-    dim3 grid(sgrid(H * W, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(H * W, 256 / (C / ep), B), B);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(in_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, coef, (const bf16_t*)extra, noise, (bf16_t*)gout, red, H, W, C, extra_pool, extra_scale, act);
     else hipLaunchKernelGGL(in_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gy, (const float*)x, coef, (const float*)extra, noise, (float*)gout, red, H, W, C, extra_pool, extra_scale, act);
     DGE_LAUNCH_CHECK("in_bwd");
@@ -627,7 +626,7 @@ extern "C" int dge_in_bwd(const void* gy, const void* x, const float* coef, cons
 extern "C" int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "chan_sum: unsupported channel count %d", C);
-    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(HW, 256 / (C / ep), B), B);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(chan_sum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, out, HW, C, scale);
     else hipLaunchKernelGGL(chan_sum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, out, HW, C, scale);
     DGE_LAUNCH_CHECK("chan_sum");
@@ -637,7 +636,7 @@ extern "C" int dge_chan_sum(const void* x, float* out, int B, int HW, int C, flo
 extern "C" int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img, float* out4, int B, int HW, int C, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "fromrgb_bwd: unsupported channel count %d", C);
-    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(HW, 256 / (C / ep), B), B);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gx, (const bf16_t*)x0, img, out4, HW, C);
     else hipLaunchKernelGGL(fromrgb_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gx, (const float*)x0, img, out4, HW, C);
     DGE_LAUNCH_CHECK("fromrgb_bwd");
@@ -647,7 +646,7 @@ extern "C" int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img,
 extern "C" int dge_fromrgb_dgrad(const void* gx, const void* x0, const float* w, float* gimg, int B, int HW, int C, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "fromrgb_dgrad: unsupported channel count %d", C);
-    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(HW, 256 / (C / ep), B), B);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_dgrad_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gx, (const bf16_t*)x0, w, gimg, HW, C);
     else hipLaunchKernelGGL(fromrgb_dgrad_kernel<float>, grid, dim3(256), 0, s, (const float*)gx, (const float*)x0, w, gimg, HW, C);
     DGE_LAUNCH_CHECK("fromrgb_dgrad");

@@ -218,17 +218,13 @@ __global__ __launch_bounds__(256) void pixelnorm_nhwc_kernel(const T* __restrict
 }
 
 // =================================================================== C ABI
-static int grid_for(int hw, int ppi) {
-    int g = (hw + ppi - 1) / ppi;
-    return g > 256 ? 256 : (g < 1 ? 1 : g);      // see enc_bwd_kernels.hip: same-address atomics of the statistics flush
-}
 
 extern "C" int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, float* stats, int B, int HW,
                            int C, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "fromrgb: unsupported channel count %d", C);
     const int ppi = 256 / (C / ep);
-    dim3 grid(grid_for(HW, ppi), B);
+    dim3 grid(dge_stream_grid(HW, ppi, B), B);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_kernel<bf16_t>, grid, dim3(256), 0, s, img, w, bias, (bf16_t*)y, stats, HW, C);
     else hipLaunchKernelGGL(fromrgb_kernel<float>, grid, dim3(256), 0, s, img, w, bias, (float*)y, stats, HW, C);
     DGE_LAUNCH_CHECK("fromrgb");
@@ -248,7 +244,7 @@ extern "C" int dge_blend(const void* x, const void* z, void* y, const float* sc,
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "blend: unsupported channel count %d", C);
     const int ppi = 256 / (C / ep);
-    dim3 grid(grid_for(OH * OW, ppi), B);
+    dim3 grid(dge_stream_grid(OH * OW, ppi, B), B);
     if (dtype == DGE_BF16)
         hipLaunchKernelGGL(blend_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)z, (bf16_t*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta);
     else
@@ -262,7 +258,7 @@ extern "C" int dge_blur_noise_act(const void* x, const float* noise, const float
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "blur_noise_act: unsupported channel count %d", C);
     const int ppi = 256 / (C / ep);
-    dim3 grid(grid_for(H * W, ppi), B);
+    dim3 grid(dge_stream_grid(H * W, ppi, B), B);
     const int nbs = noise_batch > 1 ? H * W : 0;
     if (dtype == DGE_BF16)
         hipLaunchKernelGGL(blur_noise_act_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, noise, noise_w, bias, (bf16_t*)y, stats, H, W, C, do_blur, nbs, act);

@@ -146,13 +146,12 @@ __global__ void up2_bwd_kernel(const float* __restrict__ g, float* __restrict__ 
 }
 
 // =================================================================== C ABI
-static int sgrid(int hw, int ppi) { int g = (hw + ppi - 1) / ppi; return g > 256 ? 256 : (g < 1 ? 1 : g); }   // <= 256 workgroups per sample: each flushes one atomic per (channel, sum) and same-address f32 atomics retire at ~40 ns
 
 extern "C" int dge_modconv_bwd_prep(const void* gx, const void* x, const float* d, const float* noise, void* gy, float* R,
                                     int B, int HW, int C, int noise_batch, float gain, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "modconv_bwd_prep: unsupported channel count %d", C);
-    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(HW, 256 / (C / ep), B), B);
     const int nbs = noise_batch > 1 ? HW : 0;
     if (dtype == DGE_BF16)
         hipLaunchKernelGGL(modconv_bwd_prep_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gx, (const bf16_t*)x, d, noise, (bf16_t*)gy, R, HW, C, nbs, gain);
@@ -180,7 +179,7 @@ extern "C" int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb
                              int B, int HW, int C, float wscale, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "torgb_bwd: unsupported channel count %d", C);
-    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(HW, 256 / (C / ep), B), B);
     if (dtype == DGE_BF16)
         hipLaunchKernelGGL(torgb_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, gimg, (const bf16_t*)x, wrgb, style, (bf16_t*)gx, gs, HW, C, wscale);
     else

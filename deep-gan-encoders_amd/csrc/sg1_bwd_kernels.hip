@@ -6,10 +6,6 @@
 #include "common.h"
 #include "../../include/dge_hip.h"
 
-static inline int sgrid(int npix, int ppi) {
-    const int nb = (npix + ppi - 1) / ppi;
-    return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
-}
 #define CHAN_OK(C, ep) ((C) % (ep) == 0 && (C) / (ep) <= 256 && 256 % ((C) / (ep)) == 0)
 
 // u = style_mod(IN(y)) = (y*r + s)*(1+s0) + s1 with r = sc, s = sh = -mu*r, style = [s0 | s1].
@@ -115,7 +111,7 @@ extern "C" int dge_sg1_in_bwd_coef(const float* dots, const float* sc, const flo
 extern "C" int dge_dot_stats(const void* g, const void* x, float* stats, int B, int HW, int C, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "dot_stats: unsupported channel count %d", C);
-    dim3 grid(sgrid(HW, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(HW, 256 / (C / ep), B), B);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(dot_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, stats, HW, C);
     else hipLaunchKernelGGL(dot_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)g, (const float*)x, stats, HW, C);
     DGE_LAUNCH_CHECK("dot_stats");
@@ -127,7 +123,7 @@ extern "C" int dge_nearest_up2_bwd(const void* ghi, const void* x, void* glow, f
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "nearest_up2_bwd: unsupported channel count %d", C);
     DGE_CHECK(!stats || x, "nearest_up2_bwd: statistics need the low-resolution activation");
-    dim3 grid(sgrid(H * W, 256 / (C / ep)), B);
+    dim3 grid(dge_stream_grid(H * W, 256 / (C / ep), B), B);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(nearest_up2_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)ghi, (const bf16_t*)x, (bf16_t*)glow, stats, H, W, C);
     else hipLaunchKernelGGL(nearest_up2_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)ghi, (const float*)x, (float*)glow, stats, H, W, C);
     DGE_LAUNCH_CHECK("nearest_up2_bwd");
