@@ -15,7 +15,8 @@ __device__ __forceinline__ void block_atomic_sums(float* vals, int n, float* out
         if (lane == 0) red[i * 4 + wave] = s;
     }
     __syncthreads();
-    if (threadIdx.x < n) atomicAdd(out + threadIdx.x, red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
+    // 16 slot copies of the 8 sums: thousands of workgroups end here and same-address f32 atomics serialise (~40 ns each)
+    if (threadIdx.x < n) atomicAdd(out + (blockIdx.x & 15) * 8 + threadIdx.x, red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
 }
 
 // sums[0]=sum (a-b)^2, [1]=a.b, [2]=a.a, [3]=b.b, [4]=sum a, [5]=sum b, [6]=sum softmax_c(a)*(log softmax_c(a) - log softmax_c(b))
@@ -201,7 +202,7 @@ extern "C" int dge_loss_reduce(const float* a, const float* b, float* sums7, int
                                int h, int w, hipStream_t s) {
     DGE_CHECK(y0 >= 0 && x0 >= 0 && y0 + h <= H && x0 + w <= W && h > 0 && w > 0, "loss_reduce: bad crop");
     long npix = (long)B * h * w;
-    int grid = (int)((npix + 255) / 256); if (grid > 512) grid = 512;      // every workgroup ends with 8 same-address atomics
+    int grid = (int)((npix + 255) / 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, s, a, b, sums7, B, C, mk(H, W, y0, x0, h, w));
     DGE_LAUNCH_CHECK("loss_reduce");
     return 0;

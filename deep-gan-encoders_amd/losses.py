@@ -43,8 +43,9 @@ def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accum
     y0, x0, h, w = win
     dev = a.device
     L = lib()
-    sums = ops.zeros((8,), dev)
-    check(L.dge_loss_reduce(_f32(a), _f32(b), _p(sums), B, Cc, H, W, y0, x0, h, w, _stream()), "dge_loss_reduce")
+    slots = ops.zeros((16, 8), dev)         # 16 slot copies of the 8 sums (atomics contention), added up below
+    check(L.dge_loss_reduce(_f32(a), _f32(b), _p(slots), B, Cc, H, W, y0, x0, h, w, _stream()), "dge_loss_reduce")
+    sums = ops._sum_over_batch(slots)
     n = float(B * Cc * h * w)
     world = 1
     if gb is not None:

@@ -120,7 +120,8 @@ int dge_blend(const void* x, const void* z, void* y, const float* sc, const floa
               int OW, int C, int pool, float alpha, float beta, int dtype, dge_stream_t stream);
 
 /* ---- space_loss (training_utils.py:54-99) and SSIM (metric/pytorch_ssim.py:18-38) ---------- */
-/* One pass over a crop window of a,b [B,C,H,W] f32: sums7 (pre-zeroed) += { sum (a-b)^2, a.b, a.a, b.b, sum a, sum b,
+/* One pass over a crop window of a,b [B,C,H,W] f32: sums7 = [16][8] slot copies (pre-zeroed; the caller adds the 16 slots,
+ * e.g. dge_sum_slots, before dge_space_loss_finalize) += { sum (a-b)^2, a.b, a.a, b.b, sum a, sum b,
  * sum softmax_C(a)*(log softmax_C(a)-log softmax_C(b)) }  -> mse :63, mean/std terms :64-65, KL :67-71, cosine :73-75. */
 int dge_loss_reduce(const float* a, const float* b, float* sums7, int B, int C, int H, int W, int y0, int x0, int h, int w,
                     dge_stream_t stream);
