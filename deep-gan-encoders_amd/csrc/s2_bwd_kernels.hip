@@ -54,30 +54,34 @@ __global__ void demod_bwd_kernel(const float* __restrict__ R, const float* __res
 }
 
 // y[b*ldy + k*incy] (+)= scale * mul[b,k] * sum_o x[b*ldx + o*incx] * W[o,k]
-// block = 4 waves: lanes own 64 consecutive k (coalesced W rows), waves split the o range, LDS combine.
-__global__ __launch_bounds__(256) void linear_t_kernel(const float* __restrict__ x, int ldx, int incx, const float* __restrict__ W,
+// block = 16 waves: lanes own 64 consecutive k (coalesced W rows), waves split the o range, LDS combine.
+__global__ __launch_bounds__(1024) void linear_t_kernel(const float* __restrict__ x, int ldx, int incx, const float* __restrict__ W,
                                 const float* __restrict__ mul, float* __restrict__ y, int ldy, int incy, int B, int O, int K,
                                 float scale, int accumulate) {
-    __shared__ float part[4][64];
+    // The grid is small ((K/64) x B workgroups) and every wave walks its share of O serially: the loop is bound by load
+    // latency, so 16 waves split O and each keeps 8 independent loads in flight.
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + lane, b = blockIdx.y;
-    const int per = (O + 3) / 4, o0 = wave * per, o1 = min(O, o0 + per);
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int per = (O + 15) / 16, o0 = wave * per, o1 = min(O, o0 + per);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
     if (k < K) {
         const float* xr = x + (size_t)b * ldx;
         int o = o0;
-        for (; o + 3 < o1; o += 4) {
-            s0 += xr[(size_t)o * incx] * W[(size_t)o * K + k];
-            s1 += xr[(size_t)(o + 1) * incx] * W[(size_t)(o + 1) * K + k];
-            s2 += xr[(size_t)(o + 2) * incx] * W[(size_t)(o + 2) * K + k];
-            s3 += xr[(size_t)(o + 3) * incx] * W[(size_t)(o + 3) * K + k];
+        for (; o + 7 < o1; o += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += xr[(size_t)(o + j) * incx] * W[(size_t)(o + j) * K + k];
         }
-        for (; o < o1; o++) s0 += xr[(size_t)o * incx] * W[(size_t)o * K + k];
+        for (; o < o1; o++) acc[0] += xr[(size_t)o * incx] * W[(size_t)o * K + k];
     }
-    part[wave][lane] = (s0 + s1) + (s2 + s3);
+    part[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     __syncthreads();
     if (wave == 0 && k < K) {
-        float s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += part[j][lane];
         s *= scale;
         if (mul) s *= mul[(size_t)b * K + k];
         float* yp = y + (size_t)b * ldy + (size_t)k * incy;
@@ -170,7 +174,7 @@ extern "C" int dge_demod_bwd(const float* R, const float* d, const float* bias, 
 
 extern "C" int dge_linear_t(const float* x, int ldx, int incx, const float* w, const float* mul, float* y, int ldy, int incy,
                             int B, int O, int K, float scale, int accumulate, hipStream_t s) {
-    hipLaunchKernelGGL(linear_t_kernel, dim3((K + 63) / 64, B), dim3(256), 0, s, x, ldx, incx, w, mul, y, ldy, incy, B, O, K, scale, accumulate);
+    hipLaunchKernelGGL(linear_t_kernel, dim3((K + 63) / 64, B), dim3(1024), 0, s, x, ldx, incx, w, mul, y, ldy, incy, B, O, K, scale, accumulate);
     DGE_LAUNCH_CHECK("linear_t");
     return 0;
 }
