@@ -68,6 +68,8 @@ SIGNATURES = {
     "dge_blur_noise_act": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_affine_compose": [_P, _P, _P, _P, _P, _I, _I, _P],
     "dge_lerp_layers": [_P, _P, _I, _P, _P, _I, _I, _I, _P],
+    "dge_linear_rows": [_P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
+    "dge_demod_rows": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "dge_fromrgb_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dge_nearest_up2": [_P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dge_sg1_in_bwd_coef": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

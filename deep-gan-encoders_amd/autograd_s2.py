@@ -24,23 +24,85 @@ def _layer_fwd(L, x, w_row, randomize_noise):
     return y, s, d, noise
 
 
+def _style_tables(mod, B, dt):
+    """Row-concatenated style weights / demodulation tables of all 17 + 9 modulated blocks (cached; G is frozen in E_align)
+    so that every style vector and demodulation factor of a pass comes from two launches (dge_linear_rows, dge_demod_rows)."""
+    nl = mod.num_layers
+    groups = [(getattr(mod, f"layer{i}"), i) for i in range(nl - 1)] + [(getattr(mod, f"output{k}"), 2 * k + 1) for k in range(nl // 2)]
+    key = (B, str(dt)) + tuple((p._version, p.data_ptr()) for L, _ in groups for p in (L.style.weight, L.style.bias, L.weight))
+    hit = mod.__dict__.get("_style_tab")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    dev = groups[0][0].weight.device
+    K = mod.w_space_dim
+    Wc = torch.cat([L.style.weight.detach() for L, _ in groups]).contiguous()
+    bc = torch.cat([L.style.bias.detach() for L, _ in groups]).contiguous()
+    xoff, ybase, ybs, s_off = [], [], [], []
+    off = 0
+    for L, row in groups:
+        C = L.in_c
+        s_off.append(B * off)
+        xoff += [row * K] * C
+        ybase += [B * off + c for c in range(C)]
+        ybs += [C] * C
+        off += C
+    woff, sbase, cin, dbase, dbs, d_off, wsq = [], [], [], [], [], [], []
+    doff, wpos = 0, 0
+    for gi, (L, _) in enumerate(groups[:nl - 1]):
+        _, wq = L._prepared(dt)
+        wsq.append(wq.reshape(-1))
+        d_off.append(B * doff)
+        for o in range(L.out_c):
+            woff.append(wpos + o * L.in_c); sbase.append(s_off[gi]); cin.append(L.in_c)
+            dbase.append(B * doff + o); dbs.append(L.out_c)
+        doff += L.out_c
+        wpos += L.out_c * L.in_c
+    i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=dev)
+    st0 = groups[0][0].style
+    for L, _ in groups:
+        assert L.style.wscale == st0.wscale and L.style.bscale == st0.bscale and L.style.additional_bias == st0.additional_bias
+    tab = dict(groups=groups, Wc=Wc, bc=bc, xoff=i32(xoff), ybase=i32(ybase), ybs=i32(ybs), s_off=s_off, s_total=B * off,
+               wsq=torch.cat(wsq).contiguous(), woff=i32(woff), sbase=i32(sbase), cin=i32(cin), dbase=i32(dbase), dbs=i32(dbs),
+               d_off=d_off, d_total=B * doff, wscale=st0.wscale, bscale=st0.bscale, add=st0.additional_bias, eps=groups[0][0].eps)
+    mod.__dict__["_style_tab"] = (key, tab)
+    return tab
+
+
 def synthesis_run(mod, wp, randomize_noise=False, save=False):
     dt = _dt(mod.compute_dtype)
     B = wp.shape[0]
     results = {"wp": wp}
+    nl = mod.num_layers
+    # ---- all styles and demodulation factors of the pass: two launches instead of 2*17 + 9
+    tab = _style_tables(mod, B, dt)
+    wpc = wp if (wp.dtype == torch.float32 and wp.is_contiguous()) else wp.float().contiguous()
+    s_all = torch.empty(tab["s_total"], dtype=torch.float32, device=wp.device)
+    ops.linear_rows(wpc, nl * mod.w_space_dim, tab["xoff"], tab["Wc"], tab["bc"], s_all, tab["ybase"], tab["ybs"], B,
+                    tab["wscale"], tab["bscale"], tab["add"])
+    d_all = torch.empty(tab["d_total"], dtype=torch.float32, device=wp.device)
+    ops.demod_rows(s_all, tab["wsq"], tab["woff"], tab["sbase"], tab["cin"], d_all, tab["dbase"], tab["dbs"], B, tab["eps"])
+    s_of = lambda g, C: s_all[tab["s_off"][g]:tab["s_off"][g] + B * C].view(B, C)
     x = ops.nchw_to_nhwc(mod.early_layer.const.detach(), B, dt)
     saved = {"const": x, "layers": [], "rgb": []} if save else None
     image = None
-    for i in range(mod.num_layers - 1):
+    for i in range(nl - 1):
         L = getattr(mod, f"layer{i}")
-        y, s, d, noise = _layer_fwd(L, x, wp[:, i], randomize_noise)
+        s = s_of(i, L.in_c)
+        d = d_all[tab["d_off"][i]:tab["d_off"][i] + B * L.out_c].view(B, L.out_c)
+        packed, _ = L._prepared(dt)
+        if randomize_noise:
+            noise = torch.randn(x.shape[0], L.res, L.res, device=x.device)
+        else:
+            noise = L.noise.reshape(1, L.res, L.res)
+        y = ops.conv2d(x, packed, L.out_c, 3, up=L.up, in_scale=s, out_scale=d, bias=L.bias, bias_scale=L.bscale,
+                       noise=noise, noise_w=L.noise_strength.detach().reshape(1), act=L.act, gain=L.gain)
         results[f"style{i:02d}"] = s
         if save:
             saved["layers"].append(dict(y=y, s=s, d=d, noise=noise))
         x = y
         if i % 2 == 0:
             O_ = getattr(mod, f"output{i // 2}")
-            srgb = O_.style(wp[:, i + 1])
+            srgb = s_of(nl - 1 + i // 2, O_.in_c)
             image = ops.torgb(x, O_.weight, srgb, O_.bias, image, O_.wscale)
             results[f"output_style{i // 2}"] = srgb
             if save:

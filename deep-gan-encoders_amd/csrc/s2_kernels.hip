@@ -109,6 +109,42 @@ __global__ void linear_kernel(const float* __restrict__ x, int ldx, const float*
     }
 }
 
+// All style vectors of a synthesis pass in ONE launch (17 modulated convs + 9 toRGB at 1024^2 = 26 dense layers,
+// :858-864 / :990-996): row r of the concatenated weight matrix belongs to one layer and reads that layer's latent row
+// x[b, row_xoff[r] .. +K); results are written per layer as contiguous [B, C_layer] blocks (the conv prologue indexes
+// in_scale[b*Cin + c]):  y[row_ybase[r] + b*row_ybstride[r]] = wscale * <x_b, W_r> + bias[r]*bscale + add.
+__global__ void linear_rows_kernel(const float* __restrict__ x, int ldx_b, const int* __restrict__ row_xoff,
+                                   const float* __restrict__ W, const float* __restrict__ bias, float* __restrict__ y,
+                                   const int* __restrict__ row_ybase, const int* __restrict__ row_ybstride, int B, int R, int K,
+                                   float wscale, float bscale, float add) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * R) return;
+    const int b = wave / R, r = wave % R;
+    const float* xr = x + (size_t)b * ldx_b + row_xoff[r];
+    const float* wr = W + (size_t)r * K;
+    float s = 0.f;
+    for (int i = lane; i < K; i += 64) s += xr[i] * wr[i];
+    s = wave_sum(s);
+    if (lane == 0) y[(size_t)row_ybase[r] + (size_t)b * row_ybstride[r]] = s * wscale + bias[r] * bscale + add;
+}
+
+// All demodulation factors of a synthesis pass in one launch (:867-870): row r = output channel o of some layer,
+// d = rsqrt(sum_c s[b,c]^2 * wsq[o,c] + eps) with that layer's style block s (contiguous [B, cin]) and wsq row.
+__global__ void demod_rows_kernel(const float* __restrict__ s_all, const float* __restrict__ wsq_cat, const int* __restrict__ row_woff,
+                                  const int* __restrict__ row_sbase, const int* __restrict__ row_cin, float* __restrict__ d_all,
+                                  const int* __restrict__ row_dbase, const int* __restrict__ row_dbstride, int B, int R, float eps) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * R) return;
+    const int b = wave / R, r = wave % R;
+    const int cin = row_cin[r];
+    const float* sr = s_all + (size_t)row_sbase[r] + (size_t)b * cin;
+    const float* wr = wsq_cat + (size_t)row_woff[r];
+    float a = 0.f;
+    for (int i = lane; i < cin; i += 64) { const float v = sr[i]; a += v * v * wr[i]; }
+    a = wave_sum(a);
+    if (lane == 0) d_all[(size_t)row_dbase[r] + (size_t)b * row_dbstride[r]] = rsqrtf(a + eps);
+}
+
 // pixel norm over rows: y = x / sqrt(mean(x^2) + eps)   (:550-553)
 __global__ void pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D, float eps) {
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -219,6 +255,25 @@ extern "C" int dge_lerp_layers(const float* w, const float* avg, int avg_stride,
     const long n = (long)B * L * D;
     hipLaunchKernelGGL(lerp_layers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, avg, avg_stride, coefs, out, B, L, D);
     DGE_LAUNCH_CHECK("lerp_layers");
+    return 0;
+}
+
+extern "C" int dge_linear_rows(const float* x, int ldx_b, const int* row_xoff, const float* w, const float* bias, float* y,
+                               const int* row_ybase, const int* row_ybstride, int B, int R, int K, float wscale, float bscale,
+                               float add, hipStream_t s) {
+    const long waves = (long)B * R;
+    hipLaunchKernelGGL(linear_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, ldx_b, row_xoff, w, bias, y, row_ybase,
+                       row_ybstride, B, R, K, wscale, bscale, add);
+    DGE_LAUNCH_CHECK("linear_rows");
+    return 0;
+}
+
+extern "C" int dge_demod_rows(const float* s_all, const float* wsq_cat, const int* row_woff, const int* row_sbase, const int* row_cin,
+                              float* d_all, const int* row_dbase, const int* row_dbstride, int B, int R, float eps, hipStream_t s) {
+    const long waves = (long)B * R;
+    hipLaunchKernelGGL(demod_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, s_all, wsq_cat, row_woff, row_sbase, row_cin,
+                       d_all, row_dbase, row_dbstride, B, R, eps);
+    DGE_LAUNCH_CHECK("demod_rows");
     return 0;
 }
 

@@ -496,3 +496,17 @@ def nearest_up2(x, scale=1.0):
     y = torch.empty((B, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
     check(lib().dge_nearest_up2(_p(x), _p(y), B, H, W, Cc, float(scale), dtype_of(x), _stream()), "dge_nearest_up2")
     return y
+
+
+def linear_rows(x, ldx_b, row_xoff, w, bias, y, row_ybase, row_ybstride, B, wscale, bscale, add):
+    R, K = w.shape
+    check(lib().dge_linear_rows(_f32(x), int(ldx_b), _p(row_xoff), _f32(w), _f32(bias), _p(y), _p(row_ybase), _p(row_ybstride), B, R, K,
+                                float(wscale), float(bscale), float(add), _stream()), "dge_linear_rows")
+    return y
+
+
+def demod_rows(s_all, wsq_cat, row_woff, row_sbase, row_cin, d_all, row_dbase, row_dbstride, B, eps):
+    R = row_woff.numel()
+    check(lib().dge_demod_rows(_f32(s_all), _f32(wsq_cat), _p(row_woff), _p(row_sbase), _p(row_cin), _p(d_all), _p(row_dbase),
+                               _p(row_dbstride), B, R, float(eps), _stream()), "dge_demod_rows")
+    return d_all

@@ -81,6 +81,17 @@ int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumu
 /* Weight preparation (once per weight update).  w_oihw: [Cout][Cin][k][k] f32 as stored by the
  * reference (model/stylegan2_generator.py:814-819; model/utils/lreq.py:107-110).  `out` holds
  * k*k * dge_packed_n(N) * K elements of `dtype` (N,K per mode above). */
+/* Every style vector of a synthesis pass in one launch (the 17 + 9 `style` DenseBlocks of :825-829, 465-474): row r of the
+ * row-concatenated weights w [R,K] / bias [R] reads the latent row x[b*ldx_b + row_xoff[r] .. +K) and writes
+ * y[row_ybase[r] + b*row_ybstride[r]] = wscale*<x,w_r> + bias[r]*bscale + add, i.e. per-layer contiguous [B,C] blocks. */
+int dge_linear_rows(const float* x, int ldx_b, const int* row_xoff, const float* w, const float* bias, float* y,
+                    const int* row_ybase, const int* row_ybstride, int B, int R, int K, float wscale, float bscale, float add,
+                    dge_stream_t stream);
+/* Every demodulation factor of a synthesis pass in one launch (:867-870): row r = an output channel of some layer,
+ * d = rsqrt(sum_c s[b,c]^2 * wsq[c] + eps) over that layer's style block s_all[row_sbase[r] + b*cin ..) and its
+ * row wsq_cat[row_woff[r] ..) of dge_weight_sumsq values. */
+int dge_demod_rows(const float* s_all, const float* wsq_cat, const int* row_woff, const int* row_sbase, const int* row_cin,
+                   float* d_all, const int* row_dbase, const int* row_dbstride, int B, int R, float eps, dge_stream_t stream);
 int dge_packed_n(int n_valid);
 int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
                          float scale, dge_stream_t stream);
