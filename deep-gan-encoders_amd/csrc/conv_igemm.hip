@@ -126,7 +126,16 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps tile/DMA index math on the scalar unit
     const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so workgroup id i runs on
+    // XCD i % 8.  Give every XCD a CONTIGUOUS range of tiles: neighbouring tiles share halo rows and the same weight
+    // slice, which then hit in that XCD's L2 instead of being fetched once per XCD.
     int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, per = nb >> 3;
+        if (per > 0 && bid < (per << 3) && !(p.dbg & 32)) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int vbid = bid;             // tile id in (tx, ty, b, ntile) order: statistics slots are dealt by THIS id, so that the
+                                      // workgroups sharing a slot stay spread over the samples (same-address atomics)
     const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
     const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
     const int b = bid % p.B;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     //          products with dot_src, statistics of results that include the addend.
     // In DOT mode (data gradients) the per-channel scale is applied post, on the staged raw value.
     const bool post_stats = p.stats && (DOT || ADD);
-    float* __restrict__ STATS = p.stats ? p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * p.Cout * 2 : nullptr;
+    float* __restrict__ STATS = p.stats ? p.stats + (size_t)(vbid % p.stats_slots) * p.B * p.Cout * 2 : nullptr;
     // activation as max(v, slope*v) (slope in [0,1]); the gain (> 0, checked by the launcher) is folded
     // into scale / noise weight / bias because every supported activation is positively homogeneous
     const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
