@@ -40,6 +40,8 @@ def parse():
                     "host launch overhead that bounds small batches); off by default so that N=1 and N>1 run the same path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-synthesis", action="store_true", help="skip the synthesis-only timing (used by tools/pmc_traffic.sh so that "
+                    "the profiled conv launches are exactly those of the training steps)")
     ap.add_argument("--cpu-size", type=int, default=256, help="image size of the bounded CPU-oracle sample")
     return ap.parse_args()
 
@@ -132,21 +134,22 @@ def main():
 
     # ---- G-synthesis ms/img (second half of the BASELINE metric), eval-mode synthesis(wp)
     with torch.no_grad():
-        if a.mtype == 2:
-            wp = torch.randn(a.batch, G.num_layers, 512, device=dev)
-            synth = lambda: G.synthesis(wp)
-        else:
-            wp = torch.randn(a.batch, 2 * G.layer_count, 512, device=dev)
-            synth = lambda: G.forward(wp, G.layer_count - 1)
-        for _ in range(2):
-            synth()
-        sync()
-        t0 = time.time()
-        n = 10
-        for _ in range(n):
-            synth()
-        sync()
-        out["synthesis_ms_per_img"] = (time.time() - t0) / n / a.batch * 1e3
+      if not a.no_synthesis:
+            if a.mtype == 2:
+                wp = torch.randn(a.batch, G.num_layers, 512, device=dev)
+                synth = lambda: G.synthesis(wp)
+            else:
+                wp = torch.randn(a.batch, 2 * G.layer_count, 512, device=dev)
+                synth = lambda: G.forward(wp, G.layer_count - 1)
+            for _ in range(2):
+                synth()
+            sync()
+            t0 = time.time()
+            n = 10
+            for _ in range(n):
+                synth()
+            sync()
+            out["synthesis_ms_per_img"] = (time.time() - t0) / n / a.batch * 1e3
 
     # ---- roofline of the dominant kernel family (conv_igemm), instrumented extra pass
     if not a.no_roofline:

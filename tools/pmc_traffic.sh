@@ -5,7 +5,7 @@
 # trace domains.  FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md "HBM").
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-synthesis"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- $CMD > /tmp/pmc_$c.log 2>&1
@@ -33,7 +33,7 @@ fetch = 2.0 * tot["FETCH_SIZE"][1] * 1024 / nl        # KB -> bytes, x2 gfx950 c
 write = tot["WRITE_SIZE"][1] * 1024 / tot["WRITE_SIZE"][0]
 out = {"kernel": "conv_igemm_kernel<*>", "launches_profiled": nl, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
        "traffic_bytes_per_launch": fetch + write, "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as reported",
-       "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"}
+       "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-synthesis"}
 json.dump(out, open(f"{R}/gpurun_out/r01_conv_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 with open(f"{R}/gpurun_out/r01_pmc_traffic_by_kernel.txt", "w") as fo:
