@@ -76,6 +76,7 @@ SIGNATURES = {
     "dge_dot_stats": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dge_nearest_up2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dge_pixelnorm_nhwc": [_P, _P, C.c_long, _I, _F, _I, _P],
+    "dge_pixelnorm_nhwc_bwd": [_P, _P, _P, C.c_long, _I, _F, _I, _P],
     "dge_cbn_affine": [_P, _P, _I, _P, _P, _F, _P, _P, _I, _I, _P],
     "dge_slice_up": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -217,6 +217,42 @@ __global__ __launch_bounds__(256) void pixelnorm_nhwc_kernel(const T* __restrict
     }
 }
 
+// backward of the pixel norm: with r = rsqrt(mean_c x^2 + eps), yhat = x*r:  gx = r * (gy - yhat * mean_c(gy*yhat))
+template <typename T, int NJ>
+__global__ __launch_bounds__(256) void pixelnorm_nhwc_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, T* __restrict__ gx,
+                                                                  long npix, int C, int lpp, float eps) {
+    constexpr int EP = Elem<T>::PER16;
+    const int lane = threadIdx.x & 63;
+    const int ppw = 64 / lpp, sub = lane / lpp, li = lane % lpp;
+    const long p = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ppw + sub;
+    const bool ok = p < npix;
+    float f[NJ][EP], g[NJ][EP];
+    float s = 0.f, d = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        if (ok) {
+            unpack16(*(const uint4*)(x + (size_t)p * C + (j * lpp + li) * EP), f[j], (T*)nullptr);
+            unpack16(*(const uint4*)(gy + (size_t)p * C + (j * lpp + li) * EP), g[j], (T*)nullptr);
+        } else {
+#pragma unroll
+            for (int e = 0; e < EP; e++) { f[j][e] = 0.f; g[j][e] = 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < EP; e++) { s += f[j][e] * f[j][e]; d += f[j][e] * g[j][e]; }
+    }
+    for (int m = lpp >> 1; m > 0; m >>= 1) { s += __shfl_xor(s, m, 64); d += __shfl_xor(d, m, 64); }
+    const float r = rsqrtf(s / (float)C + eps);
+    const float k = d * r * r * r / (float)C;          // yhat * mean(gy*yhat) * r = x * (sum gy*x) * r^3 / C
+    if (ok) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+#pragma unroll
+            for (int e = 0; e < EP; e++) g[j][e] = g[j][e] * r - f[j][e] * k;
+            *(uint4*)(gx + (size_t)p * C + (j * lpp + li) * EP) = pack16(g[j], (T*)nullptr);
+        }
+    }
+}
+
 // =================================================================== C ABI
 
 extern "C" int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, float* stats, int B, int HW,
@@ -293,5 +329,28 @@ extern "C" int dge_pixelnorm_nhwc(const void* x, void* y, long npix, int C, floa
     const int rc = dtype == DGE_BF16 ? pixelnorm_nhwc_launch<bf16_t>(x, y, npix, C, eps, s) : pixelnorm_nhwc_launch<float>(x, y, npix, C, eps, s);
     if (rc) return rc;
     DGE_LAUNCH_CHECK("pixelnorm_nhwc");
+    return 0;
+}
+
+template <typename T>
+static int pixelnorm_nhwc_bwd_launch(const void* gy, const void* x, void* gx, long npix, int C, float eps, hipStream_t s) {
+    constexpr int EP = Elem<T>::PER16;
+    const int chunks = C / EP;
+    const int lpp = chunks >= 64 ? 64 : chunks;
+    const int nj = chunks / lpp;
+    const long ppb = 4 * (64 / lpp);
+    dim3 grid((unsigned)((npix + ppb - 1) / ppb));
+#define PNB(NJ) hipLaunchKernelGGL((pixelnorm_nhwc_bwd_kernel<T, NJ>), grid, dim3(256), 0, s, (const T*)gy, (const T*)x, (T*)gx, npix, C, lpp, eps)
+    if (nj == 1) PNB(1); else if (nj == 2) PNB(2); else { dge_set_error("pixelnorm_nhwc_bwd: unsupported C=%d", C); return -1; }
+#undef PNB
+    return 0;
+}
+extern "C" int dge_pixelnorm_nhwc_bwd(const void* gy, const void* x, void* gx, long npix, int C, float eps, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && ((C / ep) & (C / ep - 1)) == 0, "pixelnorm_nhwc_bwd: C=%d must be a power-of-two multiple of %d", C, ep);
+    const int rc = dtype == DGE_BF16 ? pixelnorm_nhwc_bwd_launch<bf16_t>(gy, x, gx, npix, C, eps, s)
+                                      : pixelnorm_nhwc_bwd_launch<float>(gy, x, gx, npix, C, eps, s);
+    if (rc) return rc;
+    DGE_LAUNCH_CHECK("pixelnorm_nhwc_bwd");
     return 0;
 }

@@ -510,3 +510,11 @@ def demod_rows(s_all, wsq_cat, row_woff, row_sbase, row_cin, d_all, row_dbase, r
     check(lib().dge_demod_rows(_f32(s_all), _f32(wsq_cat), _p(row_woff), _p(row_sbase), _p(row_cin), _p(d_all), _p(row_dbase),
                                _p(row_dbstride), B, R, float(eps), _stream()), "dge_demod_rows")
     return d_all
+
+
+def pixelnorm_nhwc_bwd(gy, x, eps=1e-8):
+    """x: [..., C] channel-last (NHWC activations, or [B,1,1,D] latent rows in f32)."""
+    Cc = x.shape[-1]
+    gx = torch.empty_like(x)
+    check(lib().dge_pixelnorm_nhwc_bwd(_p(gy), _p(x), _p(gx), x.numel() // Cc, Cc, float(eps), dtype_of(x), _stream()), "dge_pixelnorm_nhwc_bwd")
+    return gx

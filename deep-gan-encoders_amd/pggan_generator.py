@@ -31,6 +31,15 @@ class ConvBlock(nn.Module):
         self.act = ops.ACT_LRELU if activation_type == "lrelu" else ops.ACT_NONE
         self._cache = {}
 
+    def packed_dgrad(self, dtype):
+        w = self.weight
+        ver = (dtype, w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
+        hit = self._cache.get("wd")
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_conv_weight(w, ops.PACK_DGRAD, dtype, self.wscale))
+            self._cache["wd"] = hit
+        return hit[1]
+
     def packed(self, dtype):
         w = self.weight
         ver = (dtype, w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
@@ -88,22 +97,76 @@ class PGGANGenerator(nn.Module):
         lod = float(self.lod) if lod is None else lod
         if lod != 0:
             raise ValueError("only lod == 0 is implemented (the released generators are fully grown)")
+        image, zn = _PGGANFunction.apply(self, z)
+        return {"z": zn, "label": label, "image": image}
+
+    # ------------------------------------------------------------------ pipelines
+    def _run(self, z, save):
         dt = _dt(self.compute_dtype)
         B = z.shape[0]
-        with torch.no_grad():
-            zn = ops.pixelnorm(z.float().contiguous())
-            wd, bd = self._dense0_weight()
-            h = ops.linear(zn, wd, bd, wscale=self.layer0.wscale, act=ops.ACT_LRELU)           # [B, 16*C0] == NHWC [B,4,4,C0]
-            C0 = self.layer0.out_c
-            x = ops.nchw_to_nhwc(h.view(B, 16 * C0, 1, 1), B, dt).view(B, 4, 4, C0)
-            nblk = self.final_res_log2 - self.init_res_log2 + 1
-            for k in range(nblk):
-                if k > 0:
-                    L = getattr(self, f"layer{2 * k}")
-                    x = ops.conv2d(ops.pixelnorm_nhwc(x), L.packed(dt), L.out_c, 3, bias=L.bias.detach(), act=L.act, in_up2=True)
-                L = getattr(self, f"layer{2 * k + 1}")
-                x = ops.conv2d(ops.pixelnorm_nhwc(x), L.packed(dt), L.out_c, 3, bias=L.bias.detach(), act=L.act)
-            O_ = getattr(self, f"output{nblk - 1}")
-            ones = torch.ones((B, x.shape[3]), dtype=torch.float32, device=x.device)
-            image = ops.torgb(ops.pixelnorm_nhwc(x), O_.weight.detach().reshape(3, -1), ones, O_.bias.detach(), None, O_.wscale)
-        return {"z": zn, "label": label, "image": image}
+        zf = z.float().contiguous()
+        zn = ops.pixelnorm(zf)
+        wd, bd = self._dense0_weight()
+        h = ops.linear(zn, wd, bd, wscale=self.layer0.wscale, act=ops.ACT_LRELU)           # [B, 16*C0] == NHWC [B,4,4,C0]
+        C0 = self.layer0.out_c
+        x = ops.nchw_to_nhwc(h.view(B, 16 * C0, 1, 1), B, dt).view(B, 4, 4, C0)
+        saved = dict(z=zf, h=h, convs=[]) if save else None
+        nblk = self.final_res_log2 - self.init_res_log2 + 1
+        for k in range(nblk):
+            if k > 0:
+                L = getattr(self, f"layer{2 * k}")
+                y = ops.conv2d(ops.pixelnorm_nhwc(x), L.packed(dt), L.out_c, 3, bias=L.bias.detach(), act=L.act, in_up2=True)
+                if save:
+                    saved["convs"].append((L, x, y, True))
+                x = y
+            L = getattr(self, f"layer{2 * k + 1}")
+            y = ops.conv2d(ops.pixelnorm_nhwc(x), L.packed(dt), L.out_c, 3, bias=L.bias.detach(), act=L.act)
+            if save:
+                saved["convs"].append((L, x, y, False))
+            x = y
+        O_ = getattr(self, f"output{nblk - 1}")
+        ones = torch.ones((B, x.shape[3]), dtype=torch.float32, device=x.device)
+        xn = ops.pixelnorm_nhwc(x)
+        image = ops.torgb(xn, O_.weight.detach().reshape(3, -1), ones, O_.bias.detach(), None, O_.wscale)
+        if save:
+            saved.update(x_last=x, xn_last=xn, out=O_)
+        return image, zn, saved
+
+    def _backward(self, saved, g_image):
+        """d(image)/d(z) contracted with g_image (hand-written data gradient; the generator's parameters are frozen in E_align)."""
+        dt = ops.dtype_of(saved["x_last"])
+        B = g_image.shape[0]
+        O_ = saved["out"]
+        ones = torch.ones((B, saved["x_last"].shape[3]), dtype=torch.float32, device=g_image.device)
+        g_xn, _ = ops.torgb_bwd(g_image.float().contiguous(), saved["xn_last"], O_.weight.detach().reshape(3, -1), ones, O_.wscale)
+        g = ops.pixelnorm_nhwc_bwd(g_xn, saved["x_last"])
+        for L, x_in, y, up in reversed(saved["convs"]):
+            g_pre = ops.act_bwd(g, y, None, pool=False, scale=1.0) if L.act == ops.ACT_LRELU else g
+            g_xn = ops.conv2d(g_pre, L.packed_dgrad(dt), L.in_c, 3)
+            if up:
+                g_xn, _ = ops.nearest_up2_bwd(g_xn)
+            g = ops.pixelnorm_nhwc_bwd(g_xn, x_in)
+        # layer0: h = lrelu(wscale * zn @ wd^T + bd) viewed as NHWC [B,4,4,C0]
+        C0 = self.layer0.out_c
+        g_h = ops.nhwc_to_nchw(g.view(B, 1, 1, 16 * C0)).view(B, 4, 4, C0)          # f32, same (y, x, c) order as h
+        g_hpre = ops.act_bwd(g_h, saved["h"].view(B, 4, 4, C0), None, pool=False, scale=1.0).view(B, 16 * C0)
+        wd, _ = self._dense0_weight()
+        g_zn = torch.empty((B, self.z_space_dim), dtype=torch.float32, device=g_image.device)
+        ops.linear_t(g_hpre, wd, g_zn, scale=self.layer0.wscale)
+        return ops.pixelnorm_nhwc_bwd(g_zn.view(B, 1, 1, -1), saved["z"].view(B, 1, 1, -1)).view(B, -1)
+
+
+class _PGGANFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, G, z):
+        need = ctx.needs_input_grad[1]
+        image, zn, saved = G._run(z.detach(), save=need)
+        ctx.G, ctx.saved_acts = G, saved
+        ctx.mark_non_differentiable(zn)
+        return image, zn
+
+    @staticmethod
+    def backward(ctx, g_image, _g_zn):
+        if ctx.saved_acts is None:
+            raise RuntimeError("PGGAN forward ran without saved activations")
+        return None, ctx.G._backward(ctx.saved_acts, g_image)

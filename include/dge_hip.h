@@ -252,6 +252,8 @@ int dge_nearest_up2_bwd(const void* ghi, const void* x, void* glow, float* stats
 /* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */
 /* pixel-wise feature normalisation over the channel axis of an NHWC tensor (PixelNormLayer :207-216) */
 int dge_pixelnorm_nhwc(const void* x, void* y, long npix, int C, float eps, int dtype, dge_stream_t stream);
+/* backward of dge_pixelnorm_nhwc: gx = r*(gy - yhat*mean_c(gy*yhat)), r = rsqrt(mean_c x^2 + eps), yhat = x*r */
+int dge_pixelnorm_nhwc_bwd(const void* gy, const void* x, void* gx, long npix, int C, float eps, int dtype, dge_stream_t stream);
 
 /* ---- BigGAN-deep (model/biggan_generator.py) ----------------------------------------------- */
 /* BigGANBatchNorm :127-150 as a per-(b,c) affine: a = (1 + scale[b,c]) / sqrt(var[c]+eps), b = offset[b,c] - mean[c]*a

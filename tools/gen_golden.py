@@ -760,6 +760,25 @@ def gen_embed():
 
 SECTIONS["embed"] = gen_embed
 
+def gen_pggangrad():
+    """Gradient of a seeded linear functional of the PGGAN image w.r.t. z (same generator / z as pggan_small.npz)."""
+    import contextlib, io
+    from model.pggan.pggan_generator import PGGANGenerator
+    G = PGGANGenerator(32, fmaps_base=1024, fmaps_max=64)
+    sd = {k: (R.randn("pg." + k, tuple(v.shape), 51, 0.2 if k.endswith("bias") else 1.0) if v.ndim else v.clone())
+          for k, v in G.state_dict().items()}
+    G.load_state_dict(sd)
+    z = R.randn("pg.z", (2, 512), 51).requires_grad_(True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        img = G(z)["image"]
+    gimg = R.randn("pg.gimg", tuple(img.shape), 52)
+    loss = (img * gimg).sum()
+    loss.backward()
+    save_npz("pggan_grad.npz", g_z=z.grad, loss=loss.detach())
+
+
+SECTIONS["pggangrad"] = gen_pggangrad
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
