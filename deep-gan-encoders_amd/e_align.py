@@ -61,13 +61,34 @@ class _StyleGAN1Adapter:
         return self.G.forward(w, self.lod, noises=noises)
 
 
+class _PGGANAdapter:
+    """mtype 3: w1 = z; imgs1 = generator(w1)['image'] (E_align_s2.py:134-138).  The script's second pass calls
+    `generator.synthesis(w2)` (:160), which PGGANGenerator does not have; the evident intent
+    `generator(w2)['image']` is what runs here."""
+
+    def __init__(self, generator):
+        self.G = generator
+
+    def sample(self, z, noises=None):
+        return self.G(z)["image"], z
+
+    def synth(self, w, noises=None):
+        return self.G(w)["image"]
+
+
 class EAlignStep:
     def __init__(self, generator, E, lpips_model, lr=0.0015, beta_1=0.0, batch_size=2, z_dim=512,
                  reference_noise=False, exact_ddp=True, mapping=None):
-        """`generator`: StyleGAN2Generator (mtype 2), or the StyleGAN1 synthesis network Gs together with
-        `mapping` = Gm (mtype 1)."""
+        """`generator`: StyleGAN2Generator (mtype 2), the StyleGAN1 synthesis network Gs together with
+        `mapping` = Gm (mtype 1), or a PGGANGenerator (mtype 3)."""
+        from .pggan_generator import PGGANGenerator
         self.G, self.E, self.lpips = generator, E, lpips_model
-        self.gen = _StyleGAN1Adapter(generator, mapping) if mapping is not None else _StyleGAN2Adapter(generator)
+        if mapping is not None:
+            self.gen = _StyleGAN1Adapter(generator, mapping)
+        elif isinstance(generator, PGGANGenerator):
+            self.gen = _PGGANAdapter(generator)
+        else:
+            self.gen = _StyleGAN2Adapter(generator)
         self.opt = LREQAdam([{"params": E.parameters()}], lr=lr, betas=(beta_1, 0.99), weight_decay=0)
         self.batch_size, self.z_dim = batch_size, z_dim
         self.reference_noise = reference_noise      # True: CPU-generated noise in the reference's order (Q6)
@@ -230,6 +251,20 @@ def build_models_sg1(img_size=256, start_features=64, compute_dtype="bf16", devi
     return Gs, Gm, E, LP
 
 
+def build_models_pg(img_size=256, start_features=64, compute_dtype="bf16", device="cuda", lpips=True, seed=0):
+    """Models of BASELINE config 1 (PGGAN, E_align_s2.py:67-77) with seeded random-init weights."""
+    from .pggan_generator import PGGANGenerator
+    from .encoder_variants import PGBE
+    from .lpips import LPIPS
+    torch.manual_seed(seed)
+    G = PGGANGenerator(resolution=img_size, compute_dtype=compute_dtype).to(device)
+    for p in G.parameters():
+        p.requires_grad_(False)
+    E = PGBE(startf=start_features, maxf=512, layer_count=int(math.log2(img_size) - 1), pggan=True, compute_dtype=compute_dtype).to(device)
+    LP = LPIPS(compute_dtype=compute_dtype).to(device) if lpips else None
+    return G, E, LP
+
+
 def train(tensor_writer=None, args=None):
     """Reference E_align_s2.train() for --mtype 2 (flags: E_align_s2.py:304-318)."""
     cd = getattr(args, "compute_dtype", "bf16")
@@ -245,9 +280,15 @@ def train(tensor_writer=None, args=None):
             G.load_state_dict(torch.load(args.checkpoint_dir_GAN + "Gs_dict.pth", map_location="cpu"))
             Gm.load_state_dict(torch.load(args.checkpoint_dir_GAN + "Gm_dict.pth", map_location="cpu"))
             Gm.buffer1 = torch.load(args.checkpoint_dir_GAN + "./center_tensor.pt", map_location="cpu")
+    elif args.mtype == 3:
+        G, E, LP = build_models_pg(args.img_size, args.start_features, cd)
+        Gm = None
+        if args.checkpoint_dir_GAN:
+            ckpt = torch.load(args.checkpoint_dir_GAN, map_location="cpu")
+            G.load_state_dict(ckpt["generator_smooth"] if "generator_smooth" in ckpt else ckpt["generator"])
     else:
-        raise NotImplementedError("--mtype 1 (StyleGAN1) and 2 (StyleGAN2) are wired into the training loop; "
-                                  "PGGAN/BigGAN generators are forward-only in this build")
+        raise NotImplementedError("--mtype 1 (StyleGAN1), 2 (StyleGAN2) and 3 (PGGAN) are wired into the training loop; "
+                                  "the BigGAN generator / E_BIG encoder are forward-only in this build")
     if args.checkpoint_dir_E is not None:
         E.load_state_dict(torch.load(args.checkpoint_dir_E, map_location="cpu"))
     st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm)

@@ -5,7 +5,7 @@
   (model/utils/lreq.py:145-147).  That 4x4 stride-2 kernel 0.25*sum-of-4-shifts is algebraically
   conv3x3 followed by avg_pool2d(2) (zero padding included), so it runs as conv3x3 + the pooling
   blend; noise / bias / leaky_relu are then applied at the HALF resolution, as in the reference.
-* `E_PG.BE`    (model/E/E_PG.py:39-164, PGGAN encoder): IN -> conv -> noise -> bias -> lrelu -> IN ->
+* `E_PG.BE`    (model/E/E_PG.py:39-164, PGGAN encoder; forward + backward in autograd_encpg.py): IN -> conv -> noise -> bias -> lrelu -> IN ->
   conv -> noise -> bias -> (+ affine-IN(conv1x1(residual))) -> lrelu -> avgpool; FC head.
   The reference returns (tensor(0), tensor(0)); the evident intent is implemented:
   `(tensor(0), new_final(x.view(B, -1)))`, and `trunk()` exposes the activation before the head.
@@ -111,53 +111,18 @@ class PGBE(nn.Module):
     @torch.no_grad()
     def trunk(self, img, noises=None):
         """Activation [B,C,4,4] (NCHW f32) after the last block - what the reference computes and then discards."""
-        dt = _dt(self.compute_dtype)
-        dev = img.device
-        B, _, R, _ = img.shape
-        if noises is None:
-            noises = draw_noises(self, B, R, dev)
-        cache = self.__dict__.setdefault("_pack_cache", {})
-        zeros = lambda c: torch.zeros((B, c, 2), dtype=torch.float32, device=dev)
-        fr = self.FromRGB.from_rgb
-        stats = zeros(self.startf)
-        x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats)
-        ni = 0
-        for j, blk in enumerate(self.decode_block):
-            Cc, C2, H = blk.inputs, blk.outputs, R >> j
-            _, sc1, sh1 = ops.stats_finalize(stats, H * H)
-            st1 = zeros(Cc)
-            x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1,
-                            noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_1.detach().reshape(-1),
-                            bias=blk.bias_1.detach().reshape(-1), act=ops.ACT_LRELU, stats=st1)
-            ni += 1
-            if not blk.has_second_conv:
-                x = x1
-                break
-            _, sc2, sh2 = ops.stats_finalize(st1, H * H)
-            pre2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=sc2, in_shift=sh2,
-                              noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_2.detach().reshape(-1),
-                              bias=blk.bias_2.detach().reshape(-1))
-            ni += 1
-            if Cc != C2:
-                st3 = zeros(C2)
-                r3 = ops.conv2d(x, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(), stats=st3)
-                _, sc3, sh3 = ops.stats_finalize(st3, H * H)
-                g, bta = blk.instance_norm_3.weight.detach(), blk.instance_norm_3.bias.detach()
-                s = ops.blend(r3, z=pre2, sc=(sc3 * g).contiguous(), sh=(sh3 * g + bta).contiguous(), alpha=1.0, beta=1.0)
-            else:
-                s = ops.blend(x, z=pre2, alpha=1.0, beta=1.0)
-            nstats = zeros(C2)
-            x = ops.blend(ops.blur_noise_act(s, None, None, None, blur=False), pool=True, stats=nstats)     # lrelu, then avg_pool2d
-            stats = nstats
-        return ops.nhwc_to_nchw(x)
+        from .autograd_encpg import pg_encoder_forward
+        return pg_encoder_forward(self, img, noises, save=False)[0]
 
-    @torch.no_grad()
     def forward(self, img, block_num=9, noises=None):
-        x = self.trunk(img, noises)
+        """-> (tensor(0), z): z = new_final(trunk) is differentiable w.r.t. every parameter (autograd_encpg)."""
+        if block_num != 9:
+            raise ValueError("progressive block_num != 9 is not used by the reference's scripts")
         if not self.pggan:
+            self.trunk(img, noises)
             return torch.tensor(0), torch.tensor(0)
-        z = ops.linear(x.reshape(x.shape[0], -1).contiguous(), self.new_final.weight.detach(), self.new_final.bias.detach())
-        return torch.tensor(0), z
+        from .autograd_encpg import PGEncoderFunction
+        return torch.tensor(0), PGEncoderFunction.apply(self, img, noises, *list(self.parameters()))
 
 
 # ----------------------------------------------------------------------------------- E_BIG

@@ -154,6 +154,12 @@ def space_loss(imgs1, imgs2, image_space=True, lpips_model=None, global_batch=No
         # 3-D latents: the implicit softmax dim is 0 (the batch) -> planes = batch (training_utils.py:67)
         Bt = a.shape[0]
         n_in = a.numel() // Bt
+        if a.dim() == 2:
+            # 2-D latents (PGGAN / BigGAN z): the implicit softmax dim is 1 -> one softmax per sample over the features
+            out8 = _space_loss_window(a.view(Bt, n_in, 1, 1), b.view(Bt, n_in, 1, 1), (0, 0, 1, 1), False, None, 1.0,
+                                      g.view(Bt, n_in, 1, 1) if need else None, accumulate=False, gb=global_batch)
+            loss = out8[0]
+            return (_ScaledGrad.apply(imgs2, loss, g) if need else loss), out8
         out8 = _space_loss_window(a.view(1, Bt, 1, n_in), b.view(1, Bt, 1, n_in), (0, 0, 1, n_in), False, None, 1.0,
                                   g.view(1, Bt, 1, n_in) if need else None, accumulate=False, gb=global_batch)
         if imgs1.requires_grad and torch.is_grad_enabled():

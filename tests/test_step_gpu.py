@@ -195,3 +195,62 @@ def test_graph_replay_of_the_training_step_runs():
     assert float((E.decode_block[0].conv_1.weight.detach() - p0).abs().max()) > 0
     assert float((G.truncation.w_avg - wavg0).abs().max()) > 0
     assert len(set(losses)) == 3            # a new z every replay
+
+
+def test_two_phase_step_pggan_matches_reference_run():
+    """--mtype 3 (PGGAN generator + E_PG encoder, BASELINE config 1) in the evident-intent form of SURVEY Q5, against two
+    iterations run with the reference's own modules (tests/golden/step_pg.npz): images, latents, losses and encoder
+    parameters after both optimiser phases.  Exercises the PGGAN data gradient and the complete E_PG backward."""
+    from dge_amd.pggan_generator import PGGANGenerator
+    from dge_amd.encoder_variants import PGBE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.e_align import EAlignStep
+    g = golden("step_pg.npz")
+    G = PGGANGenerator(64, fmaps_base=1024, fmaps_max=64, compute_dtype="f32").cuda()
+    G.load_state_dict({k: (R.randn("pgstep." + k, tuple(v.shape), 51, 0.2 if k.endswith("bias") else 1.0) if v.ndim else v.clone())
+                       for k, v in G.state_dict().items()})
+    for p in G.parameters():
+        p.requires_grad_(False)
+    E = PGBE(startf=32, maxf=512, layer_count=5, pggan=True, compute_dtype="f32").cuda()
+
+    def e_params():
+        sd = R.fill_encoder({k: list(v.shape) for k, v in E.state_dict().items()}, seed=62)
+        for k in sd:
+            if "instance_norm_3.weight" in k:
+                sd[k] = R.randn("pg." + k, tuple(sd[k].shape), 62, 0.2, 1.0)
+        return sd
+    E.load_state_dict(e_params())
+    LP = LPIPS(compute_dtype="f32").cuda()
+    LP.load_state_dict(LR.seeded_params(0))
+    st = EAlignStep(G, E, LP, lr=0.0015, batch_size=2)
+    nshapes = [tuple(s) for s in g["noise_shapes"].tolist()]
+    assert len(nshapes) == 9
+    for it in range(2):
+        z = R.randn(f"pgstep.z{it}", (2, 512), 1)
+        nz = [R.randn(f"pgstep.it{it}.noise{i}", s, 1).cuda() for i, s in enumerate(nshapes)]
+        r = st.step(it, z=z, noises=nz)
+        assert float(r["const2"]) == 0
+        assert relerr(r["imgs1"], g[f"it{it}_imgs1"]) < 5e-4
+        assert relerr(r["w2"], g[f"it{it}_w2"]) < 2e-3
+        assert relerr(r["imgs2"], g[f"it{it}_imgs2"]) < 3e-3
+        ref_l = g[f"it{it}_losses"]
+        info = r["info_img"].cpu().numpy()
+        got = [float(r["loss_tsa"]), info[0, 0], info[1, 0], info[2, 0], float(r["loss_w"])]
+        for a, b in zip(got, ref_l):
+            assert abs(a - b) < 3e-3 * abs(b), (it, got, ref_l)
+        # logged-only terms of the latent loss (2-D latents: softmax over dim 1): mse, mse(mean), mse(std), kl, cosine
+        iw = r["info_w"].cpu().numpy()
+        ref_w = g[f"it{it}_info"][3]
+        assert abs(iw[1] - ref_w[0]) < 3e-3 * abs(ref_w[0]) and abs(iw[4] - ref_w[3]) < 2e-2 * abs(ref_w[3]) + 1e-6, (iw, ref_w)
+        sd_e = E.state_dict()
+        for key in g.files:
+            if key.startswith(f"it{it}_after_phase2:"):
+                k = key.split(":", 1)[1]
+                assert relerr(sd_e[k], g[key]) < 2e-3, (it, k, relerr(sd_e[k], g[key]))
+                if it == 0:
+                    before = e_params()[k]
+                    du_ref = torch.as_tensor(g[key]) - before
+                    du = sd_e[k].cpu() - before
+                    if du_ref.abs().max() > 0:
+                        assert ((du - du_ref).norm() / du_ref.norm()).item() < 0.08, (it, k)
+        assert abs(R.checksum({k: v.cpu() for k, v in sd_e.items()}) - float(g[f"it{it}_param_checksum"])) < 1e-5 * float(g[f"it{it}_param_checksum"])

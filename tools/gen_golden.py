@@ -779,6 +779,110 @@ def gen_pggangrad():
 
 SECTIONS["pggangrad"] = gen_pggangrad
 
+def gen_encpggrad():
+    """Gradients of the reference E_PG.BE w.r.t. every parameter for a seeded linear functional of the head output
+    new_final(x.view(B,-1)) -- the value the reference computes and then discards; it is taken live (with its
+    autograd graph) from a forward hook on the reference's own module.  Same model / input / noise as encpg_small.npz."""
+    import model.E.E_PG as EP
+    E = EP.BE(startf=32, maxf=512, layer_count=5, pggan=True)
+    sd = R.fill_encoder(shapes_of(E.state_dict()), seed=62)
+    for k in sd:
+        if "instance_norm_3.weight" in k:
+            sd[k] = R.randn("pg." + k, tuple(sd[k].shape), 62, 0.2, 1.0)
+    E.load_state_dict(sd)
+    img = R.randn("ep.img", (2, 3, 64, 64), 62, 0.5)
+    feats = {}
+    h = E.new_final.register_forward_hook(lambda m_, i, o: feats.__setitem__("head", o))
+    with _NoiseFeeder("ep", 62):
+        E(img)
+    h.remove()
+    z = feats["head"]
+    loss = (z * R.randn("ep.gz", tuple(z.shape), 64)).sum()
+    loss.backward()
+    out = {"loss": loss.detach()}
+    for k, p_ in E.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad
+        out["norm:" + k] = g.norm()
+        out["grad:" + k] = g if g.numel() <= 40000 else g.flatten()[:4096]
+    save_npz("encpg_grad.npz", **out)
+
+
+SECTIONS["encpggrad"] = gen_encpggrad
+
+def gen_step_pg():
+    """Two E_align_s2 iterations for --mtype 3 (PGGAN) with the reference's own modules, in the evident-intent form of
+    SURVEY Q5 (the script as shipped crashes: E_PG returns (0, 0) and PGGANGenerator has no .synthesis): w2 = the live
+    output of the reference's `new_final` (forward hook), imgs2 = generator(w2)['image'] (E_align_s2.py:134-138,153,160).
+    Reduced size: PGGAN res 64, E_PG 5 blocks."""
+    import contextlib, io, warnings
+    from model.pggan.pggan_generator import PGGANGenerator
+    import model.E.E_PG as EP
+    import training_utils as TU
+    from model.utils.custom_adam import LREQAdam
+    from oracle import lpips_ref as LR
+
+    G = PGGANGenerator(64, fmaps_base=1024, fmaps_max=64)
+    G.load_state_dict({k: (R.randn("pgstep." + k, tuple(v.shape), 51, 0.2 if k.endswith("bias") else 1.0) if v.ndim else v.clone())
+                       for k, v in G.state_dict().items()})
+    E = EP.BE(startf=32, maxf=512, layer_count=5, pggan=True)
+    sd = R.fill_encoder(shapes_of(E.state_dict()), seed=62)
+    for k in sd:
+        if "instance_norm_3.weight" in k:
+            sd[k] = R.randn("pg." + k, tuple(sd[k].shape), 62, 0.2, 1.0)
+    E.load_state_dict(sd)
+    feats = {}
+    E.new_final.register_forward_hook(lambda m_, i, o: feats.__setitem__("head", o))
+    LP = LR.seeded_params(0)
+    lp = lambda a, b: LR.lpips(LP, a, b)
+    opt = LREQAdam([{"params": E.parameters()}], lr=0.0015, betas=(0.0, 0.99), weight_decay=0)
+    out = {}
+    B = 2
+    for it in range(2):
+        z = R.randn(f"pgstep.z{it}", (B, 512), 1)
+        with _NoiseFeeder(f"pgstep.it{it}", 1) as nf, contextlib.redirect_stdout(io.StringIO()):
+            with torch.no_grad():
+                w1 = z
+                imgs1 = G(w1)["image"]
+            E(imgs1)
+            w2 = feats["head"]
+            imgs2 = G(w2)["image"]
+        if it == 0:
+            out["noise_shapes"] = np.array([list(s_) for s_ in nf.log])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            l_i, i_i = TU.space_loss(imgs1, imgs2, lpips_model=lp)
+            m1 = imgs1[:, :, :, imgs1.shape[3] // 8:-imgs1.shape[3] // 8]
+            m2 = imgs2[:, :, :, imgs2.shape[3] // 8:-imgs2.shape[3] // 8]
+            l_m, i_m = TU.space_loss(m1, m2, lpips_model=lp)
+            o = imgs1.shape[2] // 8 + imgs1.shape[2] // 32
+            s1, s2 = imgs1[:, :, o:-o, o:-o], imgs2[:, :, o:-o, o:-o]
+            l_s, i_s = TU.space_loss(s1, s2, lpips_model=lp)
+            loss_tsa = l_i + l_m * 5 + l_s * 9
+            opt.zero_grad()
+            loss_tsa.backward(retain_graph=True)
+            opt.step()
+            l_w, i_w = TU.space_loss(w1, w2, image_space=False)
+            loss_mtv = l_w * 0.01
+            opt.zero_grad()
+            loss_mtv.backward()
+            opt.step()
+        flat = lambda inf: [inf[0][0], inf[0][1], inf[0][2], inf[1], inf[2], inf[3], inf[4]]
+        out[f"it{it}_imgs1"] = imgs1
+        out[f"it{it}_w2"] = w2.detach()
+        out[f"it{it}_imgs2"] = imgs2.detach()
+        out[f"it{it}_losses"] = np.array([float(loss_tsa), float(l_i), float(l_m), float(l_s), float(l_w)])
+        out[f"it{it}_info"] = np.array([flat(i_i), flat(i_m), flat(i_s), flat(i_w)])
+        out[f"it{it}_param_checksum"] = np.array(R.checksum(E.state_dict()))
+        for k in ("decode_block.0.conv_1.weight", "decode_block.2.conv_2.weight", "decode_block.1.conv_3.weight",
+                  "decode_block.1.instance_norm_3.weight", "decode_block.1.bias_1", "FromRGB.from_rgb.weight", "new_final.bias"):
+            out[f"it{it}_after_phase2:{k}"] = E.state_dict()[k].clone()
+    save_npz("step_pg.npz", **out)
+
+
+SECTIONS["step_pg"] = gen_step_pg
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
