@@ -77,6 +77,11 @@ SIGNATURES = {
     "dge_nearest_up2_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dge_pixelnorm_nhwc": [_P, _P, C.c_long, _I, _F, _I, _P],
     "dge_pixelnorm_nhwc_bwd": [_P, _P, _P, C.c_long, _I, _F, _I, _P],
+    "dge_affine_relu_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dge_slice_up_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dge_softmax_rows": [_P, C.c_long, _I, _I, _P],
+    "dge_softmax_rows_bwd": [_P, _P, C.c_long, _I, _I, _P],
+    "dge_rgb_tanh_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dge_cbn_affine": [_P, _P, _I, _P, _P, _F, _P, _P, _I, _I, _P],
     "dge_slice_up": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -92,7 +92,8 @@ class BigGANBatchNorm(nn.Module):
             self.weight = nn.Parameter(torch.ones(num_features))
             self.bias = nn.Parameter(torch.zeros(num_features))
 
-    def affine(self, truncation, cond, training):
+    def affine(self, truncation, cond, training, ctx=None):
+        """-> per-(b,c) affine (a, b).  `ctx` (a dict) receives what the backward w.r.t. the condition vector needs."""
         coef, start_idx = math.modf(truncation / self.step_size)
         start_idx = int(start_idx)
         if coef != 0.0:
@@ -101,12 +102,24 @@ class BigGANBatchNorm(nn.Module):
         else:
             mean, var = self.running_means[start_idx], self.running_vars[start_idx]
         if self.conditional:
-            sc = ops.linear(cond, self.scale.effective_weight(training).contiguous())
-            of = ops.linear(cond, self.offset.effective_weight(training).contiguous())
+            wsc, wof = self.scale.effective_weight(training).contiguous(), self.offset.effective_weight(training).contiguous()
+            sc = ops.linear(cond, wsc)
+            of = ops.linear(cond, wof)
+            if ctx is not None:
+                ctx.update(wsc=wsc, wof=wof, mean=mean, rstd=torch.rsqrt(var + self.eps))
         else:
             sc = (self.weight.detach() - 1.0).reshape(1, -1).contiguous()
             of = self.bias.detach().reshape(1, -1).contiguous()
         return ops.cbn_affine(sc, of, mean, var, self.eps)
+
+
+def _cbn_cond_grad(ctx, st, g_cond):
+    """st [B,C,2] = (dL/da, dL/db) of the affine a = (1+scale)*rstd, b = offset - mean*a; accumulates dL/dcond into g_cond
+    through the two spectral-norm linears scale = cond @ Wsc^T, offset = cond @ Wof^T (:141-144)."""
+    g_a, g_b = st[:, :, 0], st[:, :, 1]
+    g_scale = ((g_a - g_b * ctx["mean"]) * ctx["rstd"]).contiguous()          # [B,C] glue on the per-(b,c) sums
+    ops.linear_t(g_scale, ctx["wsc"], g_cond, accumulate=True)
+    ops.linear_t(g_b.contiguous(), ctx["wof"], g_cond, accumulate=True)
 
 
 class GenBlock(nn.Module):
@@ -125,16 +138,38 @@ class GenBlock(nn.Module):
         self.bn_3 = BigGANBatchNorm(mid, condition_vector_dim, n_stats, eps, True)
         self.conv_3 = _SN((out_size, mid, 1, 1), True, eps)
 
-    def run(self, x, cond, truncation, dt, training):
+    def run(self, x, cond, truncation, dt, training, saved=None):
+        recs = []
+
         def conv(sn, bn, inp, k, cout, **kw):
-            a, b = bn.affine(truncation, cond, training)
-            wp = ops.pack_conv_weight(sn.effective_weight(training).contiguous(), ops.PACK_FWD, dt, 1.0)
+            ctx = {} if saved is not None else None
+            a, b = bn.affine(truncation, cond, training, ctx)
+            w = sn.effective_weight(training).contiguous()
+            wp = ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0)
+            if saved is not None:
+                recs.append(dict(inp=inp, a=a, b=b, w=w, k=k, ctx=ctx))
             return ops.conv2d(inp, wp, cout, k, in_scale=a, in_shift=b, in_relu=True, bias=sn.bias.detach(), **kw)
         t = conv(self.conv_0, self.bn_0, x, 1, self.mid)
         t = conv(self.conv_1, self.bn_1, t, 3, self.mid, in_up2=self.up_sample)
         t = conv(self.conv_2, self.bn_2, t, 3, self.mid)
         skip = ops.slice_up(x, self.out_size, self.up_sample) if (self.drop_channels or self.up_sample) else x
-        return conv(self.conv_3, self.bn_3, t, 1, self.out_size, addend=skip, add_scale=1.0)
+        y = conv(self.conv_3, self.bn_3, t, 1, self.out_size, addend=skip, add_scale=1.0)
+        if saved is not None:
+            saved.append(("block", self, recs))
+        return y
+
+    def backward(self, recs, g_out, g_cond, dt):
+        """Data gradient of the block: returns dL/dx, accumulates dL/dcond (through the four conditional batch norms)."""
+        g = g_out
+        for idx in (3, 2, 1, 0):
+            r = recs[idx]
+            cin = r["inp"].shape[3]
+            gu = ops.conv2d(g, ops.pack_conv_weight(r["w"], ops.PACK_DGRAD, dt, 1.0), cin, r["k"])
+            if idx == 1 and self.up_sample:
+                gu, _ = ops.nearest_up2_bwd(gu)
+            g, st = ops.affine_relu_bwd(gu, r["inp"], r["a"], r["b"])
+            _cbn_cond_grad(r["ctx"], st, g_cond)
+        return ops.slice_up_bwd(g_out, g, self.up_sample)          # skip path: channel drop + nearest upsample adjoint, added
 
 
 class SelfAttn(nn.Module):
@@ -147,15 +182,52 @@ class SelfAttn(nn.Module):
         self.snconv1x1_o_conv = _SN((in_channels, in_channels // 2, 1, 1), False, eps)
         self.gamma = nn.Parameter(torch.zeros(1))
 
-    def run(self, x, dt, training):
+    def run(self, x, dt, training, saved=None):
         B, H, W, Cc = x.shape
-        pk = lambda sn: ops.pack_conv_weight(sn.effective_weight(training).contiguous(), ops.PACK_FWD, dt, 1.0)
-        theta = ops.conv2d(x, pk(self.snconv1x1_theta), Cc // 8, 1)
-        phi = ops.maxpool2(ops.conv2d(x, pk(self.snconv1x1_phi), Cc // 8, 1))
-        g = ops.maxpool2(ops.conv2d(x, pk(self.snconv1x1_g), Cc // 2, 1))
+        ws = [sn.effective_weight(training).contiguous() for sn in (self.snconv1x1_theta, self.snconv1x1_phi, self.snconv1x1_g,
+                                                                     self.snconv1x1_o_conv)]
+        pk = lambda w: ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0)
+        theta = ops.conv2d(x, pk(ws[0]), Cc // 8, 1)
+        phi_pre = ops.conv2d(x, pk(ws[1]), Cc // 8, 1)
+        phi = ops.maxpool2(phi_pre)
+        g_pre = ops.conv2d(x, pk(ws[2]), Cc // 2, 1)
+        g = ops.maxpool2(g_pre)
         o = ops.attention(theta.view(B, H * W, Cc // 8), phi.view(B, H * W // 4, Cc // 8), g.view(B, H * W // 4, Cc // 2))
         gam = self.gamma.detach().reshape(1, 1).expand(B, Cc).contiguous()
-        return ops.conv2d(o.view(B, H, W, Cc // 2), pk(self.snconv1x1_o_conv), Cc, 1, out_scale=gam, addend=x, add_scale=1.0)
+        if saved is not None:
+            saved.append(("attn", self, dict(theta=theta, phi_pre=phi_pre, phi=phi, g_pre=g_pre, g=g, ws=ws)))
+        return ops.conv2d(o.view(B, H, W, Cc // 2), pk(ws[3]), Cc, 1, out_scale=gam, addend=x, add_scale=1.0)
+
+    def backward(self, rec, g_out, dt):
+        """out = x + gamma * conv_o(softmax(theta phi^T) g)  (:75-97).  The softmax-attention backward runs as per-sample
+        GEMMs on the MFMA conv kernels (1x1 convs / weight-gradient kernels with the sample's own K, V as the "weights");
+        the probability matrix is recomputed, not saved."""
+        theta, phi, gv = rec["theta"], rec["phi"], rec["g"]
+        B, H, W, D = theta.shape
+        M, DV, Cc = phi.shape[1] * phi.shape[2], gv.shape[3], 8 * D
+        wth, wph, wg, wo = rec["ws"]
+        pkd = lambda w: ops.pack_conv_weight(w, ops.PACK_DGRAD, dt, 1.0)
+        pkf = lambda m: ops.pack_conv_weight(m.float().contiguous().view(m.shape[0], m.shape[1], 1, 1), ops.PACK_FWD, dt, 1.0)
+        gam = self.gamma.detach().reshape(1, 1).expand(B, DV).contiguous()
+        g_o = ops.conv2d(g_out, pkd(wo), DV, 1, out_scale=gam)                     # [B,H,W,DV]
+        g_q = torch.empty_like(theta)
+        g_k = torch.empty((B, M, D), dtype=torch.float32, device=theta.device)
+        g_v = torch.empty((B, M, DV), dtype=torch.float32, device=theta.device)
+        for b in range(B):
+            Qb, Kb, Vb, gOb = theta[b:b + 1], phi[b].reshape(M, D), gv[b].reshape(M, DV), g_o[b:b + 1]
+            P = ops.softmax_rows_(ops.conv2d(Qb, pkf(Kb), M, 1))                   # [1,H,W,M]
+            gvb = ops.zeros((M, DV, 1, 1), theta.device)
+            ops.conv_wgrad(P, gOb, gvb)                                           # gV = P^T gO
+            gS = ops.softmax_rows_bwd_(P, ops.conv2d(gOb, pkf(Vb), M, 1))         # gP = gO V^T -> gS
+            ops.conv2d(gS, pkf(Kb.t()), D, 1, out=g_q[b:b + 1])                   # gQ = gS K
+            gkb = ops.zeros((M, D, 1, 1), theta.device)
+            ops.conv_wgrad(gS, Qb, gkb)                                           # gK = gS^T Q
+            g_k[b].copy_(gkb.view(M, D)); g_v[b].copy_(gvb.view(M, DV))
+        g_phi_pre = ops.maxpool2_bwd(g_k.view(B, H // 2, W // 2, D).to(theta.dtype), rec["phi_pre"])
+        g_g_pre = ops.maxpool2_bwd(g_v.view(B, H // 2, W // 2, DV).to(theta.dtype), rec["g_pre"])
+        gx = ops.conv2d(g_q, pkd(wth), Cc, 1, addend=g_out, add_scale=1.0)
+        gx = ops.conv2d(g_phi_pre, pkd(wph), Cc, 1, addend=gx, add_scale=1.0)
+        return ops.conv2d(g_g_pre, pkd(wg), Cc, 1, addend=gx, add_scale=1.0)
 
 
 class Generator(nn.Module):
@@ -174,22 +246,61 @@ class Generator(nn.Module):
         self.bn = BigGANBatchNorm(ch, n_stats=config.n_stats, eps=config.eps, conditional=False)
         self.conv_to_rgb = _SN((ch, ch, 3, 3), True, config.eps)
 
-    def forward(self, cond_vector, truncation, compute_dtype="bf16"):
+    def forward(self, cond_vector, truncation, compute_dtype="bf16", saved=None):
         dt = _dt(compute_dtype)
         training = self.training
         truncation = float(truncation)
         B = cond_vector.shape[0]
         ch = self.config.channel_width
-        z = ops.linear(cond_vector, self.gen_z.effective_weight(training).contiguous(), self.gen_z.bias.detach())   # [B, 4*4*16ch] == NHWC
+        wz = self.gen_z.effective_weight(training).contiguous()
+        z = ops.linear(cond_vector, wz, self.gen_z.bias.detach())   # [B, 4*4*16ch] == NHWC
         x = ops.nchw_to_nhwc(z.view(B, 4 * 4 * 16 * ch, 1, 1), B, dt).view(B, 4, 4, 16 * ch)
+        layers = [] if saved is not None else None
         for layer in self.layers:
-            x = layer.run(x, cond_vector, truncation, dt, training) if isinstance(layer, GenBlock) else layer.run(x, dt, training)
+            x = layer.run(x, cond_vector, truncation, dt, training, layers) if isinstance(layer, GenBlock) else layer.run(x, dt, training, layers)
         a, b = self.bn.affine(truncation, None, training)
         a, b = a.expand(B, -1).contiguous(), b.expand(B, -1).contiguous()
         w = self.conv_to_rgb.effective_weight(training)[:16].contiguous()            # only channels 0..2 are used (:253)
         y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0), 16, 3, in_scale=a, in_shift=b, in_relu=True,
                        bias=self.conv_to_rgb.bias.detach()[:16].contiguous())
-        return ops.rgb_tanh(y)
+        img = ops.rgb_tanh(y)
+        if saved is not None:
+            saved.update(wz=wz, layers=layers, x_last=x, a=a, b=b, w_rgb=w, img=img, dt=dt)
+        return img
+
+    def backward(self, saved, g_img):
+        """dL/dcond_vector [B, 2*z_dim] for a gradient g_img on the image (hand-written data gradient; parameters frozen)."""
+        dt = saved["dt"]
+        x = saved["x_last"]
+        B, ch = x.shape[0], x.shape[3]
+        g_cond = torch.zeros((B, saved["wz"].shape[1]), dtype=torch.float32, device=x.device)
+        g_y = ops.rgb_tanh_bwd(g_img.float(), saved["img"], 16, dt)
+        g_u = ops.conv2d(g_y, ops.pack_conv_weight(saved["w_rgb"], ops.PACK_DGRAD, dt, 1.0), ch, 3)
+        g, _ = ops.affine_relu_bwd(g_u, x, saved["a"], saved["b"])
+        for kind, layer, rec in reversed(saved["layers"]):
+            g = layer.backward(rec, g, g_cond, dt) if kind == "block" else layer.backward(rec, g, dt)
+        g_flat = ops.nhwc_to_nchw(g.reshape(B, 1, 1, -1)).view(B, -1)               # f32, same (y, x, c) order as gen_z's output
+        ops.linear_t(g_flat, saved["wz"], g_cond, accumulate=True)
+        return g_cond
+
+
+class _BigGANFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, G, z, embed, truncation):
+        need = ctx.needs_input_grad[1]
+        cond_vector = torch.cat((z.detach().float(), embed), dim=1).contiguous()
+        saved = {} if need else None
+        img = G.generator(cond_vector, truncation, G.compute_dtype, saved)
+        ctx.G, ctx.saved_acts, ctx.zdim = G, saved, z.shape[1]
+        ctx.mark_non_differentiable(cond_vector)
+        return img, cond_vector
+
+    @staticmethod
+    def backward(ctx, g_img, _g_cond):
+        if ctx.saved_acts is None:
+            raise RuntimeError("BigGAN forward ran without saved activations")
+        g_cond = ctx.G.generator.backward(ctx.saved_acts, g_img.contiguous())
+        return None, g_cond[:, :ctx.zdim].contiguous(), None, None
 
 
 class BigGAN(nn.Module):
@@ -205,6 +316,4 @@ class BigGAN(nn.Module):
         assert 0 < truncation <= 1
         with torch.no_grad():
             embed = ops.linear(class_label.float().contiguous(), self.embeddings.weight.detach())
-            cond_vector = torch.cat((z.float(), embed), dim=1).contiguous()
-            img = self.generator(cond_vector, truncation, self.compute_dtype)
-        return img, cond_vector
+        return _BigGANFunction.apply(self, z, embed, truncation)          # differentiable w.r.t. z (E_align_s2.py:162)

@@ -79,6 +79,113 @@ __global__ void rgb_tanh_kernel(const T* __restrict__ x, float* __restrict__ img
     for (int c = 0; c < 3; c++) img[((size_t)b * 3 + c) * HW + p] = tanhf(Elem<T>::ld(xp + c));
 }
 
+// ------------------------------------------------------------------- backward (data gradient w.r.t. z, E_align --mtype 4)
+// Backward of the conv prologue u = relu(a[b,c]*x + bq[b,c]) (conditional batch norm + ReLU, GenBlock :175-203):
+//   gx = [a*x + bq > 0] * a * gu ;  stats[b,c,:] (pre-zeroed) += (sum_p m*gu*x, sum_p m*gu) = (d/da, d/dbq).
+// Channel groups of Cg channels (blockIdx.z) so that any C streams with 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256) void affine_relu_bwd_kernel(const T* __restrict__ gu, const T* __restrict__ x,
+                                                               const float* __restrict__ a, const float* __restrict__ bq,
+                                                               T* __restrict__ gx, float* __restrict__ stats, int HW, int C, int Cg) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * 2 * EP];
+    const int b = blockIdx.y, c0 = blockIdx.z * Cg;
+    const int cpt = Cg / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    float s[2][EP], av[EP], bv[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) {
+        s[0][e] = s[1][e] = 0.f;
+        av[e] = a[(size_t)b * C + c0 + chunk * EP + e];
+        bv[e] = bq[(size_t)b * C + c0 + chunk * EP + e];
+    }
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
+        const int p = p0 + slot;
+        if (slot < ppi && p < HW) {
+            const size_t o = ((size_t)b * HW + p) * C + c0 + chunk * EP;
+            float gv[EP], xv[EP], r[EP];
+            unpack16(*(const uint4*)(gu + o), gv, (T*)nullptr);
+            unpack16(*(const uint4*)(x + o), xv, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                const float m = (av[e] * xv[e] + bv[e] > 0.f) ? gv[e] : 0.f;
+                r[e] = m * av[e];
+                s[0][e] += m * xv[e]; s[1][e] += m;
+            }
+            *(uint4*)(gx + o) = pack16(r, (T*)nullptr);
+        }
+    }
+    block_chan_flush<EP, 2>(s, cpt, ppi, stats + ((size_t)b * C + c0) * 2, Cg, red);
+}
+
+// adjoint of slice_up, accumulated: gx[b,y,x,c] += sum over the 2^up x 2^up block of gy[b,.,.,c] for c < Cout
+template <typename T>
+__global__ void slice_up_bwd_kernel(const T* __restrict__ gy, T* __restrict__ gx, int B, int H, int W, int Cin, int Cout, int up) {
+    constexpr int EP = Elem<T>::PER16;
+    const int cpt = Cout / EP;
+    const long n = (long)B * H * W * cpt;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n) return;
+    const int ch = idx % cpt; long r = idx / cpt; const int xq = r % W; r /= W; const int y = r % H; const int b = r / H;
+    T* dst = gx + (((size_t)b * H + y) * W + xq) * Cin + ch * EP;
+    float acc[EP], gv[EP];
+    unpack16(*(const uint4*)dst, acc, (T*)nullptr);
+    const int f = 1 << up, OW = W << up;
+    for (int dy = 0; dy < f; dy++)
+        for (int dx = 0; dx < f; dx++) {
+            unpack16(*(const uint4*)(gy + (((size_t)b * (H << up) + (y << up) + dy) * OW + (xq << up) + dx) * Cout + ch * EP), gv, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < EP; e++) acc[e] += gv[e];
+        }
+    *(uint4*)dst = pack16(acc, (T*)nullptr);
+}
+
+// Row softmax over M keys, in place (scores S [R, M] of the self-attention backward recomputation); one wavefront per row.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* __restrict__ S, long R, int M) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    T* sp = S + (size_t)row * M;
+    float mx = -INFINITY;
+    for (int m = lane; m < M; m += 64) mx = fmaxf(mx, Elem<T>::ld(sp + m));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int m = lane; m < M; m += 64) sum += __expf(Elem<T>::ld(sp + m) - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int m = lane; m < M; m += 64) Elem<T>::st(sp + m, __expf(Elem<T>::ld(sp + m) - mx) * inv);
+}
+
+// gS = P * (gP - sum_m P*gP) per row, written over gP
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const T* __restrict__ P, T* __restrict__ gP, long R, int M) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const T* pp = P + (size_t)row * M;
+    T* gp = gP + (size_t)row * M;
+    float dot = 0.f;
+    for (int m = lane; m < M; m += 64) dot += Elem<T>::ld(pp + m) * Elem<T>::ld(gp + m);
+    dot = wave_sum(dot);
+    for (int m = lane; m < M; m += 64) Elem<T>::st(gp + m, Elem<T>::ld(pp + m) * (Elem<T>::ld(gp + m) - dot));
+}
+
+// backward of rgb_tanh: gy[b,p,c] = gimg[b,c,p] * (1 - img[b,c,p]^2) for c < 3, 0 for the other (unused) channels
+template <typename T>
+__global__ void rgb_tanh_bwd_kernel(const float* __restrict__ gimg, const float* __restrict__ img, T* __restrict__ gy, int B, int HW, int C) {
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= (long)B * HW) return;
+    const int b = idx / HW, p = idx % HW;
+    T* gp = gy + (size_t)idx * C;
+    for (int c = 0; c < C; c++) {
+        float v = 0.f;
+        if (c < 3) { const size_t o = ((size_t)b * 3 + c) * HW + p; const float t = img[o]; v = gimg[o] * (1.f - t * t); }
+        Elem<T>::st(gp + c, v);
+    }
+}
+
 // =================================================================== C ABI
 extern "C" int dge_cbn_affine(const float* scale, const float* offset, int ld, const float* mean, const float* var, float eps,
                               float* a, float* b, int B, int C, hipStream_t s) {
@@ -115,5 +222,52 @@ extern "C" int dge_rgb_tanh(const void* x, float* img, int B, int HW, int C, int
     if (dtype == DGE_BF16) hipLaunchKernelGGL(rgb_tanh_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)x, img, B, HW, C);
     else hipLaunchKernelGGL(rgb_tanh_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)x, img, B, HW, C);
     DGE_LAUNCH_CHECK("rgb_tanh");
+    return 0;
+}
+
+extern "C" int dge_affine_relu_bwd(const void* gu, const void* x, const float* a, const float* b, void* gx, float* stats, int B,
+                                   int HW, int C, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && ((C / ep) & (C / ep - 1)) == 0, "affine_relu_bwd: C=%d must be a power-of-two multiple of %d", C, ep);
+    const int Cg = C / ep > 256 ? 256 * ep : C;
+    dim3 grid(dge_stream_grid(HW, 256 / (Cg / ep), B), B, C / Cg);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(affine_relu_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gu, (const bf16_t*)x, a, b, (bf16_t*)gx, stats, HW, C, Cg);
+    else hipLaunchKernelGGL(affine_relu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gu, (const float*)x, a, b, (float*)gx, stats, HW, C, Cg);
+    DGE_LAUNCH_CHECK("affine_relu_bwd");
+    return 0;
+}
+
+extern "C" int dge_slice_up_bwd(const void* gy, void* gx, int B, int H, int W, int Cin, int Cout, int up, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(Cout % ep == 0 && Cin % ep == 0 && Cout <= Cin && (up == 0 || up == 1), "slice_up_bwd: bad arguments");
+    const long n = (long)B * H * W * (Cout / ep);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(slice_up_bwd_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)gy, (bf16_t*)gx, B, H, W, Cin, Cout, up);
+    else hipLaunchKernelGGL(slice_up_bwd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gy, (float*)gx, B, H, W, Cin, Cout, up);
+    DGE_LAUNCH_CHECK("slice_up_bwd");
+    return 0;
+}
+
+extern "C" int dge_softmax_rows(void* S, long R, int M, int dtype, hipStream_t s) {
+    dim3 grid((unsigned)((R + 3) / 4));
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, s, (bf16_t*)S, R, M);
+    else hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, s, (float*)S, R, M);
+    DGE_LAUNCH_CHECK("softmax_rows");
+    return 0;
+}
+
+extern "C" int dge_softmax_rows_bwd(const void* P, void* gP, long R, int M, int dtype, hipStream_t s) {
+    dim3 grid((unsigned)((R + 3) / 4));
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(softmax_rows_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)P, (bf16_t*)gP, R, M);
+    else hipLaunchKernelGGL(softmax_rows_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)P, (float*)gP, R, M);
+    DGE_LAUNCH_CHECK("softmax_rows_bwd");
+    return 0;
+}
+
+extern "C" int dge_rgb_tanh_bwd(const float* gimg, const float* img, void* gy, int B, int HW, int C, int dtype, hipStream_t s) {
+    DGE_CHECK(C >= 3, "rgb_tanh_bwd: need at least 3 channels");
+    const long n = (long)B * HW;
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(rgb_tanh_bwd_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gimg, img, (bf16_t*)gy, B, HW, C);
+    else hipLaunchKernelGGL(rgb_tanh_bwd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, gimg, img, (float*)gy, B, HW, C);
+    DGE_LAUNCH_CHECK("rgb_tanh_bwd");
     return 0;
 }

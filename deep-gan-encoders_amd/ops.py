@@ -518,3 +518,49 @@ def pixelnorm_nhwc_bwd(gy, x, eps=1e-8):
     gx = torch.empty_like(x)
     check(lib().dge_pixelnorm_nhwc_bwd(_p(gy), _p(x), _p(gx), x.numel() // Cc, Cc, float(eps), dtype_of(x), _stream()), "dge_pixelnorm_nhwc_bwd")
     return gx
+
+
+# ------------------------------------------------------------------ BigGAN-deep backward ops
+def affine_relu_bwd(gu, x, a, b):
+    """Backward of u = relu(a*x + b): -> (gx, stats [B,C,2] = (d/da, d/db))."""
+    B, H, W, Cc = x.shape
+    gx = torch.empty_like(x)
+    st = zeros((B, Cc, 2), x.device)
+    check(lib().dge_affine_relu_bwd(_p(gu), _p(x), _f32(a), _f32(b), _p(gx), _p(st), B, H * W, Cc, dtype_of(x), _stream()),
+          "dge_affine_relu_bwd")
+    return gx, st
+
+
+def slice_up_bwd(gy, gx, up):
+    """gx [B,H,W,Cin] += adjoint of slice_up applied to gy [B,H<<up,W<<up,Cout]."""
+    B, H, W, Cin = gx.shape
+    check(lib().dge_slice_up_bwd(_p(gy), _p(gx), B, H, W, Cin, gy.shape[3], 1 if up else 0, dtype_of(gx), _stream()), "dge_slice_up_bwd")
+    return gx
+
+
+def softmax_rows_(s):
+    """in-place softmax over the last axis of a contiguous tensor"""
+    M = s.shape[-1]
+    check(lib().dge_softmax_rows(_p(s), s.numel() // M, M, dtype_of(s), _stream()), "dge_softmax_rows")
+    return s
+
+
+def softmax_rows_bwd_(p, gp):
+    M = p.shape[-1]
+    check(lib().dge_softmax_rows_bwd(_p(p), _p(gp), p.numel() // M, M, dtype_of(p), _stream()), "dge_softmax_rows_bwd")
+    return gp
+
+
+def rgb_tanh_bwd(gimg, img, Cc, dtype):
+    B, _, H, W = img.shape
+    gy = torch.empty((B, H, W, Cc), dtype=tdtype(dtype), device=img.device)
+    check(lib().dge_rgb_tanh_bwd(_f32(gimg.contiguous()), _f32(img), _p(gy), B, H * W, Cc, dtype, _stream()), "dge_rgb_tanh_bwd")
+    return gy
+
+
+def maxpool2_bwd(gy, x, addend=None):
+    """gy [B,H/2,W/2,C], x [B,H,W,C] (the pooled tensor) -> gx [B,H,W,C] (+ addend)"""
+    B, H, W, Cc = x.shape
+    gx = torch.empty_like(x)
+    check(lib().dge_maxpool2_bwd(_p(gy), _p(x), _p(addend), _p(gx), B, H, W, Cc, dtype_of(x), _stream()), "dge_maxpool2_bwd")
+    return gx

@@ -267,6 +267,18 @@ int dge_attention(const void* q, const void* k, const void* v, void* o, int B, i
                   dge_stream_t stream);
 /* img[b,c,p] = tanh(x[b,p,c]) for c < 3   (Generator.forward :251-255; x NHWC with >= 3 channels) */
 int dge_rgb_tanh(const void* x, float* img, int B, int HW, int C, int dtype, dge_stream_t stream);
+/* ---- BigGAN-deep backward (data gradient w.r.t. z for E_align --mtype 4, E_align_s2.py:140-162) ---- */
+/* backward of the conv prologue u = relu(a*x + b) (BigGANBatchNorm :127-150 + relu :180-197):
+ * gx = [a*x+b > 0]*a*gu; stats [B,C,2] (pre-zeroed) += (d/da, d/db) */
+int dge_affine_relu_bwd(const void* gu, const void* x, const float* a, const float* b, void* gx, float* stats, int B, int HW, int C,
+                        int dtype, dge_stream_t stream);
+/* adjoint of dge_slice_up accumulated into gx [B,H,W,Cin]: channels < Cout receive the 2^up x 2^up block sums of gy */
+int dge_slice_up_bwd(const void* gy, void* gx, int B, int H, int W, int Cin, int Cout, int up, int dtype, dge_stream_t stream);
+/* SelfAttn :75-97 backward pieces: in-place row softmax of the recomputed scores [R,M]; gS = P*(gP - sum P*gP) over gP */
+int dge_softmax_rows(void* S, long R, int M, int dtype, dge_stream_t stream);
+int dge_softmax_rows_bwd(const void* P, void* gP, long R, int M, int dtype, dge_stream_t stream);
+/* backward of dge_rgb_tanh (:251-254): gy [B,HW,C] NHWC, channels >= 3 zero */
+int dge_rgb_tanh_bwd(const float* gimg, const float* img, void* gy, int B, int HW, int C, int dtype, dge_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -883,6 +883,26 @@ def gen_step_pg():
 
 SECTIONS["step_pg"] = gen_step_pg
 
+def gen_biggangrad():
+    """Gradient of a seeded linear functional of the BigGAN-deep image w.r.t. z (same generator / inputs as biggan_small.npz,
+    eval mode) -- what E_align_s2.py:162 back-propagates into the encoder."""
+    _stub("boto3"); _stub("botocore"); _stub("botocore.exceptions", ClientError=Exception)
+    _stub("requests")
+    from model.biggan_generator import BigGAN
+    from model.utils.biggan_config import BigGANConfig
+    G = BigGAN(BigGANConfig.from_dict(BIGGAN_SMALL_CFG))
+    G.load_state_dict(R.fill_biggan(shapes_of(G.state_dict()), seed=71))
+    G.eval()
+    z = R.randn("bg.z", (2, 128), 71, 0.4).requires_grad_(True)
+    onehot = torch.zeros(2, 1000); onehot[:, 207] = 1.0
+    img, cond = G(z, onehot, 0.4)
+    loss = (img * R.randn("bg.gimg", tuple(img.shape), 72)).sum()
+    loss.backward()
+    save_npz("biggan_grad.npz", g_z=z.grad, loss=loss.detach())
+
+
+SECTIONS["biggangrad"] = gen_biggangrad
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
