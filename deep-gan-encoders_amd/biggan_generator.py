@@ -67,7 +67,8 @@ class _SN(nn.Module):
         self.eps = eps
 
     @torch.no_grad()
-    def effective_weight(self, training):
+    def effective_weight(self, training, ctx=None):
+        """`ctx` (a dict) receives sigma and copies of u, v: what the gradient w.r.t. weight_orig needs (sn_weight_grad)."""
         w = self.weight_orig.detach()
         wm = w.reshape(w.shape[0], -1)
         u, v = self.weight_u, self.weight_v
@@ -75,7 +76,19 @@ class _SN(nn.Module):
             v.copy_(F.normalize(torch.mv(wm.t(), u), dim=0, eps=self.eps))
             u.copy_(F.normalize(torch.mv(wm, v), dim=0, eps=self.eps))
         sigma = torch.dot(u, torch.mv(wm, v))
+        if ctx is not None:
+            ctx.update(sigma=sigma, u=u.clone(), v=v.clone())
         return w / sigma
+
+
+def sn_weight_grad(g_w_eff, weight_orig, sn_ctx):
+    """Gradient w.r.t. `weight_orig` of W_eff = W / sigma, sigma = u^T W v with u, v held constant (the semantics of
+    torch.nn.utils.spectral_norm's autograd): (g - <g, W> / sigma * u v^T) / sigma.  sigma, u, v are the forward's;
+    `weight_orig` is the LIVE parameter: the division's backward reads the tensor autograd saved, which LREQAdam has
+    meanwhile updated through .data when the second backward of a step runs.  Parameter-sized glue."""
+    gm = g_w_eff.reshape(g_w_eff.shape[0], -1)
+    dot = (gm * weight_orig.detach().reshape(gm.shape)).sum() / sn_ctx["sigma"]
+    return ((gm - dot * torch.outer(sn_ctx["u"], sn_ctx["v"])) / sn_ctx["sigma"]).reshape(g_w_eff.shape)
 
 
 class BigGANBatchNorm(nn.Module):
@@ -94,7 +107,9 @@ class BigGANBatchNorm(nn.Module):
 
     def affine(self, truncation, cond, training, ctx=None):
         """-> per-(b,c) affine (a, b).  `ctx` (a dict) receives what the backward w.r.t. the condition vector needs."""
-        coef, start_idx = math.modf(truncation / self.step_size)
+        # `truncation` may be the float32 tensor the training script builds (E_align_s2.py:148): tensor / float is then a
+        # float32 division (0.4f / 0.02 == 20.0 exactly, whereas float(0.4f) / 0.02 == 20.0000003 would select the next row)
+        coef, start_idx = math.modf(float(truncation / self.step_size))
         start_idx = int(start_idx)
         if coef != 0.0:
             mean = self.running_means[start_idx] * coef + self.running_means[start_idx + 1] * (1 - coef)
@@ -102,11 +117,12 @@ class BigGANBatchNorm(nn.Module):
         else:
             mean, var = self.running_means[start_idx], self.running_vars[start_idx]
         if self.conditional:
-            wsc, wof = self.scale.effective_weight(training).contiguous(), self.offset.effective_weight(training).contiguous()
+            sn_sc, sn_of = ({}, {}) if ctx is not None else (None, None)
+            wsc, wof = self.scale.effective_weight(training, sn_sc).contiguous(), self.offset.effective_weight(training, sn_of).contiguous()
             sc = ops.linear(cond, wsc)
             of = ops.linear(cond, wof)
             if ctx is not None:
-                ctx.update(wsc=wsc, wof=wof, mean=mean, rstd=torch.rsqrt(var + self.eps))
+                ctx.update(wsc=wsc, wof=wof, mean=mean, rstd=torch.rsqrt(var + self.eps), sn_sc=sn_sc, sn_of=sn_of)
         else:
             sc = (self.weight.detach() - 1.0).reshape(1, -1).contiguous()
             of = self.bias.detach().reshape(1, -1).contiguous()
@@ -249,7 +265,6 @@ class Generator(nn.Module):
     def forward(self, cond_vector, truncation, compute_dtype="bf16", saved=None):
         dt = _dt(compute_dtype)
         training = self.training
-        truncation = float(truncation)
         B = cond_vector.shape[0]
         ch = self.config.channel_width
         wz = self.gen_z.effective_weight(training).contiguous()
@@ -312,8 +327,8 @@ class BigGAN(nn.Module):
         self.generator = Generator(config)
 
     def forward(self, z, class_label, truncation):
-        truncation = float(truncation)
-        assert 0 < truncation <= 1
+        truncation = truncation.detach().cpu() if torch.is_tensor(truncation) else float(truncation)
+        assert 0 < float(truncation) <= 1
         with torch.no_grad():
             embed = ops.linear(class_label.float().contiguous(), self.embeddings.weight.detach())
         return _BigGANFunction.apply(self, z, embed, truncation)          # differentiable w.r.t. z (E_align_s2.py:162)

@@ -76,17 +76,57 @@ class _PGGANAdapter:
         return self.G(w)["image"]
 
 
+def truncated_noise_sample(batch_size=1, dim_z=128, truncation=1.0, seed=None):
+    """training_utils.py:32-44 (scipy truncnorm on a seeded RandomState)"""
+    from scipy.stats import truncnorm
+    state = None if seed is None else np.random.RandomState(seed)
+    return truncation * truncnorm.rvs(-2, 2, size=(batch_size, dim_z), random_state=state).astype(np.float32)
+
+
+class _BigGANAdapter:
+    """mtype 4 (E_align_s2.py:139-150,155,162): z = 0.4 * truncnorm(seed), one class id per batch drawn with
+    np.random.randint(1000) after set_seed, truncation = float32 tensor 0.4 (kept on the host: its BN-row arithmetic is the
+    reference's float32 division); the encoder is conditioned on the generator's condition vector."""
+
+    def __init__(self, generator):
+        self.G = generator
+        self.truncation = torch.tensor(0.4, dtype=torch.float)
+        self.conditions = self.const1 = None
+
+    def draw(self, iteration, n, dev):
+        z = truncated_noise_sample(truncation=0.4, batch_size=n, dim_z=self.G.config.z_dim, seed=iteration % 30000)
+        self.set_label(int(np.random.randint(1000)), dev)
+        return torch.tensor(z, dtype=torch.float)
+
+    def set_label(self, flag, dev):
+        self.flag = flag
+
+    def sample(self, z, noises=None):
+        B = z.shape[0]
+        self.conditions = torch.zeros(B, self.G.config.num_classes, device=z.device)
+        self.conditions[:, self.flag] = 1.0
+        imgs1, self.const1 = self.G(z, self.conditions, self.truncation)
+        return imgs1, z
+
+    def synth(self, w, noises=None):
+        return self.G(w, self.conditions, self.truncation)[0]
+
+
 class EAlignStep:
     def __init__(self, generator, E, lpips_model, lr=0.0015, beta_1=0.0, batch_size=2, z_dim=512,
                  reference_noise=False, exact_ddp=True, mapping=None):
         """`generator`: StyleGAN2Generator (mtype 2), the StyleGAN1 synthesis network Gs together with
-        `mapping` = Gm (mtype 1), or a PGGANGenerator (mtype 3)."""
+        `mapping` = Gm (mtype 1), a PGGANGenerator (mtype 3) or a BigGAN (mtype 4; z_dim is taken from its config)."""
         from .pggan_generator import PGGANGenerator
+        from .biggan_generator import BigGAN
         self.G, self.E, self.lpips = generator, E, lpips_model
         if mapping is not None:
             self.gen = _StyleGAN1Adapter(generator, mapping)
         elif isinstance(generator, PGGANGenerator):
             self.gen = _PGGANAdapter(generator)
+        elif isinstance(generator, BigGAN):
+            self.gen = _BigGANAdapter(generator)
+            z_dim = generator.config.z_dim
         else:
             self.gen = _StyleGAN2Adapter(generator)
         self.opt = LREQAdam([{"params": E.parameters()}], lr=lr, betas=(beta_1, 0.99), weight_decay=0)
@@ -179,9 +219,10 @@ class EAlignStep:
         ops.zero_arena_begin(self.dev)       # one memset for all of this step's accumulation buffers
         if z is None or not z.is_cuda:
             set_seed(iteration % 30000)
+        big = isinstance(self.gen, _BigGANAdapter)
         if z is None:
             # every rank draws the same global z and takes its slice
-            zg = torch.randn(B * self.world, self.z_dim)
+            zg = self.gen.draw(iteration, B * self.world, self.dev) if big else torch.randn(B * self.world, self.z_dim)
             z = zg[self.rank * B:(self.rank + 1) * B]
         z = z.to(self.dev)
         with torch.no_grad():
@@ -189,7 +230,7 @@ class EAlignStep:
         if noises is None and self.reference_noise:
             from .autograd_enc import draw_noises
             noises = [n.to(self.dev) for n in draw_noises(E, B, imgs1.shape[2], "cpu")]
-        const2, w2 = E(imgs1, noises=noises)
+        const2, w2 = E(imgs1, self.gen.const1, noises=noises) if big else E(imgs1, noises=noises)
         imgs2 = self.gen.synth(w2, gen_noises[1])
 
         gctx = losses.GlobalBatch(self.world) if (self.dist_on and self.exact_ddp) else None
@@ -265,6 +306,20 @@ def build_models_pg(img_size=256, start_features=64, compute_dtype="bf16", devic
     return G, E, LP
 
 
+def build_models_big(config, img_size=256, start_features=64, compute_dtype="bf16", device="cuda", lpips=True, seed=0):
+    """Models of BASELINE config 4 (BigGAN-deep, E_align_s2.py:79-86) with seeded random-init weights; `config`: BigGANConfig."""
+    from .biggan_generator import BigGAN
+    from .encoder_variants import BigBE
+    from .lpips import LPIPS
+    torch.manual_seed(seed)
+    G = BigGAN(config, compute_dtype=compute_dtype).to(device)
+    for p in G.parameters():
+        p.requires_grad_(False)
+    E = BigBE(startf=start_features, maxf=512, layer_count=int(math.log2(img_size) - 1), biggan=True, compute_dtype=compute_dtype).to(device)
+    LP = LPIPS(compute_dtype=compute_dtype).to(device) if lpips else None
+    return G, E, LP
+
+
 def train(tensor_writer=None, args=None):
     """Reference E_align_s2.train() for --mtype 2 (flags: E_align_s2.py:304-318)."""
     cd = getattr(args, "compute_dtype", "bf16")
@@ -286,9 +341,14 @@ def train(tensor_writer=None, args=None):
         if args.checkpoint_dir_GAN:
             ckpt = torch.load(args.checkpoint_dir_GAN, map_location="cpu")
             G.load_state_dict(ckpt["generator_smooth"] if "generator_smooth" in ckpt else ckpt["generator"])
+    elif args.mtype == 4:
+        from .biggan_generator import BigGANConfig
+        G, E, LP = build_models_big(BigGANConfig.from_json_file(args.config_dir), args.img_size, args.start_features, cd)
+        Gm = None
+        if args.checkpoint_dir_GAN:
+            G.load_state_dict(torch.load(args.checkpoint_dir_GAN, map_location="cpu"))
     else:
-        raise NotImplementedError("--mtype 1 (StyleGAN1), 2 (StyleGAN2) and 3 (PGGAN) are wired into the training loop; "
-                                  "the BigGAN generator / E_BIG encoder are forward-only in this build")
+        raise ValueError("--mtype must be 1 (StyleGAN1), 2 (StyleGAN2), 3 (PGGAN) or 4 (BigGAN)")
     if args.checkpoint_dir_E is not None:
         E.load_state_dict(torch.load(args.checkpoint_dir_E, map_location="cpu"))
     st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm)

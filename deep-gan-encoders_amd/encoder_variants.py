@@ -180,46 +180,12 @@ class BigBE(nn.Module):
 
     @torch.no_grad()
     def trunk(self, img, cond_vector, noises=None, truncation=0.4):
-        dt = _dt(self.compute_dtype)
-        dev = img.device
-        B, _, R, _ = img.shape
-        training = self.training
-        cond = cond_vector.float().contiguous()
-        if noises is None:
-            noises = draw_noises(self, B, R, dev)
-        cache = self.__dict__.setdefault("_pack_cache", {})
-        fr = self.FromRGB.from_rgb
-        x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, None)
-        ni = 0
-        for j, blk in enumerate(self.decode_block):
-            Cc, C2, H = blk.inputs, blk.outputs, R >> j
-            a1, b1 = blk.batch_norm_1.affine(truncation, cond, training)
-            x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=a1, in_shift=b1,
-                            noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_1.detach().reshape(-1),
-                            bias=blk.bias_1.detach().reshape(-1), act=ops.ACT_LRELU)
-            ni += 1
-            if not blk.has_second_conv:
-                x = x1
-                break
-            a2, b2 = blk.batch_norm_2.affine(truncation, cond, training)
-            x2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=a2, in_shift=b2,
-                            noise=noises[ni].reshape(B, H, H).contiguous(), noise_w=blk.noise_weight_2.detach().reshape(-1),
-                            bias=blk.bias_2.detach().reshape(-1), act=ops.ACT_LRELU)
-            ni += 1
-            if Cc != C2:
-                a3, b3 = blk.batch_norm_3.affine(truncation, cond, training)
-                res = ops.conv2d(x, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, in_scale=a3, in_shift=b3, bias=blk.conv_3.bias.detach())
-                x2 = ops.blur_noise_act(x2, None, None, None, blur=False)          # the second leaky_relu of E_BIG.py:163
-            else:
-                res = x
-            x = ops.blend(x2, z=ops.blend(res, pool=True), pool=True, alpha=1.0, beta=1.0)   # avg_pool2d(x + residual)
-        return ops.nhwc_to_nchw(x)
+        from .autograd_encbig import big_encoder_forward
+        return big_encoder_forward(self, img, cond_vector, noises, save=False, truncation=truncation)[0]
 
-    @torch.no_grad()
     def forward(self, img, cond_vector, block_num=9, noises=None):
-        x = self.trunk(img, cond_vector, noises)
+        """-> (c_v [B,256], z [B,128]), differentiable w.r.t. every parameter (autograd_encbig)."""
         if not self.biggan:
             raise RuntimeError("E_BIG.BE.forward needs biggan=True (the reference raises UnboundLocalError otherwise, E_BIG.py:223-227)")
-        c_v = ops.linear(x.reshape(x.shape[0], -1).contiguous(), self.new_final_1.weight.detach(), self.new_final_1.bias.detach())
-        z = ops.linear(c_v, self.new_final_2.weight.detach(), self.new_final_2.bias.detach())
-        return c_v, z
+        from .autograd_encbig import BigEncoderFunction
+        return BigEncoderFunction.apply(self, img, cond_vector, noises, *list(self.parameters()))

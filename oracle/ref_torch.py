@@ -427,6 +427,21 @@ def bg_sn_weight(P, name):
     return w / torch.dot(P[name + ".weight_u"], torch.mv(wm, P[name + ".weight_v"]))
 
 
+def bg_sn_power_iteration(P, eps=1e-12, only=None):
+    """One train-mode power iteration of torch.nn.utils.spectral_norm on every (selected) `*.weight_orig` of P, updating
+    `weight_u` / `weight_v` in place under no_grad (torch/nn/utils/spectral_norm.py compute_weight; the reference's
+    BigGAN / E_BIG stay in train mode).  After it, the eval-form `bg_sn_weight` equals the train-mode weight."""
+    with torch.no_grad():
+        for k in list(P):
+            if not k.endswith(".weight_orig") or (only is not None and not only(k)):
+                continue
+            n = k[:-len(".weight_orig")]
+            w = P[k].detach().reshape(P[k].shape[0], -1)
+            v = F.normalize(torch.mv(w.t(), P[n + ".weight_u"]), dim=0, eps=eps)
+            u = F.normalize(torch.mv(w, v), dim=0, eps=eps)
+            P[n + ".weight_u"], P[n + ".weight_v"] = u, v
+
+
 def bg_bn(P, name, x, trunc, cond, eps, n_stats=51):
     """BigGANBatchNorm.forward model/biggan_generator.py:127-150."""
     coef, idx = math.modf(trunc / (1.0 / (n_stats - 1)))

@@ -231,3 +231,46 @@ def test_hip_e_blur_gradients_vs_reference_golden(cd):
         # bf16 activations and bf16-stored gradients: per-tensor L2 within 25 % (worst: the 64-element bias / noise-weight
         # reductions of the deep blocks), the f32 run above is the parity check of the formulas
         _check_blur_grads(named, img.grad, g, 0.25, 0.15)
+
+
+# ---------------------------------------------------------------------------- E_BIG gradients (training --mtype 4)
+def test_oracle_e_big_gradients_vs_reference_golden():
+    """Pins the oracle's differentiated E_BIG (train mode: one spectral-norm power iteration, gradient through sigma) on
+    the reference's own parameter gradients."""
+    from dge_amd.encoder_variants import BigBE
+    g0, g = golden("encbig_small.npz"), golden("encbig_grad.npz")
+    E = BigBE(startf=32, maxf=512, layer_count=5, biggan=True)
+    P = R.fill_encbig({n: list(v.shape) for n, v in E.state_dict().items()}, 81)
+    O.bg_sn_power_iteration(P, eps=1e-12)
+    P = {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and "running_" not in k and "weight_u" not in k and "weight_v" not in k) else v)
+         for k, v in P.items()}
+    noises = [R.randn(f"ebg.noise{i}", tuple(s), 81) for i, s in enumerate(g0["noise_shapes"].tolist())]
+    _, c_v, z = O.encbig_forward(P, R.randn("ebg.img", (2, 3, 64, 64), 81, 0.5), R.randn("ebg.cond", (2, 256), 81, 0.5), noises, 5)
+    assert relerr(c_v, g["c_v"]) < 2e-4 and relerr(z, g["z"]) < 2e-4
+    loss = (z * R.randn("ebg.gz", tuple(z.shape), 82)).sum() + (c_v * R.randn("ebg.gcv", tuple(c_v.shape), 82)).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    _check_grads({k: v.grad for k, v in P.items() if v.requires_grad}, g, 2e-3, 60)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", ["f32", "bf16"])
+def test_hip_e_big_gradients_vs_reference_golden(cd):
+    """Hand-written E_BIG backward (autograd_encbig): every parameter gradient -- convs, noise weights, biases, the spectral-norm
+    `scale` / `offset` linears of the conditional batch norms (through sigma), both head layers -- for gradients entering
+    through both outputs, against the reference's autograd in train mode."""
+    from dge_amd.encoder_variants import BigBE
+    g0, g = golden("encbig_small.npz"), golden("encbig_grad.npz")
+    E = BigBE(startf=32, maxf=512, layer_count=5, biggan=True, compute_dtype=cd).cuda()
+    E.load_state_dict(R.fill_encbig({n: list(v.shape) for n, v in E.state_dict().items()}, 81))
+    E.train()
+    noises = [R.randn(f"ebg.noise{i}", tuple(s), 81).cuda() for i, s in enumerate(g0["noise_shapes"].tolist())]
+    img, cond = R.randn("ebg.img", (2, 3, 64, 64), 81, 0.5).cuda(), R.randn("ebg.cond", (2, 256), 81, 0.5).cuda()
+    c_v, z = E(img, cond, noises=noises)
+    tol = 3e-4 if cd == "f32" else 5e-2
+    assert relerr(c_v, g["c_v"]) < tol and relerr(z, g["z"]) < tol
+    loss = (z * R.randn("ebg.gz", tuple(z.shape), 82).cuda()).sum() + (c_v * R.randn("ebg.gcv", tuple(c_v.shape), 82).cuda()).sum()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) < (2e-4 if cd == "f32" else 0.1) * abs(float(g["loss"]))
+    # f32 tolerance: see test_hip_e_pg_gradients_vs_reference_golden (leaky-relu kink flips move small reductions)
+    _check_grads({k: p.grad for k, p in E.named_parameters()}, g, 1e-2 if cd == "f32" else 0.25, 60)

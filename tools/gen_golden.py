@@ -903,6 +903,113 @@ def gen_biggangrad():
 
 SECTIONS["biggangrad"] = gen_biggangrad
 
+def gen_encbiggrad():
+    """Gradients of the reference E_BIG.BE w.r.t. every parameter for a seeded linear functional of both outputs (c_v, z),
+    in TRAIN mode (the training script never calls .eval(): every conditional-BN linear runs one spectral-norm power
+    iteration in the forward, and the gradient w.r.t. weight_orig goes through sigma).  Model / inputs of encbig_small.npz."""
+    import model.E.E_BIG as EBG
+    E = EBG.BE(startf=32, maxf=512, layer_count=5, biggan=True)
+    E.load_state_dict(R.fill_encbig(shapes_of(E.state_dict()), seed=81))
+    E.train()
+    img = R.randn("ebg.img", (2, 3, 64, 64), 81, 0.5)
+    cond = R.randn("ebg.cond", (2, 256), 81, 0.5)
+    with _NoiseFeeder("ebg", 81):
+        c_v, z = E(img, cond)
+    loss = (z * R.randn("ebg.gz", tuple(z.shape), 82)).sum() + (c_v * R.randn("ebg.gcv", tuple(c_v.shape), 82)).sum()
+    loss.backward()
+    out = {"loss": loss.detach(), "c_v": c_v.detach(), "z": z.detach()}
+    for k, p_ in E.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad
+        out["norm:" + k] = g.norm()
+        out["grad:" + k] = g if g.numel() <= 40000 else g.flatten()[:4096]
+    save_npz("encbig_grad.npz", **out)
+
+
+SECTIONS["encbiggrad"] = gen_encbiggrad
+
+
+def gen_step_big():
+    """Two E_align_s2 iterations for --mtype 4 (BigGAN-deep + E_BIG, E_align_s2.py:79-86,139-162) with the reference's own
+    modules at reduced size (generator config BIGGAN_SMALL_CFG -> 64x64, E_BIG 5 blocks).  Both networks stay in train
+    mode as in the script (one spectral-norm power iteration per forward: SURVEY Q2); `truncation` is the float32 tensor
+    0.4 the script builds (tensor / step_size is a float32 division: exactly row 20, no interpolation); E_BIG's blocks use the
+    Python float 0.4.  z comes from scipy's truncnorm and is stored as a fixture;
+    the label index is the script's np.random.randint(1000) after set_seed (cast to an integer index: the script's float
+    index array is rejected by torch.eye(...)[x,:])."""
+    import warnings
+    _stub("boto3"); _stub("botocore"); _stub("botocore.exceptions", ClientError=Exception)
+    _stub("requests")
+    from model.biggan_generator import BigGAN
+    from model.utils.biggan_config import BigGANConfig
+    import model.E.E_BIG as EBG
+    import training_utils as TU
+    from model.utils.custom_adam import LREQAdam
+    from oracle import lpips_ref as LR
+
+    G = BigGAN(BigGANConfig.from_dict(BIGGAN_SMALL_CFG))
+    G.load_state_dict(R.fill_biggan(shapes_of(G.state_dict()), seed=71))
+    E = EBG.BE(startf=32, maxf=512, layer_count=5, biggan=True)
+    E.load_state_dict(R.fill_encbig(shapes_of(E.state_dict()), seed=81))
+    LP = LR.seeded_params(0)
+    lp = lambda a, b: LR.lpips(LP, a, b)
+    opt = LREQAdam([{"params": E.parameters()}], lr=0.0015, betas=(0.0, 0.99), weight_decay=0)
+    out = {}
+    B = 2
+    for it in range(2):
+        TU.set_seed(it % 30000)
+        z = TU.truncated_noise_sample(truncation=0.4, batch_size=B, seed=it % 30000)
+        flag = np.random.randint(1000)
+        label = TU.one_hot((flag * np.ones(B)).astype(np.int64))
+        w1 = torch.tensor(z, dtype=torch.float)
+        conditions = torch.tensor(label, dtype=torch.float)
+        truncation = torch.tensor(0.4, dtype=torch.float)
+        with _NoiseFeeder(f"bigstep.it{it}", 1) as nf:
+            with torch.no_grad():
+                imgs1, const1 = G(w1, conditions, truncation)
+            const2, w2 = E(imgs1, const1)
+            imgs2, _ = G(w2, conditions, truncation)
+        if it == 0:
+            out["noise_shapes"] = np.array([list(s_) for s_ in nf.log])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            l_i, i_i = TU.space_loss(imgs1, imgs2, lpips_model=lp)
+            m1 = imgs1[:, :, :, imgs1.shape[3] // 8:-imgs1.shape[3] // 8]
+            m2 = imgs2[:, :, :, imgs2.shape[3] // 8:-imgs2.shape[3] // 8]
+            l_m, i_m = TU.space_loss(m1, m2, lpips_model=lp)
+            o = imgs1.shape[2] // 8 + imgs1.shape[2] // 32
+            s1, s2 = imgs1[:, :, o:-o, o:-o], imgs2[:, :, o:-o, o:-o]
+            l_s, i_s = TU.space_loss(s1, s2, lpips_model=lp)
+            loss_tsa = l_i + l_m * 5 + l_s * 9
+            opt.zero_grad()
+            loss_tsa.backward(retain_graph=True)
+            opt.step()
+            l_w, i_w = TU.space_loss(w1, w2, image_space=False)
+            loss_mtv = l_w * 0.01
+            opt.zero_grad()
+            loss_mtv.backward()
+            opt.step()
+        flat = lambda inf: [inf[0][0], inf[0][1], inf[0][2], inf[1], inf[2], inf[3], inf[4]]
+        out[f"it{it}_z"] = w1
+        out[f"it{it}_flag"] = np.array(flag)
+        out[f"it{it}_imgs1"] = imgs1
+        out[f"it{it}_const1"] = const1
+        out[f"it{it}_const2"] = const2.detach()
+        out[f"it{it}_w2"] = w2.detach()
+        out[f"it{it}_imgs2"] = imgs2.detach()
+        out[f"it{it}_losses"] = np.array([float(loss_tsa), float(l_i), float(l_m), float(l_s), float(l_w)])
+        out[f"it{it}_info"] = np.array([flat(i_i), flat(i_m), flat(i_s), flat(i_w)])
+        out[f"it{it}_param_checksum"] = np.array(R.checksum({k: v for k, v in E.state_dict().items() if v.dtype.is_floating_point}))
+        for k in ("decode_block.0.conv_1.weight", "decode_block.2.conv_2.weight", "decode_block.1.conv_3.weight",
+                  "decode_block.1.batch_norm_1.scale.weight_orig", "decode_block.0.batch_norm_3.offset.weight_orig",
+                  "decode_block.1.batch_norm_2.scale.weight_u", "decode_block.1.bias_1", "FromRGB.from_rgb.weight", "new_final_2.bias"):
+            out[f"it{it}_after_phase2:{k}"] = E.state_dict()[k].clone()
+    save_npz("step_big.npz", **out)
+
+
+SECTIONS["step_big"] = gen_step_big
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
