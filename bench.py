@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU: 8 = the batch of the reference ablation scripts (ablation_utils/Cat256/E_align_case_1.py:306); E_align_s2.py:308 defaults to 2")
-    ap.add_argument("--mtype", type=int, default=2, choices=[1, 2], help="2 = StyleGAN2 (headline, BASELINE config 3); 1 = StyleGAN1 "
+    ap.add_argument("--mtype", type=int, default=2, choices=[1, 2, 3, 4], help="2 = StyleGAN2 (headline, BASELINE config 3); 3 = PGGAN (config 1, --img-size 256 --start-features 64); 4 = BigGAN-deep-256 (config 4, same flags); 1 = StyleGAN1 "
                     "(BASELINE config 2: run with --img-size 256 --start-features 64)")
     ap.add_argument("--img-size", type=int, default=1024)
     ap.add_argument("--start-features", type=int, default=16)
@@ -91,6 +91,24 @@ def main():
         G.train()                       # the reference never calls .eval() on G
         st = EAlignStep(G, E, LP, batch_size=a.batch)
         gname = f"StyleGAN2-{a.img_size} G (train mode)"
+    elif a.mtype == 3:
+        from dge_amd.e_align import build_models_pg
+        G, E, LP = build_models_pg(a.img_size, a.start_features, a.dtype, dev, seed=0)
+        st = EAlignStep(G, E, LP, batch_size=a.batch)
+        gname = f"PGGAN-{a.img_size}"
+    elif a.mtype == 4:
+        from dge_amd.e_align import build_models_big
+        from dge_amd.biggan_generator import BigGANConfig
+        assert a.img_size == 256, "--mtype 4 benchmarks the biggan-deep-256 configuration (BASELINE config 4)"
+        cfg = BigGANConfig(output_dim=256, layers=[(False, 16, 16), (True, 16, 16), (False, 16, 16), (True, 16, 8), (False, 8, 8), (True, 8, 8),
+                                                   (False, 8, 8), (True, 8, 4), (False, 4, 4), (True, 4, 2), (False, 2, 2), (True, 2, 1)])
+        G, E, LP = build_models_big(cfg, a.img_size, a.start_features, a.dtype, dev, seed=0)
+        with torch.no_grad():
+            for n_, b_ in G.named_buffers():
+                if n_.endswith("running_vars"):
+                    b_.fill_(1.0)
+        st = EAlignStep(G, E, LP, batch_size=a.batch)
+        gname = "BigGAN-deep-256 (train mode)"
     else:
         G, Gm, E, LP = build_models_sg1(a.img_size, a.start_features, a.dtype, dev, seed=0)
         st = EAlignStep(G, E, LP, batch_size=a.batch, mapping=Gm)
@@ -126,7 +144,7 @@ def main():
         "value": imgs / dt, "unit": "images/sec",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "config": {"workload": f"E_align_s2 two-phase step, {gname} + E.BE(startf={a.start_features}, "
+        "config": {"workload": f"E_align_s2 two-phase step, {gname} + {type(E).__name__}(startf={a.start_features}, "
                                f"L={E.layer_count}) + LPIPS-VGG16 (seeded stand-in weights), batch {a.batch}/GPU",
                    "global_batch": a.batch * world, "img_size": a.img_size, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if a.graph else "eager"},
@@ -138,6 +156,13 @@ def main():
             if a.mtype == 2:
                 wp = torch.randn(a.batch, G.num_layers, 512, device=dev)
                 synth = lambda: G.synthesis(wp)
+            elif a.mtype == 3:
+                wp = torch.randn(a.batch, 512, device=dev)
+                synth = lambda: G(wp)
+            elif a.mtype == 4:
+                wp = 0.4 * torch.randn(a.batch, 128, device=dev)
+                onehot = torch.zeros(a.batch, 1000, device=dev); onehot[:, 207] = 1.0
+                synth = lambda: G(wp, onehot, 0.4)
             else:
                 wp = torch.randn(a.batch, 2 * G.layer_count, 512, device=dev)
                 synth = lambda: G.forward(wp, G.layer_count - 1)
