@@ -82,6 +82,9 @@ SIGNATURES = {
     "dge_softmax_rows": [_P, C.c_long, _I, _I, _P],
     "dge_softmax_rows_bwd": [_P, _P, C.c_long, _I, _I, _P],
     "dge_rgb_tanh_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "dge_upconv_supported": [_I, _I, _I],
+    "dge_pack_upconv_weight": [_P, _P, _I, _I, _F, _I, _P],
+    "dge_upconv_fir": [_P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _F, _F, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_cbn_affine": [_P, _P, _I, _P, _P, _F, _P, _P, _I, _I, _P],
     "dge_slice_up": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -89,13 +89,11 @@ def synthesis_run(mod, wp, randomize_noise=False, save=False):
         L = getattr(mod, f"layer{i}")
         s = s_of(i, L.in_c)
         d = d_all[tab["d_off"][i]:tab["d_off"][i] + B * L.out_c].view(B, L.out_c)
-        packed, _ = L._prepared(dt)
         if randomize_noise:
             noise = torch.randn(x.shape[0], L.res, L.res, device=x.device)
         else:
             noise = L.noise.reshape(1, L.res, L.res)
-        y = ops.conv2d(x, packed, L.out_c, 3, up=L.up, in_scale=s, out_scale=d, bias=L.bias, bias_scale=L.bscale,
-                       noise=noise, noise_w=L.noise_strength.detach().reshape(1), act=L.act, gain=L.gain)
+        y = L.conv(x, s, d, noise, dt)
         results[f"style{i:02d}"] = s
         if save:
             saved["layers"].append(dict(y=y, s=s, d=d, noise=noise))

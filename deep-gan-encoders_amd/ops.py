@@ -564,3 +564,30 @@ def maxpool2_bwd(gy, x, addend=None):
     gx = torch.empty_like(x)
     check(lib().dge_maxpool2_bwd(_p(gy), _p(x), _p(addend), _p(gx), B, H, W, Cc, dtype_of(x), _stream()), "dge_maxpool2_bwd")
     return gx
+
+
+# ------------------------------------------------------------------ StyleGAN2 up layer at algorithmic cost
+def upconv_supported(cin, cout, dtype):
+    return bool(lib().dge_upconv_supported(int(cin), int(cout), int(dtype)))
+
+
+def pack_upconv_weight(w, dtype=BF16, scale=1.0):
+    """w: [Cout,Cin,3,3] f32 -> [9 (phase,tap) units, Cout, Cin] of `dtype` (dge_pack_upconv_weight)."""
+    cout, cin = w.shape[0], w.shape[1]
+    out = torch.empty((9, cout, cin), dtype=tdtype(dtype), device=w.device)
+    check(lib().dge_pack_upconv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, float(scale), dtype, _stream()),
+          "dge_pack_upconv_weight")
+    return out
+
+
+def upconv_fir(x, w_packed, cout, in_scale=None, out_scale=None, bias=None, bias_scale=1.0, noise=None, noise_w=None,
+               act=ACT_NONE, gain=1.0):
+    """x [B,H,W,Cin] -> y [B,2H,2W,cout]: conv_transpose2d(stride 2) + 4x4 FIR + noise / bias / activation in one kernel."""
+    B, H, W, Cin = x.shape
+    y = torch.empty((B, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
+    nbs = 0 if (noise is None or noise.shape[0] == 1) else 4 * H * W
+    nws = 0 if (noise_w is None or noise_w.numel() == 1) else 1
+    check(lib().dge_upconv_fir(_p(x), _p(w_packed), _p(y), _f32(in_scale), _f32(out_scale), _f32(noise), nbs, _f32(noise_w), nws,
+                               _f32(bias), float(bias_scale), float(gain), int(act), B, H, W, Cin, cout, dtype_of(x), _stream()),
+          "dge_upconv_fir")
+    return y

@@ -158,6 +158,32 @@ class ModulateConvBlock(nn.Module):
             self._cache["w"] = c
         return c[1], c[2]
 
+    def _prepared_up(self, dtype):
+        """[9 units][Cout][Cin] weights of the phase-form up kernel (ops.upconv_fir), or None when the layer shape is not
+        covered by it (then the folded 3x3-per-phase form of conv2d(up=True) runs)."""
+        import os
+        # (input resolutions below 16: a single 16x16 t-pixel tile per sample would be mostly padding -- the folded form is faster)
+        if (not self.up or self.res < 32 or os.environ.get("DGE_UP_FOLDED") == "1"
+                or not ops.upconv_supported(self.in_c, self.out_c, dtype)):
+            return None
+        key = (dtype, self.weight._version, self.weight.data_ptr(), getattr(self.weight, "_dge_gen", 0))
+        c = self._cache.get("wu")
+        if c is None or c[0] != key:
+            c = (key, ops.pack_upconv_weight(self.weight, dtype, self.wscale))
+            self._cache["wu"] = c
+        return c[1]
+
+    def conv(self, x, s, d, noise, dt):
+        """The modulated conv proper (:898-921) on NHWC activations: shared-weight form with s / d as prologue / epilogue scales."""
+        nw = self.noise_strength.detach().reshape(1) if noise is not None else None
+        wu = self._prepared_up(dt)
+        if wu is not None:
+            return ops.upconv_fir(x, wu, self.out_c, in_scale=s, out_scale=d, bias=self.bias, bias_scale=self.bscale,
+                                  noise=noise, noise_w=nw, act=self.act, gain=self.gain)
+        packed, _ = self._prepared(dt)
+        return ops.conv2d(x, packed, self.out_c, 3, up=self.up, in_scale=s, out_scale=d, bias=self.bias,
+                          bias_scale=self.bscale, noise=noise, noise_w=nw, act=self.act, gain=self.gain)
+
     def styles(self, w):
         """style s[b,i] and demodulation d[b,o] for latent rows w [B, 512] (any row stride)."""
         s = self.style(w)
@@ -177,16 +203,13 @@ class ModulateConvBlock(nn.Module):
         packed, wsq = self._prepared(dt)
         s = self.style(w)
         d = ops.linear(s, wsq, None, 1.0, 1.0, self.eps, ops.LIN_RSQRT, 1.0, square_input=True) if self.demodulate else None
-        noise = nw = None
+        noise = None
         if self.add_noise:
             if randomize_noise:
                 noise = torch.randn(x.shape[0], self.res, self.res, device=x.device)
             else:
                 noise = self.noise.reshape(1, self.res, self.res)
-            nw = self.noise_strength.detach().reshape(1)
-        y = ops.conv2d(x, packed, self.out_c, 3, up=self.up, in_scale=s, out_scale=d, bias=self.bias,
-                       bias_scale=self.bscale, noise=noise, noise_w=nw, act=self.act, gain=self.gain)
-        return y, s
+        return self.conv(x, s, d, noise, dt), s
 
 
 class SynthesisModule(nn.Module):

@@ -249,6 +249,16 @@ int dge_dot_stats(const void* g, const void* x, float* stats, int B, int HW, int
 int dge_nearest_up2_bwd(const void* ghi, const void* x, void* glow, float* stats, int B, int H, int W, int C, int dtype,
                         dge_stream_t stream);
 
+/* ---- StyleGAN2 up layer at algorithmic cost (stylegan2_generator.py:879-896 conv_transpose2d + 4x4 FIR, :911-921) ----
+ * Transposed conv in phase form on the MFMAs (9 tap-MACs per input pixel instead of the 36 of the folded 3x3-per-phase
+ * form of dge_conv2d(up=1)), FIR + demodulation / noise / bias / activation from LDS in the same kernel.
+ * w_packed: dge_pack_upconv_weight ([9 (phase,tap) units][Cout][Cin]).  Supported when dge_upconv_supported(). */
+int dge_upconv_supported(int Cin, int Cout, int dtype);
+int dge_pack_upconv_weight(const float* w, void* out, int Cout, int Cin, float scale, int dtype, dge_stream_t stream);
+int dge_upconv_fir(const void* x, const void* w_packed, void* y, const float* in_scale, const float* out_scale,
+                   const float* noise, int noise_bstride, const float* noise_w, int noise_w_stride, const float* bias,
+                   float bias_scale, float gain, int act, int B, int H, int W, int Cin, int Cout, int dtype, dge_stream_t stream);
+
 /* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */
 /* pixel-wise feature normalisation over the channel axis of an NHWC tensor (PixelNormLayer :207-216) */
 int dge_pixelnorm_nhwc(const void* x, void* y, long npix, int C, float eps, int dtype, dge_stream_t stream);
