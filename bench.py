@@ -201,7 +201,7 @@ def main():
             traffic, tsrc = tj["traffic_bytes_per_launch"], "profiles/r01_conv_traffic.json"
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "conv_igemm_kernel<*> (all implicit-GEMM conv launches of a step)",
+                           "kernel": "conv_igemm_kernel<*> + upconv_fir_kernel (all implicit-GEMM conv launches of a step)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,
                            "algorithmic_bytes_per_launch": ab / max(nlaunch, 1),

@@ -587,7 +587,15 @@ def upconv_fir(x, w_packed, cout, in_scale=None, out_scale=None, bias=None, bias
     y = torch.empty((B, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
     nbs = 0 if (noise is None or noise.shape[0] == 1) else 4 * H * W
     nws = 0 if (noise_w is None or noise_w.numel() == 1) else 1
-    check(lib().dge_upconv_fir(_p(x), _p(w_packed), _p(y), _f32(in_scale), _f32(out_scale), _f32(noise), nbs, _f32(noise_w), nws,
-                               _f32(bias), float(bias_scale), float(gain), int(act), B, H, W, Cin, cout, dtype_of(x), _stream()),
-          "dge_upconv_fir")
+    def launch():
+        check(lib().dge_upconv_fir(_p(x), _p(w_packed), _p(y), _f32(in_scale), _f32(out_scale), _f32(noise), nbs, _f32(noise_w), nws,
+                                   _f32(bias), float(bias_scale), float(gain), int(act), B, H, W, Cin, cout, dtype_of(x), _stream()),
+              "dge_upconv_fir")
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); launch(); e1.record()
+        abytes = sum(t.numel() * t.element_size() for t in (x, y, w_packed))
+        PROFILE.append((e0, e1, 2.0 * 9.0 * Cin * cout * H * W * B, (B, H, W, Cin, cout, 3, "upfir", False), abytes))
+    else:
+        launch()
     return y
