@@ -208,16 +208,29 @@ class SelfAttn(nn.Module):
         phi = ops.maxpool2(phi_pre)
         g_pre = ops.conv2d(x, pk(ws[2]), Cc // 2, 1)
         g = ops.maxpool2(g_pre)
-        o = ops.attention(theta.view(B, H * W, Cc // 8), phi.view(B, H * W // 4, Cc // 8), g.view(B, H * W // 4, Cc // 2))
+        # softmax(theta phi^T) g as per-sample GEMMs on the MFMA conv kernel: the sample's keys / values are the "weights"
+        # of a 1x1 convolution over its queries (N x M scores, row softmax in place, then P V)
+        M, D, DV = H * W // 4, Cc // 8, Cc // 2
+        pkm = lambda m: ops.pack_conv_weight(m.float().contiguous().view(m.shape[0], m.shape[1], 1, 1), ops.PACK_FWD, dt, 1.0)
+        o = torch.empty((B, H, W, DV), dtype=x.dtype, device=x.device)
+        probs = []
+        import os
+        if os.environ.get("DGE_ATTN_KERNEL") == "1":       # one-wavefront-per-query kernel (kept for cross-checks)
+            o = ops.attention(theta.view(B, H * W, D), phi.view(B, M, D), g.view(B, M, DV)).view(B, H, W, DV)
+            probs = None
+        for b in range(B if probs is not None else 0):
+            P = ops.softmax_rows_(ops.conv2d(theta[b:b + 1], pkm(phi[b].reshape(M, D)), M, 1))          # [1,H,W,M]
+            ops.conv2d(P, pkm(g[b].reshape(M, DV).t()), DV, 1, out=o[b:b + 1])
+            probs.append(P)
         gam = self.gamma.detach().reshape(1, 1).expand(B, Cc).contiguous()
         if saved is not None:
-            saved.append(("attn", self, dict(theta=theta, phi_pre=phi_pre, phi=phi, g_pre=g_pre, g=g, ws=ws)))
-        return ops.conv2d(o.view(B, H, W, Cc // 2), pk(ws[3]), Cc, 1, out_scale=gam, addend=x, add_scale=1.0)
+            saved.append(("attn", self, dict(theta=theta, phi_pre=phi_pre, phi=phi, g_pre=g_pre, g=g, ws=ws, probs=probs)))
+        return ops.conv2d(o, pk(ws[3]), Cc, 1, out_scale=gam, addend=x, add_scale=1.0)
 
     def backward(self, rec, g_out, dt):
         """out = x + gamma * conv_o(softmax(theta phi^T) g)  (:75-97).  The softmax-attention backward runs as per-sample
         GEMMs on the MFMA conv kernels (1x1 convs / weight-gradient kernels with the sample's own K, V as the "weights");
-        the probability matrix is recomputed, not saved."""
+        the forward's probability matrices are re-used."""
         theta, phi, gv = rec["theta"], rec["phi"], rec["g"]
         B, H, W, D = theta.shape
         M, DV, Cc = phi.shape[1] * phi.shape[2], gv.shape[3], 8 * D
@@ -231,7 +244,7 @@ class SelfAttn(nn.Module):
         g_v = torch.empty((B, M, DV), dtype=torch.float32, device=theta.device)
         for b in range(B):
             Qb, Kb, Vb, gOb = theta[b:b + 1], phi[b].reshape(M, D), gv[b].reshape(M, DV), g_o[b:b + 1]
-            P = ops.softmax_rows_(ops.conv2d(Qb, pkf(Kb), M, 1))                   # [1,H,W,M]
+            P = rec["probs"][b] if rec["probs"] is not None else ops.softmax_rows_(ops.conv2d(Qb, pkf(Kb), M, 1))   # [1,H,W,M]
             gvb = ops.zeros((M, DV, 1, 1), theta.device)
             ops.conv_wgrad(P, gOb, gvb)                                           # gV = P^T gO
             gS = ops.softmax_rows_bwd_(P, ops.conv2d(gOb, pkf(Vb), M, 1))         # gP = gO V^T -> gS
