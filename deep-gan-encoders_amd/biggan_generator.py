@@ -69,6 +69,13 @@ class _SN(nn.Module):
     @torch.no_grad()
     def effective_weight(self, training, ctx=None):
         """`ctx` (a dict) receives sigma and copies of u, v: what the gradient w.r.t. weight_orig needs (sn_weight_grad)."""
+        prep = self.__dict__.get("_prep")
+        if prep is not None:                       # computed by sn_prepare() for the whole module in five grouped launches
+            self.__dict__["_prep"] = None
+            w_eff, sigma, us, vs = prep
+            if ctx is not None:
+                ctx.update(sigma=sigma, u=us, v=vs)
+            return w_eff
         w = self.weight_orig.detach()
         wm = w.reshape(w.shape[0], -1)
         u, v = self.weight_u, self.weight_v
@@ -79,6 +86,58 @@ class _SN(nn.Module):
         if ctx is not None:
             ctx.update(sigma=sigma, u=u.clone(), v=v.clone())
         return w / sigma
+
+
+def sn_prepare(module, training):
+    """Spectral normalisation of EVERY _SN weight under `module` for the coming forward in five grouped launches
+    (dge_sn_group): in train mode one power iteration per weight, written into the weight_u / weight_v buffers exactly as
+    the per-weight path does.  Each _SN then hands out its W_eff (and sigma, u, v for the backward) once."""
+    import numpy as np
+    sns = module.__dict__.get("_sn_list")
+    if sns is None:
+        skip = module.__dict__.get("_sn_skip", ())          # sub-modules the forward never reaches keep their u / v untouched
+        sns = [m for n, m in module.named_modules() if isinstance(m, _SN) and not any(n.startswith(p) for p in skip)]
+        module.__dict__["_sn_list"] = sns
+    if not sns:
+        return
+    dev = sns[0].weight_orig.device
+    eps = sns[0].eps
+    assert all(m.eps == eps for m in sns)
+    key = tuple((m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr()) for m in sns)
+    st = module.__dict__.get("_sn_static")
+    if st is None or st["key"] != key:
+        n = len(sns)
+        Os = np.array([m.weight_orig.shape[0] for m in sns], dtype=np.int64)
+        Ks = np.array([m.weight_orig[0].numel() for m in sns], dtype=np.int64)
+        dt = np.dtype([("W", "u8"), ("u", "u8"), ("v", "u8"), ("t", "u8"), ("s", "u8"), ("weff", "u8"), ("usnap", "u8"), ("vsnap", "u8"),
+                       ("O", "i4"), ("K", "i4")])
+        assert dt.itemsize == ops.lib().dge_sn_entry_size()
+        tab = np.zeros(n, dtype=dt)
+        tab["W"] = [m.weight_orig.data_ptr() for m in sns]
+        tab["u"] = [m.weight_u.data_ptr() for m in sns]
+        tab["v"] = [m.weight_v.data_ptr() for m in sns]
+        tab["O"], tab["K"] = Os, Ks
+        cum = lambda a: np.concatenate([[0], np.cumsum(a)[:-1]])
+        st = dict(key=key, tab=tab, Os=Os, Ks=Ks, offO=cum(Os), offK=cum(Ks), offW=cum(Os * Ks), totO=int(Os.sum()), totK=int(Ks.sum()),
+                  totW=int((Os * Ks).sum()), maxO=int(Os.max()), maxK=int(Ks.max()))
+        module.__dict__["_sn_static"] = st
+    n = len(sns)
+    f32 = dict(dtype=torch.float32, device=dev)
+    t_all = torch.zeros(st["totK"], **f32) if training else torch.empty(1, **f32)
+    s_all, weff = torch.empty(st["totO"], **f32), torch.empty(st["totW"], **f32)
+    usnap, vsnap, sigma = torch.empty(st["totO"], **f32), torch.empty(st["totK"], **f32), torch.empty(n, **f32)
+    tab = st["tab"].copy()
+    tab["t"] = t_all.data_ptr() + 4 * (st["offK"] if training else 0)
+    tab["s"] = s_all.data_ptr() + 4 * st["offO"]
+    tab["weff"] = weff.data_ptr() + 4 * st["offW"]
+    tab["usnap"] = usnap.data_ptr() + 4 * st["offO"]
+    tab["vsnap"] = vsnap.data_ptr() + 4 * st["offK"]
+    tab_dev = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+    ops.check(ops.lib().dge_sn_group(ops._p(tab_dev), n, st["maxO"], st["maxK"], ops._p(sigma), float(eps), 1 if training else 0,
+                                     ops._stream()), "dge_sn_group")
+    for i, m in enumerate(sns):
+        O, K, oo, ok, ow = int(st["Os"][i]), int(st["Ks"][i]), int(st["offO"][i]), int(st["offK"][i]), int(st["offW"][i])
+        m.__dict__["_prep"] = (weff[ow:ow + O * K].view(m.weight_orig.shape), sigma[i], usnap[oo:oo + O], vsnap[ok:ok + K])
 
 
 def sn_weight_grad(g_w_eff, weight_orig, sn_ctx):
@@ -280,6 +339,7 @@ class Generator(nn.Module):
         training = self.training
         B = cond_vector.shape[0]
         ch = self.config.channel_width
+        sn_prepare(self, training)
         wz = self.gen_z.effective_weight(training).contiguous()
         z = ops.linear(cond_vector, wz, self.gen_z.bias.detach())   # [B, 4*4*16ch] == NHWC
         x = ops.nchw_to_nhwc(z.view(B, 4 * 4 * 16 * ch, 1, 1), B, dt).view(B, 4, 4, 16 * ch)

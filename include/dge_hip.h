@@ -249,6 +249,13 @@ int dge_dot_stats(const void* g, const void* x, float* stats, int B, int HW, int
 int dge_nearest_up2_bwd(const void* ghi, const void* x, void* glow, float* stats, int B, int H, int W, int C, int dtype,
                         dge_stream_t stream);
 
+/* torch.nn.utils.spectral_norm (snconv2d / snlinear, biggan_generator.py:28-56) for a GROUP of weights in five launches:
+ * train mode = one power iteration (v = normalize(W^T u), u = normalize(W v), written into the module's buffers), sigma = u.(W v),
+ * W_eff = W / sigma.  `entries`: device array of n records {const float* W; float* u, *v, *t, *s, *weff, *usnap, *vsnap; int O, K}
+ * (dge_sn_entry_size() bytes each; t pre-zeroed in train mode; usnap / vsnap receive the u, v used for sigma). */
+int dge_sn_group(const void* entries, int n, int maxO, int maxK, float* sigma, float eps, int training, dge_stream_t stream);
+int dge_sn_entry_size(void);
+
 /* ---- StyleGAN2 up layer at algorithmic cost (stylegan2_generator.py:879-896 conv_transpose2d + 4x4 FIR, :911-921) ----
  * Transposed conv in phase form on the MFMAs (9 tap-MACs per input pixel instead of the 36 of the folded 3x3-per-phase
  * form of dge_conv2d(up=1)), FIR + demodulation / noise / bias / activation from LDS in the same kernel.
