@@ -18,8 +18,6 @@
 #include "common.h"
 #include "../../include/dge_hip.h"
 
-namespace {
-
 template <typename T> struct MmaU;
 template <> struct MmaU<bf16_t> {
     __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
@@ -411,8 +409,6 @@ __global__ void upconv_pack_kernel(const float* __restrict__ w, T* __restrict__ 
         Elem<T>::st(out + idx, scale * w[((size_t)o * Cin + i) * 9 + wy[q] * 3 + wx[q]]);
     }
 }
-
-}  // namespace
 
 extern "C" int dge_upconv_supported(int Cin, int Cout, int dtype) {
     const int kc = dtype == DGE_BF16 ? 32 : 16;

@@ -11,7 +11,7 @@ cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 rows = c.execute("select name, start, end from kernels").fetchall()
 agg = {}
 for name, s, e in rows:
-    short = re.sub(r"\(.*", "", name)
+    short = re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", ""))
     short = re.sub(r"^void ", "", short)
     a = agg.setdefault(short, [0, 0.0, 1e30, 0.0])
     d = (e - s) / 1e3
