@@ -14,7 +14,7 @@ import torch
 
 from . import ops
 from .autograd_enc import _packed, draw_noises
-from .biggan_generator import sn_weight_grad, sn_prepare
+from .biggan_generator import sn_weight_grad, sn_prepare, sn_cbn_linears
 from .stylegan2_generator import _dt
 
 
@@ -31,7 +31,7 @@ def big_encoder_forward(E, img, cond_vector, noises=None, save=False, truncation
         # the last block stops after conv_1 (E_BIG.py:146-152): its batch_norm_2 / batch_norm_3 are never called by the reference
         last = len(E.decode_block) - 1
         E.__dict__["_sn_skip"] = (f"decode_block.{last}.batch_norm_2.", f"decode_block.{last}.batch_norm_3.")
-    sn_prepare(E, training)          # every conditional-BN linear's spectral norm (power iteration in train mode) at once
+    sn_prepare(E, training); sn_cbn_linears(E, cond)          # every conditional-BN linear's spectral norm (power iteration in train mode) at once
     fr = E.FromRGB.from_rgb
     x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, None)
     saved = {"img": img, "x0": x, "cond": cond, "blocks": []} if save else None

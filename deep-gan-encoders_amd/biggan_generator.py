@@ -97,7 +97,11 @@ def sn_prepare(module, training):
     if sns is None:
         skip = module.__dict__.get("_sn_skip", ())          # sub-modules the forward never reaches keep their u / v untouched
         sns = [m for n, m in module.named_modules() if isinstance(m, _SN) and not any(n.startswith(p) for p in skip)]
+        # conditional-BN linears first (their W_eff rows then form ONE [sum C, cond_dim] matrix: sn_cbn_linears), then the rest
+        bnl = {id(l) for bn in module.modules() if isinstance(bn, BigGANBatchNorm) and bn.conditional for l in (bn.scale, bn.offset)}
+        sns = [m for m in sns if id(m) in bnl] + [m for m in sns if id(m) not in bnl]
         module.__dict__["_sn_list"] = sns
+        module.__dict__["_sn_nbn"] = sum(1 for m in sns if id(m) in bnl)
     if not sns:
         return
     dev = sns[0].weight_orig.device
@@ -138,6 +142,23 @@ def sn_prepare(module, training):
     for i, m in enumerate(sns):
         O, K, oo, ok, ow = int(st["Os"][i]), int(st["Ks"][i]), int(st["offO"][i]), int(st["offK"][i]), int(st["offW"][i])
         m.__dict__["_prep"] = (weff[ow:ow + O * K].view(m.weight_orig.shape), sigma[i], usnap[oo:oo + O], vsnap[ok:ok + K])
+    module.__dict__["_sn_weff"] = weff
+
+
+def sn_cbn_linears(module, cond):
+    """scale / offset of EVERY conditional batch norm under `module` (:141-144: two snlinears of the condition vector each) as
+    one dense launch over the concatenated W_eff rows; each BigGANBatchNorm then slices its columns.  Call after sn_prepare."""
+    st, sns, nbn = module.__dict__.get("_sn_static"), module.__dict__.get("_sn_list"), module.__dict__.get("_sn_nbn", 0)
+    if not nbn:
+        return
+    K = int(st["Ks"][0])
+    if any(int(k) != K for k in st["Ks"][:nbn]) or cond.shape[1] != K:
+        return
+    rows = int(st["offO"][nbn - 1] + st["Os"][nbn - 1])
+    out = ops.linear(cond, module.__dict__["_sn_weff"][:rows * K].view(rows, K))          # [B, sum C]
+    for i in range(nbn):
+        o0 = int(st["offO"][i])
+        sns[i].__dict__["_lin"] = out[:, o0:o0 + int(st["Os"][i])]
 
 
 def sn_weight_grad(g_w_eff, weight_orig, sn_ctx):
@@ -178,8 +199,9 @@ class BigGANBatchNorm(nn.Module):
         if self.conditional:
             sn_sc, sn_of = ({}, {}) if ctx is not None else (None, None)
             wsc, wof = self.scale.effective_weight(training, sn_sc).contiguous(), self.offset.effective_weight(training, sn_of).contiguous()
-            sc = ops.linear(cond, wsc)
-            of = ops.linear(cond, wof)
+            sc, of = self.scale.__dict__.pop("_lin", None), self.offset.__dict__.pop("_lin", None)     # sn_cbn_linears
+            if sc is None or of is None:
+                sc, of = ops.linear(cond, wsc), ops.linear(cond, wof)
             if ctx is not None:
                 ctx.update(wsc=wsc, wof=wof, mean=mean, rstd=torch.rsqrt(var + self.eps), sn_sc=sn_sc, sn_of=sn_of)
         else:
@@ -340,6 +362,7 @@ class Generator(nn.Module):
         B = cond_vector.shape[0]
         ch = self.config.channel_width
         sn_prepare(self, training)
+        sn_cbn_linears(self, cond_vector)
         wz = self.gen_z.effective_weight(training).contiguous()
         z = ops.linear(cond_vector, wz, self.gen_z.bias.detach())   # [B, 4*4*16ch] == NHWC
         x = ops.nchw_to_nhwc(z.view(B, 4 * 4 * 16 * ch, 1, 1), B, dt).view(B, 4, 4, 16 * ch)

@@ -419,8 +419,13 @@ def cbn_affine(scale, offset, mean, var, eps):
     B, Cc = scale.shape
     a = torch.empty((B, Cc), dtype=torch.float32, device=scale.device)
     b = torch.empty_like(a)
-    check(lib().dge_cbn_affine(_f32(scale), _f32(offset), Cc, _f32(mean.contiguous()), _f32(var.contiguous()), float(eps),
-                               _p(a), _p(b), B, Cc, _stream()), "dge_cbn_affine")
+    # scale / offset may be column slices of one wide [B, sum C] matrix (all conditional-BN linears of a module in one launch)
+    ld = scale.stride(0) if B > 1 else Cc
+    if scale.dtype != torch.float32 or offset.dtype != torch.float32 or scale.stride(1) != 1 or offset.stride(1) != 1 or \
+            (B > 1 and offset.stride(0) != ld):
+        raise DgeError("cbn_affine: scale / offset must be float32 rows with unit inner stride and a common row stride")
+    check(lib().dge_cbn_affine(C.c_void_p(scale.data_ptr()), C.c_void_p(offset.data_ptr()), ld, _f32(mean.contiguous()),
+                               _f32(var.contiguous()), float(eps), _p(a), _p(b), B, Cc, _stream()), "dge_cbn_affine")
     return a, b
 
 
