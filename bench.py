@@ -125,6 +125,13 @@ def main():
         run = lambda i: st.replay(i)
     else:
         run = lambda i: st.step(i)
+    # priming (not one of the W warm-up steps): RCCL builds its channels inside the first collective and the allocator / code
+    # objects settle during the first step; with a small W that start-up cost would otherwise leak into the timed region
+    if dist.is_initialized():
+        dist.all_reduce(torch.zeros(24 << 20, device=dev))
+    if not a.graph:
+        st.step(29999)
+    sync()
     for i in range(a.warmup):
         run(i)
     sync()
