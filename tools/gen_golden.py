@@ -1010,6 +1010,27 @@ def gen_step_big():
 
 SECTIONS["step_big"] = gen_step_big
 
+def gen_latent_fixtures():
+    """The reference's shipped data files for the latent-editing / inversion demos (latent_code/directions/*.npy: InterfaceGAN
+    boundaries [1,512] f64; latent_code/real_face_code/*.pt: W+ codes [1,18,512]) as one small fixture, plus the edited code
+    embeded_img_edit.py:38-41 produces from them (its exact indexing: rows start..start+end of w + bonus*direction)."""
+    out = {}
+    root = os.path.join(REF, "latent_code")
+    for name in ("age", "eyeglasses", "gender", "pose", "smile"):
+        out["dir_" + name] = np.load(os.path.join(root, "directions", f"stylegan_ffhq_{name}_w_boundary.npy"))
+    for name in ("i4_msk", "i5_ty"):
+        out["w_" + name] = torch.load(os.path.join(root, "real_face_code", name + ".pt"), map_location="cpu").detach().clone().float()
+    # the script's own arithmetic (embeded_img_edit.py:28-41) for two settings
+    for tag, dname, bonus, start, end in (("a", "eyeglasses", 70, 0, 3), ("b", "smile", 100, 0, 4)):
+        direction = torch.tensor(out["dir_" + dname]).float().expand(18, 512)
+        w = out["w_i4_msk"].clone().squeeze(0)
+        w[start:start + end] = (w + bonus * direction)[start:start + end]
+        out["edit_" + tag] = w.reshape(1, 18, 512)
+    save_npz("latent_fixtures.npz", **out)
+
+
+SECTIONS["latent"] = gen_latent_fixtures
+
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(SECTIONS)
     for s_ in todo:
