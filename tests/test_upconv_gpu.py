@@ -48,3 +48,21 @@ def test_upconv_fir_vs_reference_lines_and_folded_form(cd, B, H, W, Cin, Cout):
     tol = 2e-5 if cd == "f32" else 2e-2
     assert e_new < tol, (e_new, e_old)
     assert e_old < tol, (e_new, e_old)
+
+
+def test_upconv_fir_per_sample_noise_and_linear_activation():
+    """randomize_noise=True hands a [B,2H,2W] noise tensor (stylegan2_generator.py:912-913); linear activation / no demodulation
+    are the toRGB-style settings of the same block class.  Both against the folded form."""
+    from dge_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, H, W, Cin, Cout = 3, 16, 24, 64, 64
+    x = ops.nchw_to_nhwc(torch.randn(B, Cin, H, W, generator=g).cuda(), B, ops.BF16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).cuda()
+    s = (1.0 + 0.3 * torch.randn(B, Cin, generator=g)).cuda()
+    noise = torch.randn(B, 2 * H, 2 * W, generator=g).cuda()
+    ns = torch.tensor([0.5]).cuda()
+    for kw in (dict(in_scale=s, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=1.4142135), dict(in_scale=s, act=ops.ACT_NONE, gain=1.0),
+               dict(act=ops.ACT_NONE, gain=1.0)):
+        a = ops.upconv_fir(x, ops.pack_upconv_weight(w, ops.BF16, 0.04), Cout, **kw).float()
+        b = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_UPFOLD, ops.BF16, 0.04), Cout, 3, up=True, **kw).float()
+        assert float((a - b).abs().max()) < 2e-2 * float(b.abs().max()), kw.keys()
