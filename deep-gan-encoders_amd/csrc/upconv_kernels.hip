@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, (UpCfg<T>::MINW)) void upconv_fir_kernel(UpPar
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the untracked weight DMA
     __syncthreads();
     for (int kc = 0; kc < ((p.dbg & 1) ? 0 : nchunks); kc++) {
-        if (kc + 1 < nchunks) { dma_b(kc + 1, (kc + 1) & 1); load_ab(kc + 1); }     // in flight behind the MFMAs of this chunk
+        if (kc + 1 < nchunks) { if (!(p.dbg & 8)) dma_b(kc + 1, (kc + 1) & 1); if (!(p.dbg & 16)) load_ab(kc + 1); }     // in flight behind the MFMAs of this chunk
         const unsigned char* bcur = ldsB + (kc & 1) * C::B_BYTES;
         {
             // 18 steps = 2 K slices x 9 (phase, tap) units, software-pipelined by hand: the weight fragment of step t+3 is
