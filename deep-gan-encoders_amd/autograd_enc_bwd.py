@@ -90,6 +90,12 @@ def encoder_backward(E, saved, g_w):
         g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD), Cc, 3, stats=dots1, dot_src=x)
         coef1 = ops.in_bwd_coef(dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
         g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
+        if j == L // 2:
+            # data-parallel runs: the gradients of blocks L-1 .. L/2 (the 512-channel blocks: > 90 % of the parameter bytes) are
+            # complete here, while the high-resolution blocks still to come take most of the backward's time
+            hook = E.__dict__.get("_early_grad_hook")
+            if hook is not None:
+                hook(dict(grads))
     fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float())
     C0 = E.startf
     grads["FromRGB.from_rgb.weight"] = fr[:, :3].reshape(C0, 3, 1, 1)

@@ -141,26 +141,62 @@ class EAlignStep:
         self.dev = next(E.parameters()).device
         self._flat = None
         self.last = {}
+        if self.dist_on:
+            E.__dict__["_early_grad_hook"] = self.early_reduce        # autograd_enc_bwd calls it after the deep blocks
 
     # ------------------------------------------------------------------ DDP gradient exchange
+    def _flat_views(self, early_names=()):
+        """One flat f32 bucket for all encoder gradients: the parameters named in `early_names` first (their gradients exist
+        long before the backward ends), the rest after; returns {name: view}."""
+        lay = getattr(self, "_layout", None)
+        if lay is None or lay["early"] != tuple(early_names):
+            named = dict(self.E.named_parameters())
+            order = [n for n in early_names if n in named] + [n for n in named if n not in set(early_names)]
+            n_early = sum(named[n].numel() for n in early_names if n in named)
+            total = sum(p.numel() for p in named.values())
+            self._flat = torch.empty(total, dtype=torch.float32, device=self.dev)
+            views, off = {}, 0
+            for n in order:
+                views[n] = self._flat[off:off + named[n].numel()].view_as(named[n])
+                off += named[n].numel()
+            lay = self._layout = dict(early=tuple(early_names), views=views, n_early=n_early, named=named)
+        return lay
+
+    def early_reduce(self, grads):
+        """Called from inside the encoder backward as soon as the gradients of the deep (512-channel) blocks exist: > 90 % of
+        the 97 MB bucket.  Their all-reduce is issued asynchronously (RCCL's own stream) and runs under the backward of the
+        high-resolution blocks, which is most of the backward's time; `_sync_grads` exchanges the remainder and joins."""
+        if not getattr(self, "dist_on", self.world > 1) or not grads:
+            return
+        lay = self._flat_views(tuple(grads.keys()))
+        names = [n for n in lay["early"] if grads.get(n) is not None]
+        if len(names) != len(lay["early"]):
+            return                                          # a different set than the layout was built for: leave it to _sync_grads
+        torch._foreach_copy_([lay["views"][n] for n in names], [grads[n] for n in names])
+        self._early_work = dist.all_reduce(self._flat[:lay["n_early"]], op=dist.ReduceOp.SUM, async_op=True)
+
     def _sync_grads(self):
-        """All-reduce (sum) of every encoder gradient as one flat bucket; p.grad become views."""
+        """All-reduce (sum) of every encoder gradient through the flat bucket; p.grad become views of it."""
         if not getattr(self, "dist_on", self.world > 1):
             return None
-        ps = [p for p in self.E.parameters() if p.grad is not None]
-        n = sum(p.numel() for p in ps)
-        if self._flat is None or self._flat.numel() != n:
-            self._flat = torch.empty(n, dtype=torch.float32, device=self.dev)
-        off = 0
-        views = []
-        for p in ps:
-            views.append(self._flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        work = self.__dict__.pop("_early_work", None)
+        lay = self._flat_views(self._layout["early"] if (work is not None) else getattr(self, "_layout", {"early": ()})["early"])
+        early = set(lay["early"]) if work is not None else set()
+        rest = [(n, p) for n, p in lay["named"].items() if p.grad is not None and n not in early]
         # one multi-tensor copy instead of ~100 small ones (they sit on the critical path in front of the collective)
-        torch._foreach_copy_(views, [p.grad for p in ps])
-        dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
-        for p, v in zip(ps, views):
-            p.grad = v
+        if rest:
+            torch._foreach_copy_([lay["views"][n] for n, _ in rest], [p.grad for _, p in rest])
+        missing = [n for n, p in lay["named"].items() if p.grad is None and n not in early]
+        for n in missing:                                   # parameters without a gradient this phase contribute zeros
+            lay["views"][n].zero_()
+        if work is not None:
+            dist.all_reduce(self._flat[lay["n_early"]:], op=dist.ReduceOp.SUM)
+            work.wait()
+        else:
+            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+        for n, p in lay["named"].items():
+            if p.grad is not None:
+                p.grad = lay["views"][n]
         # exact mode: every rank differentiated the GLOBAL loss w.r.t. its own samples -> sum.
         # plain mode: local losses -> mean.
         return None if self.exact_ddp else torch.full((1,), 1.0 / self.world, device=self.dev)

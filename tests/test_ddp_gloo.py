@@ -51,13 +51,27 @@ def _worker(rank, world, port, q):
         p.grad = torch.full_like(p, float(rank + 1))
     gs = st._sync_grads()
     ok3 = abs(float(gs) - 0.5) < 1e-7
+    # --- early bucket: part of the gradients is reduced asynchronously from inside the backward, the rest in _sync_grads
+    st2 = EAlignStep.__new__(EAlignStep)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    st2.E, st2.world, st2.rank, st2.exact_ddp, st2.dev, st2._flat, st2.dist_on = net, world, rank, True, torch.device("cpu"), None, True
+    ok5 = True
+    for phase in range(2):                                   # two phases per step re-use the layout
+        for i_, p in enumerate(net.parameters()):
+            p.grad = torch.full_like(p, float((rank + 1) * (i_ + 1) + phase))
+        early = {n: p.grad.clone() for n, p in net.named_parameters() if n.startswith("1.")}
+        st2.early_reduce(early)
+        st2._sync_grads()
+        for i_, p in enumerate(net.parameters()):
+            want = float(sum((r + 1) * (i_ + 1) + phase for r in range(world)))
+            ok5 = ok5 and torch.allclose(p.grad, torch.full_like(p, want)) and p.grad.data_ptr() >= st2._flat.data_ptr()
     # every rank must draw the same global z and take its own slice
     from dge_amd.e_align import set_seed
     set_seed(7)
     zg = torch.randn(2 * world, 8)
     t = zg.clone(); dist.broadcast(t, 0)
     ok4 = torch.equal(t, zg)
-    q.put((rank, ok1, ok2, ok3, ok4))
+    q.put((rank, ok1, ok2, ok3, ok4, ok5))
     dist.destroy_process_group()
 
 
