@@ -226,7 +226,9 @@ def test_hip_e_blur_gradients_vs_reference_golden(cd):
     assert abs(float(loss) - float(g["loss"])) < (2e-4 if cd == "f32" else 0.1) * abs(float(g["loss"]))
     named = {k: p.grad for k, p in E.named_parameters()}
     if cd == "f32":
-        _check_blur_grads(named, img.grad, g, 3e-3, 3e-3)
+        # 1e-2 for the per-tensor L2 (see test_hip_e_pg_gradients_vs_reference_golden: leaky-relu kink flips move the small
+        # bias / noise-weight reductions by up to ~5e-3 from run to run); typical values are 1e-4 .. 2e-3
+        _check_blur_grads(named, img.grad, g, 1e-2, 3e-3)
     else:
         # bf16 activations and bf16-stored gradients: per-tensor L2 within 25 % (worst: the 64-element bias / noise-weight
         # reductions of the deep blocks), the f32 run above is the parity check of the formulas
