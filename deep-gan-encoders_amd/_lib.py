@@ -91,6 +91,15 @@ SIGNATURES = {
     "dge_slice_up": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dge_rgb_tanh": [_P, _P, _I, _I, _I, _I, _P],
+    "dge_guided_relu_bwd": [_P, _P, _P, C.c_long, _I, _I, _P],
+    "dge_adaptive_pool7": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dge_adaptive_pool7_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dge_class_target": [_P, _P, _P, _P, _I, _I, _P],
+    "dge_gather_row": [_P, _P, _P, _I, _I, _F, _P],
+    "dge_campp_map": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dge_cam_resize": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dge_mask2cam_blocks": [_I],
+    "dge_mask2cam": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "dge_version": [],
 }
 

@@ -89,7 +89,7 @@ __global__ void wsq_kernel(const float* __restrict__ w, float* __restrict__ wsq,
 // y[b][o] = act( (sum_i f(x[b][i]) * W[o][i]) * wscale + bias[o]*bscale + add ) * gain
 // f = identity or square (square: demodulation d = rsqrt(s^2 . wsq + eps) with act = rsqrt).
 // x rows may be strided (ldx) so a [B, L, 512] wp tensor can be indexed per layer.
-enum { LIN_ACT_NONE = 0, LIN_ACT_LRELU = 1, LIN_ACT_RSQRT = 3 };
+enum { LIN_ACT_NONE = 0, LIN_ACT_LRELU = 1, LIN_ACT_RELU = 2, LIN_ACT_RSQRT = 3 };
 __global__ void linear_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                               const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int I, int O,
                               float wscale, float bscale, float add, int act, float gain, int square) {
@@ -104,6 +104,7 @@ __global__ void linear_kernel(const float* __restrict__ x, int ldx, const float*
     if (lane == 0) {
         float v = s * wscale + (bias ? bias[o] * bscale : 0.f) + add;
         if (act == LIN_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        else if (act == LIN_ACT_RELU) v = v > 0.f ? v : 0.f;
         else if (act == LIN_ACT_RSQRT) v = rsqrtf(v);
         y[(size_t)b * ldy + o] = v * gain;
     }

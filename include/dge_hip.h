@@ -297,6 +297,33 @@ int dge_softmax_rows_bwd(const void* P, void* gP, long R, int M, int dtype, dge_
 /* backward of dge_rgb_tanh (:251-254): gy [B,HW,C] NHWC, channels >= 3 zero */
 int dge_rgb_tanh_bwd(const float* gimg, const float* img, void* gy, int B, int HW, int C, int dtype, dge_stream_t stream);
 
+/* ---- Grad-CAM++ attention maps (metric/grad_cam.py; wired by E_mis_align_cropping_s1.py:99-106,159-170).  The VGG16
+ * convolutions of the classifier run on dge_conv2d (forward, data gradient), its dense layers on dge_linear / dge_linear_t. */
+/* gpre = (a > 0 && (!guided || g > 0)) ? g : 0 over n elements: nn.ReLU backward + GuidedBackPropagation.backward_hook
+ * (grad_cam.py:208-217, clamp(grad_in, min=0)); a = the ReLU's output */
+int dge_guided_relu_bwd(const void* g, const void* a, void* gpre, long n, int guided, int dtype, dge_stream_t stream);
+/* vgg16.avgpool + torch.flatten: x NHWC [B,H,W,C] -> y [B, C*49] f32 in (c, i, j) order; and its adjoint */
+int dge_adaptive_pool7(const void* x, float* y, int B, int H, int W, int C, int dtype, dge_stream_t stream);
+int dge_adaptive_pool7_bwd(const float* gy, void* gx, int B, int H, int W, int C, int dtype, dge_stream_t stream);
+/* grad_cam.py:166-170: index = per-row argmax of logits [B,K] (or index_in [B] when given), index_max = its most frequent
+ * value (smallest on ties) -> index_out[0] (index_out[1..B] = the per-row indices); glogits [B,K] = d mean_n logits[n,index_max] */
+int dge_class_target(const float* logits, const int* index_in, int* index_out, float* glogits, int B, int K, dge_stream_t stream);
+/* y[b,:] = scale * w[index[0], :]  (w [O,I] f32, index on the device) */
+int dge_gather_row(const float* w, const int* index, float* y, int B, int I, float scale, dge_stream_t stream);
+/* per sample, mode 1 = Grad-CAM++ (grad_cam.py:180-191): weight[c] = sum relu(grad) * 1/sum relu(grad) (0 when the sum is 0),
+ * cam[p] = sum_c feat[p,c]*weight[c]; mode 0 = Grad-CAM (:101-105): weight[c] = mean grad, cam = relu(sum).  wgt [B,C],
+ * cam [B,HW], minmax [B,2] = (min, max) of cam.  grad / feat NHWC [B,HW,C] */
+int dge_campp_map(const void* grad, const void* feat, float* wgt, float* cam, float* minmax, int B, int HW, int C, int mode,
+                  int dtype, dge_stream_t stream);
+/* mask [B,1,H,W] = cv2.resize((cam - min) / (max - min), (W, H)) with INTER_LINEAR geometry (grad_cam.py:190-193) */
+int dge_cam_resize(const float* cam, const float* minmax, float* mask, int B, int h, int w, int H, int W, dge_stream_t stream);
+/* mask2cam (grad_cam.py:234-251): heat [B,3,H,W] = lut[uint8(255*mask)] / 255 (lut: 256 x (r,g,b) ints), cam = heat + img,
+ * then the reference's sequential normalisation (minimum over the whole array as it stands when sample i is reached).
+ * part: scratch [B, dge_mask2cam_blocks(HW), 3] f32, coef: scratch [B,2] f32 */
+int dge_mask2cam_blocks(int HW);
+int dge_mask2cam(const float* mask, const float* img, const int* lut, float* heat, float* cam, float* part, float* coef, int B,
+                 int HW, dge_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

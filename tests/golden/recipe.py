@@ -130,3 +130,16 @@ def fill_encbig(shapes: dict, seed: int) -> dict:
     out = fill_encoder(rest, seed)
     out.update(fill_biggan(bn, seed))
     return {k: out[k] for k in shapes}
+
+
+# Grad-CAM++ attention path (reference metric/grad_cam.py on a vgg16-layout classifier): narrow stand-in widths,
+# an input whose last-conv map is 6x6 and whose pooled map (3x3) is *smaller* than the 7x7 adaptive pool target.
+GRADCAM_CFG = dict(widths=(32, 32, "M", 32, 32, "M", 64, 64, 64, "M", 64, 64, 64, "M", 64, 64, 64, "M"),
+                   fc=128, classes=40, seed=3, N=3, H=96, W=96)
+
+
+def gradcam_images(tag: str, N: int, H: int, W: int) -> torch.Tensor:
+    """Smooth-ish images in [-1,1] (low-resolution noise upsampled + fine noise)."""
+    lo = randn("gradcam.lo." + tag, (N, 3, H // 8, W // 8), 0, 0.8)
+    up = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+    return (up + randn("gradcam.hi." + tag, (N, 3, H, W), 0, 0.15)).clamp(-1, 1)
