@@ -101,6 +101,13 @@ class LPIPS(nn.Module):
         """a, b: [B,3,h,w] f32 in [-1,1].  Returns (mean over the batch of LPIPS(a,b) as a [1]
         device tensor, d mean / d b  [B,3,h,w] f32 or None)."""
         dt = _dt(self.compute_dtype)
+        if a.shape[1] == 1:
+            # single-channel maps (the Grad-CAM masks of E_mis_align_cropping_s1.py:182): lpips' ScalingLayer broadcasts
+            # them against its [1,3,1,1] constants, i.e. the map is fed as three identical channels
+            if need_grad:
+                raise ValueError("LPIPS gradient of a single-channel input is not provided (the reference never uses it)")
+            a = a.expand(-1, 3, -1, -1).contiguous()
+            b = b.expand(-1, 3, -1, -1).contiguous()
         B, _, h, w = a.shape
         dev = a.device
         L = lib()

@@ -167,3 +167,59 @@ def test_full_size_vgg16_properties():
     c = cam.cpu().numpy()
     assert abs(c[0].max() - 1.0) < 1e-5 and abs(c[1].max() - 1.0) < 1e-5 and np.isfinite(c).all()
     assert heat.min() >= 0 and heat.max() <= 1
+
+
+@pytest.mark.gpu
+def test_mis_align_iteration_matches_reference_run():
+    """Two iterations of E_mis_align_cropping_s1.py's loop body (mtype 2) against the reference's own run of it
+    (tests/golden/step_misalign.npz, tools/gen_golden_gradcam.py): masks, the four logged image-space losses, the latent
+    loss and the encoder parameters after the (latent-only) update."""
+    import dge_amd
+    from dge_amd.encoder import BE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.mis_align import MisAlignStep
+    from tests.helpers import s2_shapes, enc_shapes
+    from oracle import ref_torch as O
+    from oracle import lpips_ref as LR
+    g = golden("step_misalign.npz")
+    Gen = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="f32").cuda()
+    Gen.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+    Gen.train()
+    for p in Gen.parameters():
+        p.requires_grad_(False)
+    E = BE(startf=16, maxf=64, layer_count=5, compute_dtype="f32").cuda()
+    E.load_state_dict(R.fill_encoder(enc_shapes(16, 64, 5), seed=31))
+    LP = LPIPS(compute_dtype="f32").cuda()
+    LP.load_state_dict(LR.seeded_params(0))
+    _, net = _net("f32")
+    st = MisAlignStep(Gen, E, LP, net, lr=0.0015, batch_size=2)
+    new_z = R.randn("step.new_z", (2, 512), 1).cuda()
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **kw: new_z.clone()
+    rel = lambda a, b: float(np.abs(np.asarray(a) - b).max() / (np.abs(b).max() + 1e-30))
+    try:
+        for it in range(2):
+            z = R.randn(f"step.z{it}", (2, 512), 1)
+            noises = [R.randn(f"step.it{it}.noise{i}", s, 1).cuda() for i, s in enumerate(O.enc_noise_shapes(5, 2, 64))]
+            r = st.step(it, z=z, noises=noises)
+            assert rel(r["w2"].cpu().numpy(), g[f"it{it}_w2"]) < 2e-3
+            for k in ("mask_1", "mask_2"):
+                assert np.abs(r[k].cpu().numpy() - g[f"it{it}_{k}"]).max() < 5e-3, (it, k)
+            ref_l = g[f"it{it}_losses"]          # loss_tsa, imgs, mask, Gcam, grad, w
+            got = [float(r["loss_tsa"]), float(r["info_imgs"][0]), float(r["info_mask"][0]), float(r["info_Gcam"][0]),
+                   float(r["info_grad"][0]), float(r["loss_w"])]
+            for a, b in zip(got, ref_l):
+                assert abs(a - b) < 5e-3 * abs(b), (it, got, ref_l)
+            ref_info = g[f"it{it}_info"]         # rows imgs, mask, Gcam, grad, w; columns mse, mean, std, kl, cos, ssim, lpips
+            for row, key in enumerate(("info_imgs", "info_mask", "info_Gcam", "info_grad")):
+                info = r[key].cpu().numpy()
+                for col in (0, 4, 5, 6):
+                    assert abs(info[1 + col] - ref_info[row, col]) < 1e-2 * abs(ref_info[row, col]) + 1e-6, (it, key, col)
+            sd = E.state_dict()
+            for key in g.files:
+                if key.startswith(f"it{it}_after:"):
+                    assert rel(sd[key.split(":", 1)[1]].cpu().numpy(), g[key]) < 1e-4, (it, key)
+            cs = float(g[f"it{it}_param_checksum"])
+            assert abs(R.checksum({k: v.cpu() for k, v in sd.items()}) - cs) < 1e-5 * cs
+    finally:
+        torch.randn_like = orig
