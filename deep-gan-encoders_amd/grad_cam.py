@@ -214,13 +214,9 @@ class GradCAM(object):
     def remove_handlers(self):
         pass
 
-    def __call__(self, inputs, index):
-        logits, st = self.net.run(inputs)
-        self.index, _ = self.net.select_target(logits, index)
-        self.gradient = self.net.backward_to_last_conv(st, self.index)
-        self.feature = st["acts"][-1]
+    def _mask(self, st):
         N, h, w, Cc = self.feature.shape
-        dev = inputs.device
+        dev = self.feature.device
         wgt = torch.empty((N, Cc), dtype=torch.float32, device=dev)
         cam = torch.empty((N, h * w), dtype=torch.float32, device=dev)
         mm = torch.empty((N, 2), dtype=torch.float32, device=dev)
@@ -229,6 +225,26 @@ class GradCAM(object):
         mask = torch.empty((N, 1, st["H"], st["W"]), dtype=torch.float32, device=dev)
         check(lib().dge_cam_resize(_f32(cam), _f32(mm), _f32(mask), N, h, w, st["H"], st["W"], _stream()), "dge_cam_resize")
         return mask
+
+    def __call__(self, inputs, index):
+        logits, st = self.net.run(inputs)
+        self.index, _ = self.net.select_target(logits, index)
+        self.gradient = self.net.backward_to_last_conv(st, self.index)
+        self.feature = st["acts"][-1]
+        return self._mask(st)
+
+    def with_input_gradient(self, inputs, index=None):
+        """(mask, d target / d inputs) from ONE forward and ONE backward.  The script calls `grad_cam_plus_plus(imgs, None)`
+        and `gbp(imgs_)` on the same images (E_mis_align_cropping_s1.py:159-168): two forward and two backward passes of
+        the same network towards the same target, the first backward being a prefix of the second.  Needs the guided
+        network (a GuidedBackPropagation object constructed on it), as the input gradient is the guided one."""
+        if not self.net.guided:
+            raise DgeError("with_input_gradient: construct GuidedBackPropagation(net) first (the input gradient is the guided one)")
+        logits, st = self.net.run(inputs)
+        self.index, _ = self.net.select_target(logits, index)
+        self.gradient = self.net.backward_to_last_conv(st, self.index)
+        self.feature = st["acts"][-1]
+        return self._mask(st), self.net.backward_to_input(st, self.gradient)
 
 
 class GradCamPlusPlus(GradCAM):

@@ -15,12 +15,13 @@ from .grad_cam import GradCamPlusPlus, GuidedBackPropagation, mask2cam
 
 
 class MisAlignStep(EAlignStep):
-    def __init__(self, generator, E, lpips_model, vgg16, **kw):
+    def __init__(self, generator, E, lpips_model, vgg16, fused_attention=True, **kw):
         """`vgg16`: dge_amd.grad_cam.VGG16 (torchvision vgg16 layout), shared by Grad-CAM++ and guided back-propagation
         as in E_mis_align_cropping_s1.py:99-106."""
         super().__init__(generator, E, lpips_model, **kw)
         self.grad_cam_plus_plus = GradCamPlusPlus(vgg16, vgg16.final_layer)
         self.gbp = GuidedBackPropagation(vgg16)
+        self.fused_attention = fused_attention
 
     def step(self, iteration, z=None, noises=None, gen_noises=(None, None)):
         E = self.E
@@ -43,10 +44,14 @@ class MisAlignStep(EAlignStep):
         with torch.no_grad():
             imgs2 = self.gen.synth(w2.detach(), gen_noises[1])
             # attention maps (:159-170)
-            mask_1 = self.grad_cam_plus_plus(imgs1, None)
-            mask_2 = self.grad_cam_plus_plus(imgs2, None)
-            grad_1 = self.gbp(imgs1)
-            grad_2 = self.gbp(imgs2)
+            if self.fused_attention:       # one forward + one backward per batch instead of two of each (same results)
+                mask_1, grad_1 = self.grad_cam_plus_plus.with_input_gradient(imgs1)
+                mask_2, grad_2 = self.grad_cam_plus_plus.with_input_gradient(imgs2)
+            else:
+                mask_1 = self.grad_cam_plus_plus(imgs1, None)
+                mask_2 = self.grad_cam_plus_plus(imgs2, None)
+                grad_1 = self.gbp(imgs1)
+                grad_2 = self.gbp(imgs2)
             heat_1, cam_1 = mask2cam(mask_1, imgs1)
             heat_2, cam_2 = mask2cam(mask_2, imgs2)
             gctx = losses.GlobalBatch(self.world) if (self.dist_on and self.exact_ddp) else None

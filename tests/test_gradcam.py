@@ -110,6 +110,8 @@ def test_gradcampp_gbp_mask2cam_f32_vs_reference(tag):
     assert np.abs(gcpp(imgs, np.array([3] * CFG["N"])).cpu().numpy() - g["mask_idx_" + tag]).max() < 2e-3
     gi, gir = gbp(imgs).cpu().numpy(), g["gbp_" + tag]
     assert np.abs(gi - gir).max() < 3e-3 * np.abs(gir).max()
+    m2, gi2 = gcpp.with_input_gradient(imgs)                 # shared forward/backward: identical results
+    assert torch.equal(m2, mask) and np.array_equal(gi2.cpu().numpy(), gi)
     # mask2cam on the reference's mask (isolates it from the network): the JET index is uint8(255*mask) by truncation,
     # so a pixel whose 255*mask sits within rounding of an integer may take the neighbouring table entry (one step is
     # <= 4/255 per channel); everything else is exact to f32 rounding
