@@ -147,10 +147,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
         }
         __syncthreads();
         if (tile + ntile_groups < ntiles) load_tile(tile + ntile_groups);   // flies under the MFMAs
-        // ---- MFMA: wave w owns tile rows {2w, 2w+1}
+        // ---- MFMA: wave w owns tile rows {RW*w .. RW*w + RW-1}
+        constexpr int RW = TH / 4;
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int row = 2 * wave + rr;
+        for (int rr = 0; rr < RW; rr++) {
+            const int row = RW * wave + rr;
             if constexpr (sizeof(T) == 2) {
                 const uint4 a = *(const uint4*)(lg + m * GPIT + row * TW + kg * 8);
 #pragma unroll
@@ -200,12 +201,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const T* __restrict__ g
 // The x window of a kernel row is read once as 12 pixels; the dx = 1, 2 fragments are register
 // shifts of it (v_alignbit / renaming), so 3 + 2 LDS reads feed 3 MFMAs.
 typedef short v4s_t __attribute__((ext_vector_type(4)));
-template <int KS>
+template <int KS, int TH>
 __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ X,
                                                              const float* __restrict__ sc, const float* __restrict__ sh,
                                                              float* __restrict__ dW, int B, int H, int W, int Co, int Ci,
                                                              int tiles_x, int tiles_y, int ntile_groups) {
-    constexpr int TH = 8, TW = 16, HALO = KS / 2, HH = TH + 2 * HALO, HW = TW + 2 * HALO;
+    // TH x 16 pixel tiles.  TH = 16 wherever the image has 16 rows: a wave then issues 36 instead of 18 MFMAs between
+    // the two barriers of a tile, which is what the per-tile overhead (LDS fill, barriers, fragment latency) is paid against.
+    constexpr int TW = 16, HALO = KS / 2, HH = TH + 2 * HALO, HW = TW + 2 * HALO;
     constexpr int NTAP = KS * KS;
     constexpr int LG_BYTES = TH * TW * 64, LX_BYTES = (HH * HW + 4) * 64;     // +4 pixels: the 12-pixel window of the last row over-reads
     constexpr int FL_BYTES = (4096 + 1024 * NTAP) * 4;      // flush staging (wgrad_flush)
@@ -291,10 +294,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const bf16_t* __rest
         }
         __syncthreads();
         if (tile + ntile_groups < ntiles) load_tile(tile + ntile_groups);   // flies under the MFMAs
-        // ---- MFMA: wave w owns tile rows {2w, 2w+1}
+        // ---- MFMA: wave w owns tile rows {RW*w .. RW*w + RW-1}
+        constexpr int RW = TH / 4;
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int row = 2 * wave + rr;
+        for (int rr = 0; rr < RW; rr++) {
+            const int row = RW * wave + rr;
             const unsigned char* ga = lg + row * TW * 64 + frag_off;
             const v4s_t a0 = trd(ga, 0), a1 = trd(ga, 4 * 64);
             const uint2 a01 = *(const uint2*)&a0, a23 = *(const uint2*)&a1;
@@ -575,15 +579,18 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(cout % ep == 0 && cin % ep == 0, "conv_wgrad: channels must be multiples of %d", ep);
     DGE_CHECK((in_scale == nullptr) == (in_shift == nullptr), "conv_wgrad: in_scale and in_shift go together");
-    const int tx = (W + 15) / 16, ty = (H + 7) / 8;
+    const bool tall = dtype == DGE_BF16 && H >= 16 && !getenv("DGE_WGRAD_TH8");
+    const int tx = (W + 15) / 16, ty = tall ? (H + 15) / 16 : (H + 7) / 8;
     const int ntiles = tx * ty * B;
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
     int groups = 512 / noi; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;   // few, long-running workgroups: one atomic flush each
     dim3 grid(noi, groups);
 #define WG(T, KS) hipLaunchKernelGGL((conv_wgrad_kernel<T, KS>), grid, dim3(256), 0, s, (const T*)g, (const T*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups)
     if (dtype == DGE_BF16) {
-        if (ksize == 3) hipLaunchKernelGGL((conv_wgrad_tr_kernel<3>), grid, dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups);
-        else hipLaunchKernelGGL((conv_wgrad_tr_kernel<1>), grid, dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups);
+#define WT(KS, TH) hipLaunchKernelGGL((conv_wgrad_tr_kernel<KS, TH>), grid, dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups)
+        if (ksize == 3) { if (tall) WT(3, 16); else WT(3, 8); }
+        else { if (tall) WT(1, 16); else WT(1, 8); }
+#undef WT
     }
     else { if (ksize == 3) WG(float, 3); else WG(float, 1); }
 #undef WG
