@@ -92,6 +92,7 @@ SIGNATURES = {
     "dge_attention": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dge_rgb_tanh": [_P, _P, _I, _I, _I, _I, _P],
     "dge_guided_relu_bwd": [_P, _P, _P, C.c_long, _I, _I, _P],
+    "dge_maxpool2_relu_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dge_adaptive_pool7": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dge_adaptive_pool7_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dge_class_target": [_P, _P, _P, _P, _I, _I, _P],

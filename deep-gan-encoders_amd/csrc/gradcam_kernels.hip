@@ -101,21 +101,24 @@ __global__ void gather_row_kernel(const float* __restrict__ w, const int* __rest
 }
 
 // Channel weights.  Grad-CAM++ (mode 1, grad_cam.py:180-186): s = sum_hw relu(g); weight = s > 0 ? s * (1/s) : 0.
-// Grad-CAM (mode 0, :101-102): weight = mean_hw g.  grid (C/64, B); 4 waves split the pixels, lane = channel.
+// Grad-CAM (mode 0, :101-102): weight = mean_hw g.  grid (C/64, B); 16 waves split the pixels, lane = channel (the grid is
+// small - 64 workgroups for 8 x 512 channels - so each workgroup brings many waves to hide the load latency).
 template <typename T>
-__global__ void campp_weight_kernel(const T* __restrict__ g, float* __restrict__ wgt, int HW, int C, int mode) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void campp_weight_kernel(const T* __restrict__ g, float* __restrict__ wgt, int HW, int C, int mode) {
+    __shared__ float red[16][64];
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
     float s = 0.f;
     if (c < C)
-        for (int p = wv; p < HW; p += 4) {
+        for (int p = wv; p < HW; p += 16) {
             const float v = Elem<T>::ld(g + ((size_t)b * HW + p) * C + c);
             s += mode ? fmaxf(v, 0.f) : v;
         }
     red[wv][threadIdx.x & 63] = s;
     __syncthreads();
     if (wv == 0 && c < C) {
-        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; k++) s += red[k][threadIdx.x];
         wgt[(size_t)b * C + c] = mode ? (s > 0.f ? s * (1.0f / s) : 0.f) : s / (float)HW;
     }
 }
@@ -306,10 +309,10 @@ extern "C" int dge_campp_map(const void* grad, const void* feat, float* wgt, flo
     DGE_CHECK(B >= 1 && HW >= 1 && C % ep == 0, "campp_map: B=%d HW=%d C=%d (C %% %d)", B, HW, C, ep);
     dim3 gw((C + 63) / 64, B), gs((HW + 3) / 4, B);
     if (dtype == DGE_BF16) {
-        hipLaunchKernelGGL(campp_weight_kernel<bf16_t>, gw, dim3(256), 0, s, (const bf16_t*)grad, wgt, HW, C, mode);
+        hipLaunchKernelGGL(campp_weight_kernel<bf16_t>, gw, dim3(1024), 0, s, (const bf16_t*)grad, wgt, HW, C, mode);
         hipLaunchKernelGGL(campp_sum_kernel<bf16_t>, gs, dim3(256), 0, s, (const bf16_t*)feat, wgt, cam, HW, C, mode == 0);
     } else {
-        hipLaunchKernelGGL(campp_weight_kernel<float>, gw, dim3(256), 0, s, (const float*)grad, wgt, HW, C, mode);
+        hipLaunchKernelGGL(campp_weight_kernel<float>, gw, dim3(1024), 0, s, (const float*)grad, wgt, HW, C, mode);
         hipLaunchKernelGGL(campp_sum_kernel<float>, gs, dim3(256), 0, s, (const float*)feat, wgt, cam, HW, C, mode == 0);
     }
     hipLaunchKernelGGL(row_minmax_kernel, dim3(B), dim3(256), 0, s, cam, minmax, HW);

@@ -55,9 +55,10 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int B
     *(uint4*)(y + (((size_t)b * OH + oy) * OW + ox) * C + ch * EP) = pack16(f0, (T*)nullptr);
 }
 // gx[b,p,c] = (p is the first arg-max of its window ? gy[window] : 0) + addend[b,p,c]
+// relu_mode (x = output of a ReLU): 1 = followed by that ReLU's backward (x > 0), 2 = by the guided form (x > 0 and g > 0)
 template <typename T>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ x, const T* __restrict__ addend,
-                                   T* __restrict__ gx, int B, int H, int W, int C) {
+                                   T* __restrict__ gx, int B, int H, int W, int C, int relu_mode) {
     constexpr int EP = Elem<T>::PER16;
     const int OH = H / 2, OW = W / 2, cpt = C / EP;
     const long n = (long)B * H * W * cpt;
@@ -84,6 +85,8 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ gy, const T* __restrict
 #pragma unroll
             for (int q = 1; q < 4; q++) if (f[q][e] > mv) { mv = f[q][e]; am = q; }
             if (am == me) out[e] = g[e];
+            // (the gradient lands on the arg-max only, whose value is mv)
+            if (relu_mode && !(mv > 0.f && (relu_mode == 1 || out[e] > 0.f))) out[e] = 0.f;
         }
     }
     if (addend) {
@@ -204,15 +207,26 @@ extern "C" int dge_maxpool2(const void* x, void* y, int B, int H, int W, int C, 
     return 0;
 }
 
-extern "C" int dge_maxpool2_bwd(const void* gy, const void* x, const void* addend, void* gx, int B, int H, int W, int C, int dtype,
-                                hipStream_t s) {
+static int maxpool2_bwd_launch(const void* gy, const void* x, const void* addend, void* gx, int B, int H, int W, int C, int relu_mode,
+                               int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0, "maxpool2_bwd: C %% %d != 0", ep);
+    DGE_CHECK(H % 2 == 0 && W % 2 == 0 || relu_mode == 0, "maxpool2_relu_bwd: H and W must be even");
     const long n = (long)B * H * W * (C / ep);
-    if (dtype == DGE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)gx, B, H, W, C);
-    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gy, (const float*)x, (const float*)addend, (float*)gx, B, H, W, C);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)gx, B, H, W, C, relu_mode);
+    else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gy, (const float*)x, (const float*)addend, (float*)gx, B, H, W, C, relu_mode);
     DGE_LAUNCH_CHECK("maxpool2_bwd");
     return 0;
+}
+
+extern "C" int dge_maxpool2_bwd(const void* gy, const void* x, const void* addend, void* gx, int B, int H, int W, int C, int dtype,
+                                hipStream_t s) {
+    return maxpool2_bwd_launch(gy, x, addend, gx, B, H, W, C, 0, dtype, s);
+}
+
+extern "C" int dge_maxpool2_relu_bwd(const void* gy, const void* x, void* gx, int B, int H, int W, int C, int guided, int dtype,
+                                     hipStream_t s) {
+    return maxpool2_bwd_launch(gy, x, nullptr, gx, B, H, W, C, guided ? 2 : 1, dtype, s);
 }
 
 template <typename T>

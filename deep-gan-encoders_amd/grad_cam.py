@@ -147,6 +147,14 @@ class VGG16(nn.Module):
               "dge_guided_relu_bwd")
         return out
 
+    def _pool_relu_bwd(self, gy, a):
+        """MaxPool2d(2,2) backward + the (guided) backward of the ReLU that produced `a`, one pass."""
+        B, H, W, Cc = a.shape
+        out = torch.empty_like(a)
+        check(lib().dge_maxpool2_relu_bwd(_p(gy), _p(a), _p(out), B, H, W, Cc, 1 if self.guided else 0, ops.dtype_of(a), _stream()),
+              "dge_maxpool2_relu_bwd")
+        return out
+
     def backward_to_last_conv(self, st, index_dev):
         """Gradient of the target w.r.t. the OUTPUT of the last conv (pre-ReLU), NHWC [N,h,w,C] - what the backward hook
         on `features.28` receives (grad_cam.py:30-40)."""
@@ -164,8 +172,7 @@ class VGG16(nn.Module):
         gpool = torch.empty((N, Hp, Wp, Cp), dtype=ops.tdtype(dt), device=dev)
         check(L.dge_adaptive_pool7_bwd(_f32(gflat), _p(gpool), N, Hp, Wp, Cp, dt, _stream()), "dge_adaptive_pool7_bwd")
         last = st["acts"][-1]
-        g = ops.maxpool2_bwd(gpool, last) if self.plan[-1][0] == "pool" else gpool
-        return self._relu_bwd(g, last)
+        return self._pool_relu_bwd(gpool, last) if self.plan[-1][0] == "pool" else self._relu_bwd(gpool, last)
 
     def backward_to_input(self, st, gpre_last):
         """Continues the (guided) backward from the last conv's output down to the image: [N,3,H,W] f32."""
@@ -183,11 +190,11 @@ class VGG16(nn.Module):
             if ci == 0:
                 break
             k -= 1
-            if self.plan[k][0] == "pool":                    # conv ci read the pooled output of conv ci-1
-                g = ops.maxpool2_bwd(g, acts[ci - 1])
+            pooled = self.plan[k][0] == "pool"               # conv ci read the pooled output of conv ci-1
+            if pooled:
                 k -= 1
             ci -= 1
-            g = self._relu_bwd(g, acts[ci])
+            g = self._pool_relu_bwd(g, acts[ci]) if pooled else self._relu_bwd(g, acts[ci])
         gimg = torch.empty((N, 3, H, W), dtype=torch.float32, device=g.device)
         one = (C.c_float * 3)(1, 1, 1)
         check(lib().dge_lpips_prep_bwd(_p(g), _p(gimg), N, H * W, _CPAD, one, 1.0, 0, dt, _stream()), "dge_lpips_prep_bwd")

@@ -302,6 +302,9 @@ int dge_rgb_tanh_bwd(const float* gimg, const float* img, void* gy, int B, int H
 /* gpre = (a > 0 && (!guided || g > 0)) ? g : 0 over n elements: nn.ReLU backward + GuidedBackPropagation.backward_hook
  * (grad_cam.py:208-217, clamp(grad_in, min=0)); a = the ReLU's output */
 int dge_guided_relu_bwd(const void* g, const void* a, void* gpre, long n, int guided, int dtype, dge_stream_t stream);
+/* MaxPool2d(2,2) backward followed by the backward of the ReLU that produced x (guided: grad_cam.py:208-217), one pass */
+int dge_maxpool2_relu_bwd(const void* gy, const void* x, void* gx, int B, int H, int W, int C, int guided, int dtype,
+                          dge_stream_t stream);
 /* vgg16.avgpool + torch.flatten: x NHWC [B,H,W,C] -> y [B, C*49] f32 in (c, i, j) order; and its adjoint */
 int dge_adaptive_pool7(const void* x, float* y, int B, int H, int W, int C, int dtype, dge_stream_t stream);
 int dge_adaptive_pool7_bwd(const float* gy, void* gx, int B, int H, int W, int C, int dtype, dge_stream_t stream);
