@@ -192,15 +192,21 @@ def main():
         for i in range(2):
             st.step(1000 + i)
         torch.cuda.synchronize()
-        fl, ms, ab = 0.0, 0.0, 0.0
+        peak = 2500.0 if a.dtype == "bf16" else 157.3
+        hbm_peak = 8.0e12
+        fl, ms, ab, roof_ms, n_hbm = 0.0, 0.0, 0.0, 0.0, 0
         for (e0, e1, flops, tag, abytes) in ops.PROFILE:
             fl += flops
             ab += abytes
             ms += e0.elapsed_time(e1)
+            # per-launch roofline time: the larger of the MFMA time of its algorithmic flops and the HBM time of its
+            # algorithmic bytes (the 512^2 / 1024^2 layers sit under the ridge and are HBM-bound)
+            t_mfma, t_hbm = flops / (peak * 1e12), abytes / hbm_peak
+            roof_ms += max(t_mfma, t_hbm) * 1e3
+            n_hbm += 1 if t_hbm > t_mfma else 0
         nlaunch = len(ops.PROFILE)
         ops.PROFILE = None
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        peak = 2500.0 if a.dtype == "bf16" else 157.3
         # HBM bytes per launch from the PMC counters: collected offline by tools/pmc_traffic.sh (separate rocprofv3 --pmc
         # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
         traffic, tsrc = None, None
@@ -215,7 +221,11 @@ def main():
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,
                            "algorithmic_bytes_per_launch": ab / max(nlaunch, 1),
-                           "algorithmic_gflop_per_step": fl / 2 / 1e9}
+                           "algorithmic_gflop_per_step": fl / 2 / 1e9,
+                           # the same launches priced per launch against max(MFMA, HBM): roofline time / measured time
+                           "per_launch_mixed": {"roofline_ms_per_step": roof_ms / 2, "measured_ms_per_step": ms / 2,
+                                                "frac": roof_ms / ms if ms > 0 else None, "hbm_bound_launches_per_step": n_hbm // 2,
+                                                "peaks": "2.5 PFLOP/s bf16 dense MFMA, 8 TB/s HBM"}}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(a.cpu_size, 64 if a.cpu_size <= 256 else 16)
