@@ -27,6 +27,7 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "dge_conv2d": [C.POINTER(ConvDesc), _P],
     "dge_sum_slots": [_P, _P, _I, _I, _I, _P],
+    "dge_sum_slots_planar": [_P, _P, _I, _I, _I, _P],
     "dge_packed_n": [_I],
     "dge_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
     "dge_weight_sumsq": [_P, _P, _I, _I, _I, _F, _P],

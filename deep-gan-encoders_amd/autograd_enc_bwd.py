@@ -56,17 +56,18 @@ def encoder_backward(E, saved, g_w):
         if not last:
             if g_out is None:
                 raise RuntimeError("non-final encoder block without an output gradient")
-            red2 = ops.zeros((C2, 3 if has3 else 2), dev)     # third column: sum of g_out = conv_3.bias gradient / 0.889
-            g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2)
-            grads[pre + "bias_2"] = red2[:, 0].reshape(1, C2, 1, 1)
-            grads[pre + "noise_weight_2"] = red2[:, 1].reshape(1, C2, 1, 1)
+            # planar reductions ([k, C]): every parameter gradient below is a contiguous view, no strided copies
+            red2 = ops.zeros((3 if has3 else 2, C2), dev)     # third row: sum of g_out = conv_3.bias gradient / 0.889
+            g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2, planar=True)
+            grads[pre + "bias_2"] = red2[0].reshape(1, C2, 1, 1)
+            grads[pre + "noise_weight_2"] = red2[1].reshape(1, C2, 1, 1)
             gW2 = ops.zeros(tuple(blk.conv_2.weight.shape), dev)
             ops.conv_wgrad(g_pre2, x1, gW2, rec["sc2"], rec["sh2"])
             grads[pre + "conv_2.weight"] = gW2
             dots2 = ops.zeros((B, Cc, 2), dev)
             g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots2, dot_src=x1)
             if has3:
-                grads[pre + "conv_3.bias"] = red2[:, 2] * 0.889
+                grads[pre + "conv_3.bias"] = red2[2] * 0.889
                 gW3 = ops.zeros(tuple(blk.conv_3.weight.shape), dev)
                 ops.conv_wgrad(g_out, rec["xp"], gW3)
                 grads[pre + "conv_3.weight"] = ops.scale_(gW3, 0.889)
@@ -79,10 +80,10 @@ def encoder_backward(E, saved, g_w):
                 raise RuntimeError("the final encoder block's activation output carries no gradient in E_align")
             g_y2, dots2 = None, None
         coef2 = ops.in_bwd_coef(dots2, gms2, rec["musig2"], rec["sc2"], rec["sh2"], N)
-        red1 = ops.zeros((Cc, 2), dev)
-        g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1)
-        grads[pre + "bias_1"] = red1[:, 0].reshape(1, Cc, 1, 1)
-        grads[pre + "noise_weight_1"] = red1[:, 1].reshape(1, Cc, 1, 1)
+        red1 = ops.zeros((2, Cc), dev)
+        g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1, planar=True)
+        grads[pre + "bias_1"] = red1[0].reshape(1, Cc, 1, 1)
+        grads[pre + "noise_weight_1"] = red1[1].reshape(1, Cc, 1, 1)
         gW1 = ops.zeros(tuple(blk.conv_1.weight.shape), dev)
         ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
         grads[pre + "conv_1.weight"] = gW1
@@ -96,10 +97,10 @@ def encoder_backward(E, saved, g_w):
             hook = E.__dict__.get("_early_grad_hook")
             if hook is not None:
                 hook(dict(grads))
-    fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float())
+    fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float(), planar=True)
     C0 = E.startf
-    grads["FromRGB.from_rgb.weight"] = fr[:, :3].reshape(C0, 3, 1, 1)
-    grads["FromRGB.from_rgb.bias"] = fr[:, 3]
+    grads["FromRGB.from_rgb.weight"] = fr[:3].t().reshape(C0, 3, 1, 1)
+    grads["FromRGB.from_rgb.bias"] = fr[3]
     out = []
     for name, p in E.named_parameters():
         g = grads.get(name)

@@ -50,6 +50,21 @@ __global__ void sum_slots_kernel(const float* __restrict__ partial, float* __res
     for (int k = 0; k < nslot; k++) s += partial[(size_t)k * n + i];
     out[i] = accumulate ? out[i] + s : s;
 }
+// out[k*C + c] = sum_s partial[s][c*NS + k]: the slot sum with the result laid out planar, so that each of the NS reductions
+// is a contiguous [C] vector (parameter gradients are handed on without a strided copy)
+__global__ void sum_slots_planar_kernel(const float* __restrict__ partial, float* __restrict__ out, int nslot, int C, int NS) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * NS) return;
+    float s = 0.f;
+    for (int k = 0; k < nslot; k++) s += partial[(size_t)k * C * NS + i];
+    out[(size_t)(i % NS) * C + i / NS] = s;
+}
+extern "C" int dge_sum_slots_planar(const float* partial, float* out, int nslot, int C, int NS, hipStream_t s) {
+    DGE_CHECK(nslot >= 1 && C >= 1 && NS >= 1, "sum_slots_planar: bad sizes");
+    hipLaunchKernelGGL(sum_slots_planar_kernel, dim3((C * NS + 255) / 256), dim3(256), 0, s, partial, out, nslot, C, NS);
+    DGE_LAUNCH_CHECK("sum_slots_planar");
+    return 0;
+}
 extern "C" int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumulate, hipStream_t s) {
     hipLaunchKernelGGL(sum_slots_kernel, dim3((n + 255) / 256), dim3(256), 0, s, partial, out, nslot, n, accumulate);
     DGE_LAUNCH_CHECK("sum_slots");

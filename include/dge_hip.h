@@ -77,6 +77,8 @@ typedef struct dge_conv_desc {
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumulate, dge_stream_t stream);
+/* the same sum over slots of [C][NS] partials, written planar: out[k*C + c] */
+int dge_sum_slots_planar(const float* partial, float* out, int nslot, int C, int NS, dge_stream_t stream);
 
 /* Weight preparation (once per weight update).  w_oihw: [Cout][Cin][k][k] f32 as stored by the
  * reference (model/stylegan2_generator.py:814-819; model/utils/lreq.py:107-110).  `out` holds
