@@ -39,6 +39,7 @@ SIGNATURES = {
     "dge_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _P],
     "dge_fromrgb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dge_stats_finalize": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "dge_stats_finalize_slots": [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P],
     "dge_blend": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_loss_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_crop_pool": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -56,6 +57,7 @@ SIGNATURES = {
     "dge_conv_wgrad": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_act_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_in_bwd_coef": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "dge_in_bwd_coef_slots": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "dge_in_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dge_chan_sum": [_P, _P, _I, _I, _I, _F, _I, _P],
     "dge_fromrgb_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -36,10 +36,10 @@ def encoder_forward(E, img, noises=None, save=False):
     if noises is None:
         noises = draw_noises(E, B, R, dev)
     cache = E.__dict__.setdefault("_pack_cache", {})
-    zeros = lambda c: ops.zeros((B, c, 2), dev)
+    zeros = lambda c: ops.SlotStats(B, c, dev)        # statistics slots are added by stats_finalize itself
     fr = E.FromRGB.from_rgb
     stats = zeros(E.startf)
-    x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats)
+    x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats.plain())
     saved = {"img": img, "x0": x, "blocks": []} if save else None
     ws, ni = [], 0
     L = E.layer_count
@@ -71,7 +71,7 @@ def encoder_forward(E, img, noises=None, save=False):
                                  gain=0.889, addend=x2, add_scale=0.111, stats=nstats)
             else:
                 xp = ops.blend(x, pool=True, alpha=0.889)
-                out = ops.blend(a2, z=xp, pool=True, alpha=0.111, beta=1.0, stats=nstats)
+                out = ops.blend(a2, z=xp, pool=True, alpha=0.111, beta=1.0, stats=nstats.plain())
             if save:
                 rec.update(n2=n2, a2=a2, xp=xp if has3 else None)
         else:

@@ -373,12 +373,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gup,
 // epilogue (may be null when y has no consumer), gms [B,2C] = [g_mu | g_sigma].
 __global__ void in_bwd_coef_kernel(const float* __restrict__ dots, const float* __restrict__ gms, const float* __restrict__ musig,
                                    const float* __restrict__ sc, const float* __restrict__ sh, float* __restrict__ coef,
-                                   int B, int C, float inv_n) {
+                                   int B, int C, float inv_n, int nslot) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx % C;
     const float r = sc[idx], s = sh[idx];
-    const float S2 = dots ? dots[(size_t)idx * 2] : 0.f, S1 = dots ? dots[(size_t)idx * 2 + 1] : 0.f;
+    float S2 = 0.f, S1 = 0.f;                 // nslot copies of the two sums (dge_conv2d statistics slots) are added here
+    if (dots)
+        for (int k = 0; k < nslot; k++) {
+            const float2 v2 = *(const float2*)(dots + ((size_t)k * B * C + idx) * 2);
+            S2 += v2.x; S1 += v2.y;
+        }
     const float m1 = S1 * inv_n, m2 = (r * S2 + s * S1) * inv_n;
     const float mu = musig[(size_t)b * 2 * C + c], sg = musig[(size_t)b * 2 * C + C + c];
     const float gmu = gms ? gms[(size_t)b * 2 * C + c] : 0.f, gsg = gms ? gms[(size_t)b * 2 * C + C + c] : 0.f;
@@ -612,11 +617,16 @@ extern "C" int dge_act_bwd(const void* gup, const void* a, const float* noise, v
     return 0;
 }
 
-extern "C" int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh,
-                               float* coef, int B, int C, int npix, hipStream_t s) {
-    hipLaunchKernelGGL(in_bwd_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, dots, gms, musig, sc, sh, coef, B, C, 1.0f / (float)npix);
+extern "C" int dge_in_bwd_coef_slots(const float* dots, int nslot, const float* gms, const float* musig, const float* sc,
+                                     const float* sh, float* coef, int B, int C, int npix, hipStream_t s) {
+    DGE_CHECK(nslot >= 1, "in_bwd_coef: nslot %d", nslot);
+    hipLaunchKernelGGL(in_bwd_coef_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, dots, gms, musig, sc, sh, coef, B, C, 1.0f / (float)npix, nslot);
     DGE_LAUNCH_CHECK("in_bwd_coef");
     return 0;
+}
+extern "C" int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh,
+                               float* coef, int B, int C, int npix, hipStream_t s) {
+    return dge_in_bwd_coef_slots(dots, 1, gms, musig, sc, sh, coef, B, C, npix, s);
 }
 
 extern "C" int dge_in_bwd(const void* gy, const void* x, const float* coef, const void* extra, const float* noise, void* gout,

@@ -45,13 +45,19 @@ __global__ __launch_bounds__(256) void fromrgb_kernel(const float* __restrict__ 
 // stats [B,C,2] (sum, sumsq) over npix pixels ->
 //   musig [B,2C] = [mean | sqrt(biased var)]          (E.py:51-53, no eps)
 //   sc [B,C] = rsqrt(var + eps), sh = -mean*sc         (InstanceNorm2d eps=1e-8, E.py:57)
+// (nslot copies of the sums - dge_conv2d spreads its statistics atomics - are added here: no separate slot-sum launch)
 __global__ void stats_finalize_kernel(const float* __restrict__ stats, float* __restrict__ musig, float* __restrict__ sc,
-                                      float* __restrict__ sh, int B, int C, float inv_n, float eps) {
+                                      float* __restrict__ sh, int B, int C, float inv_n, float eps, int nslot) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx % C;
-    const float m = stats[(size_t)idx * 2] * inv_n;
-    float v = stats[(size_t)idx * 2 + 1] * inv_n - m * m;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = 0; k < nslot; k++) {
+        const float2 v2 = *(const float2*)(stats + ((size_t)k * B * C + idx) * 2);
+        s0 += v2.x; s1 += v2.y;
+    }
+    const float m = s0 * inv_n;
+    float v = s1 * inv_n - m * m;
     v = v > 0.f ? v : 0.f;
     musig[(size_t)b * 2 * C + c] = m;
     musig[(size_t)b * 2 * C + C + c] = sqrtf(v);
@@ -267,12 +273,17 @@ extern "C" int dge_fromrgb(const float* img, const float* w, const float* bias, 
     return 0;
 }
 
-extern "C" int dge_stats_finalize(const float* stats, float* musig, float* sc, float* sh, int B, int C, int npix, float eps,
-                                  hipStream_t s) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, stats, musig, sc, sh, B, C,
-                       1.0f / (float)npix, eps);
+extern "C" int dge_stats_finalize_slots(const float* stats, int nslot, float* musig, float* sc, float* sh, int B, int C, int npix,
+                                        float eps, hipStream_t s) {
+    DGE_CHECK(nslot >= 1, "stats_finalize: nslot %d", nslot);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, stats, musig, sc, sh, B, C,
+                       1.0f / (float)npix, eps, nslot);
     DGE_LAUNCH_CHECK("stats_finalize");
     return 0;
+}
+extern "C" int dge_stats_finalize(const float* stats, float* musig, float* sc, float* sh, int B, int C, int npix, float eps,
+                                  hipStream_t s) {
+    return dge_stats_finalize_slots(stats, 1, musig, sc, sh, B, C, npix, eps, s);
 }
 
 extern "C" int dge_blend(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B,

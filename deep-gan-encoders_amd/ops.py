@@ -51,6 +51,24 @@ def zeros(shape, device):
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
+class SlotStats:
+    """Per-(b,c) statistics target [B,C,2] whose slot copies (dge_conv2d spreads its statistics atomics over up to 64 copies,
+    same-address contention) are added by the CONSUMING kernel (stats_finalize / in_bwd_coef) instead of a dge_sum_slots launch."""
+    __slots__ = ("B", "C", "device", "buf", "nslot")
+
+    def __init__(self, B, C, device):
+        self.B, self.C, self.device, self.buf, self.nslot = B, C, device, None, 1
+
+    def alloc(self, nslot):
+        self.nslot = nslot
+        self.buf = zeros((nslot, self.B, self.C, 2), self.device)
+        return self.buf
+
+    def plain(self):
+        """a [B,C,2] tensor for producers that do not use slots (fromrgb, blend)"""
+        return self.alloc(1)[0]
+
+
 def _sum_over_batch(partial, out=None):
     """partial [B, ...] per-sample sums -> [...] (dge_sum_slots); accumulates into `out` when given."""
     n = partial[0].numel()
@@ -167,10 +185,13 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d.in_scale, d.in_shift, d.out_scale = _f32(in_scale), _f32(in_shift), _f32(out_scale)
     # statistics atomics of large grids are spread over several copies (same-address contention), then combined
     partial, nslot = None, 1
+    lazy = isinstance(stats, SlotStats)
     if stats is not None:
         nblk = ((H + 15) // 16) * ((W + 15) // 16) * B
         nslot = max(1, min(64, nblk // 16))
-        if nslot > 1:
+        if lazy:
+            partial = stats.alloc(nslot)
+        elif nslot > 1:
             partial = zeros((nslot,) + tuple(stats.shape), x.device)
     d.bias, d.noise, d.noise_w, d.stats = _f32(bias), _f32(noise), _f32(noise_w), _f32(partial if partial is not None else stats)
     d.stats_slots = nslot
@@ -200,7 +221,7 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, ksize, up, in_s2d), abytes))
     else:
         check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
-    if partial is not None:
+    if partial is not None and not lazy:
         check(lib().dge_sum_slots(_p(partial), _p(stats), nslot, stats.numel(), 1, _stream()), "dge_sum_slots")
     return out
 
@@ -239,11 +260,16 @@ def fromrgb(img, w, bias, dtype, stats=None):
 
 
 def stats_finalize(stats, npix, eps=1e-8):
-    B, Cc, _ = stats.shape
+    """stats: [B,C,2] tensor or SlotStats"""
+    nslot = 1
+    if isinstance(stats, SlotStats):
+        B, Cc, nslot, stats = stats.B, stats.C, stats.nslot, stats.buf
+    else:
+        B, Cc, _ = stats.shape
     musig = torch.empty((B, 2 * Cc), dtype=torch.float32, device=stats.device)
     sc = torch.empty((B, Cc), dtype=torch.float32, device=stats.device)
     sh = torch.empty((B, Cc), dtype=torch.float32, device=stats.device)
-    check(lib().dge_stats_finalize(_f32(stats), _p(musig), _p(sc), _p(sh), B, Cc, int(npix), float(eps), _stream()),
+    check(lib().dge_stats_finalize_slots(_f32(stats), nslot, _p(musig), _p(sc), _p(sh), B, Cc, int(npix), float(eps), _stream()),
           "dge_stats_finalize")
     return musig, sc, sh
 
@@ -338,8 +364,11 @@ def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2, plan
 def in_bwd_coef(dots, gms, musig, sc, sh, npix):
     B, Cc = sc.shape
     coef = torch.empty((B, Cc, 3), dtype=torch.float32, device=sc.device)
-    check(lib().dge_in_bwd_coef(_f32(dots), _f32(gms), _f32(musig), _f32(sc), _f32(sh), _p(coef), B, Cc, int(npix), _stream()),
-          "dge_in_bwd_coef")
+    nslot = 1
+    if isinstance(dots, SlotStats):
+        nslot, dots = dots.nslot, dots.buf
+    check(lib().dge_in_bwd_coef_slots(_f32(dots), nslot, _f32(gms), _f32(musig), _f32(sc), _f32(sh), _p(coef), B, Cc, int(npix),
+                                      _stream()), "dge_in_bwd_coef")
     return coef
 
 

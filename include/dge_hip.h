@@ -127,6 +127,9 @@ int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, fl
  * affine sc = rsqrt(var+eps), sh = -mean*sc (nn.InstanceNorm2d eps=1e-8, E.py:57,68). */
 int dge_stats_finalize(const float* stats, float* musig, float* sc, float* sh, int B, int C, int npix, float eps,
                        dge_stream_t stream);
+/* the same with `nslot` copies of the sums ([nslot][B][C][2], the layout dge_conv2d's stats_slots writes) added on the fly */
+int dge_stats_finalize_slots(const float* stats, int nslot, float* musig, float* sc, float* sh, int B, int C, int npix, float eps,
+                             dge_stream_t stream);
 /* y = alpha * P(x*sc+sh) + beta * z with P = identity (pool=0) or avg_pool2d(2) (pool=1; y,z at
  * OHxOW, x at 2OHx2OW); sc/sh/z/stats optional.  E.py:75-78,84 (downscale2d, residual blend). */
 int dge_blend(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B, int OH,
@@ -199,6 +202,8 @@ int dge_nearest_up2(const void* x, void* y, int B, int H, int W, int C, float sc
 /* coefficients (A,Bc,Cc)[B,C,3] of the instance-norm + (mean,std) backward; see DESIGN.md */
 int dge_in_bwd_coef(const float* dots, const float* gms, const float* musig, const float* sc, const float* sh, float* coef,
                     int B, int C, int npix, dge_stream_t stream);
+int dge_in_bwd_coef_slots(const float* dots, int nslot, const float* gms, const float* musig, const float* sc, const float* sh,
+                          float* coef, int B, int C, int npix, dge_stream_t stream);      /* dots: [nslot][B][C][2] */
 /* gout = A*gy + Bc*x + Cc + extra_scale*extra[q(p)], then optional lrelu' of x with bias/noise reductions into
  * red [B,C,2] (per-sample partial sums, pre-zeroed; summed over b by the caller) */
 int dge_in_bwd(const void* gy, const void* x, const float* coef, const void* extra, const float* noise, void* gout, float* red,
