@@ -19,12 +19,22 @@ def _packed(cache, conv, dtype, mode):
 
 
 def draw_noises(E, B, R, device):
-    out = []
+    """The encoder's per-layer noise tensors ([B,1,r,r], two per block, one for the last): one generator launch for all of
+    them, handed out as contiguous slices (the reference draws 17 separate CPU tensors, model/E/E.py:60,73 - quirk Q6)."""
+    shapes = []
     for j in range(E.layer_count):
         r = R >> j
-        out.append(torch.randn(B, 1, r, r, device=device))
+        shapes.append((B, 1, r, r))
         if j != E.layer_count - 1:
-            out.append(torch.randn(B, 1, r, r, device=device))
+            shapes.append((B, 1, r, r))
+    if torch.device(device).type == "cpu":        # reference_noise mode: the reference's own sequence of CPU draws
+        return [torch.randn(*s) for s in shapes]
+    sizes = [B * s[2] * s[3] for s in shapes]
+    flat = torch.randn(sum(sizes), device=device)
+    out, off = [], 0
+    for s, n in zip(shapes, sizes):
+        out.append(flat[off:off + n].view(s))
+        off += n
     return out
 
 

@@ -28,3 +28,12 @@ short = [r for r in rows if r[1] - r[0] < 10000]
 print(f"kernels {len(rows)}, wall {wall/1e6:.2f} ms, busy (union) {busy/1e6:.2f} ms = {100*busy/wall:.1f} %, sum of durations {sum(r[1]-r[0] for r in rows)/1e6:.2f} ms")
 print(f"idle gaps: {len(gaps)}, total {sum(gaps)/1e6:.2f} ms; gaps > 20 us: {sum(1 for g in gaps if g > 20000)} totalling {sum(g for g in gaps if g > 20000)/1e6:.2f} ms")
 print(f"kernels shorter than 10 us: {len(short)} ({100*len(short)/len(rows):.0f} %), their durations sum to {sum(r[1]-r[0] for r in short)/1e6:.2f} ms")
+import collections, re
+cnt = collections.Counter()
+dur = collections.Counter()
+for s_, e_, n_ in rows:
+    k = re.sub(r"\(.*", "", n_.replace("(anonymous namespace)::", "")).replace("void ", "")[:70]
+    cnt[k] += 1; dur[k] += e_ - s_
+print("launches in the window by kernel (count, total us):")
+for k, n in cnt.most_common(28):
+    print(f"{n:5d} {dur[k]/1e3:9.1f}  {k}")

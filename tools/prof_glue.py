@@ -30,6 +30,10 @@ wrap(torch.Tensor, "float", lambda self, *a, **k: self.dtype != torch.float32)
 wrap(torch.Tensor, "to", lambda self, *a, **k: True)
 wrap(torch.Tensor, "__mul__"); wrap(torch.Tensor, "__add__"); wrap(torch.Tensor, "__setitem__")
 wrap(torch, "zeros"); wrap(torch, "full"); wrap(torch, "stack"); wrap(torch, "cat"); wrap(torch, "zeros_like"); wrap(torch, "ones")
+wrap(torch, "ones_like"); wrap(torch, "full_like"); wrap(torch, "randn"); wrap(torch, "tensor"); wrap(torch, "as_tensor"); wrap(torch, "where")
+wrap(torch.Tensor, "new_zeros"); wrap(torch.Tensor, "new_ones"); wrap(torch.Tensor, "new_full"); wrap(torch.Tensor, "__rmul__"); wrap(torch.Tensor, "__truediv__")
+wrap(torch.Tensor, "__sub__"); wrap(torch.Tensor, "__neg__"); wrap(torch.Tensor, "sum"); wrap(torch.Tensor, "mean"); wrap(torch.Tensor, "mul_"); wrap(torch.Tensor, "add_")
+wrap(torch.Tensor, "expand"); wrap(torch.Tensor, "repeat"); wrap(torch.Tensor, "cuda")
 st.step(7)
 torch.cuda.synchronize()
 for (name, s), n in cnt.most_common(50):
