@@ -47,7 +47,15 @@ __global__ void sum_slots_kernel(const float* __restrict__ partial, float* __res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int k = 0; k < nslot; k++) s += partial[(size_t)k * n + i];
+    int k = 0;
+    for (; k + 8 <= nslot; k += 8) {                  // 8 independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = partial[(size_t)(k + j) * n + i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[j];
+    }
+    for (; k < nslot; k++) s += partial[(size_t)k * n + i];
     out[i] = accumulate ? out[i] + s : s;
 }
 // out[k*C + c] = sum_s partial[s][c*NS + k]: the slot sum with the result laid out planar, so that each of the NS reductions
@@ -56,7 +64,15 @@ __global__ void sum_slots_planar_kernel(const float* __restrict__ partial, float
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * NS) return;
     float s = 0.f;
-    for (int k = 0; k < nslot; k++) s += partial[(size_t)k * C * NS + i];
+    int k = 0;
+    for (; k + 8 <= nslot; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = partial[(size_t)(k + j) * C * NS + i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s += v[j];
+    }
+    for (; k < nslot; k++) s += partial[(size_t)k * C * NS + i];
     out[(size_t)(i % NS) * C + i / NS] = s;
 }
 extern "C" int dge_sum_slots_planar(const float* partial, float* out, int nslot, int C, int NS, hipStream_t s) {

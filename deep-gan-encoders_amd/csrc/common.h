@@ -103,6 +103,21 @@ static inline int dge_stream_grid(int npix, int ppi, int B) {
     return g > cap ? cap : (g < 1 ? 1 : g);
 }
 
+// sum over `nslot` copies of a (sum, sum-of-squares) pair, 8 independent loads in flight (the copies sit `stride` floats apart)
+__device__ __forceinline__ float2 sum_slot_pairs(const float* __restrict__ base, size_t stride, int nslot) {
+    float s0 = 0.f, s1 = 0.f;
+    int k = 0;
+    for (; k + 8 <= nslot; k += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = *(const float2*)(base + (size_t)(k + j) * stride);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { s0 += v[j].x; s1 += v[j].y; }
+    }
+    for (; k < nslot; k++) { const float2 v = *(const float2*)(base + (size_t)k * stride); s0 += v.x; s1 += v.y; }
+    return make_float2(s0, s1);
+}
+
 // error plumbing shared by the C ABI translation units
 void dge_set_error(const char* fmt, ...);
 #define DGE_CHECK(cond, ...) do { if (!(cond)) { dge_set_error(__VA_ARGS__); return -1; } } while (0)

@@ -379,11 +379,10 @@ __global__ void in_bwd_coef_kernel(const float* __restrict__ dots, const float* 
     const int b = idx / C, c = idx % C;
     const float r = sc[idx], s = sh[idx];
     float S2 = 0.f, S1 = 0.f;                 // nslot copies of the two sums (dge_conv2d statistics slots) are added here
-    if (dots)
-        for (int k = 0; k < nslot; k++) {
-            const float2 v2 = *(const float2*)(dots + ((size_t)k * B * C + idx) * 2);
-            S2 += v2.x; S1 += v2.y;
-        }
+    if (dots) {
+        const float2 ss = sum_slot_pairs(dots + (size_t)idx * 2, (size_t)B * C * 2, nslot);
+        S2 = ss.x; S1 = ss.y;
+    }
     const float m1 = S1 * inv_n, m2 = (r * S2 + s * S1) * inv_n;
     const float mu = musig[(size_t)b * 2 * C + c], sg = musig[(size_t)b * 2 * C + C + c];
     const float gmu = gms ? gms[(size_t)b * 2 * C + c] : 0.f, gsg = gms ? gms[(size_t)b * 2 * C + C + c] : 0.f;

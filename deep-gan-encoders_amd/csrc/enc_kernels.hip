@@ -51,13 +51,9 @@ __global__ void stats_finalize_kernel(const float* __restrict__ stats, float* __
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * C) return;
     const int b = idx / C, c = idx % C;
-    float s0 = 0.f, s1 = 0.f;
-    for (int k = 0; k < nslot; k++) {
-        const float2 v2 = *(const float2*)(stats + ((size_t)k * B * C + idx) * 2);
-        s0 += v2.x; s1 += v2.y;
-    }
-    const float m = s0 * inv_n;
-    float v = s1 * inv_n - m * m;
+    const float2 ss = sum_slot_pairs(stats + (size_t)idx * 2, (size_t)B * C * 2, nslot);
+    const float m = ss.x * inv_n;
+    float v = ss.y * inv_n - m * m;
     v = v > 0.f ? v : 0.f;
     musig[(size_t)b * 2 * C + c] = m;
     musig[(size_t)b * 2 * C + C + c] = sqrtf(v);
