@@ -53,11 +53,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
                                    int Ntot, int mode, float scale) {
     const int ntap = KS * KS;
     const int Kdim = (mode == 2) ? Cout : ((mode == 3 || mode == 5) ? 4 * Cout : Cin);
-    const long total = (long)ntap * Ntot * Kdim;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int total = ntap * Ntot * Kdim;            // < 2^31 (checked by the launcher): 32-bit index math
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int k = idx % Kdim;
         const int n = (idx / Kdim) % Ntot;
-        const int tap = idx / ((long)Kdim * Ntot);
+        const int tap = idx / (Kdim * Ntot);
         float v = 0.f;
         if (mode == 0) {
             if (n < Cout) v = w[((size_t)n * Cin + k) * ntap + tap];
@@ -286,6 +286,7 @@ extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, in
     const int ntot = dge_packed_n(nvalid);
     const int kdim = mode == 2 ? cout : ((mode == 3 || mode == 5) ? 4 * cout : cin);
     const long total = (long)ksize * ksize * ntot * kdim;
+    DGE_CHECK(total < (1L << 31) - (4096L * 256), "pack: weight too large (%ld elements)", total);
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == DGE_BF16)
         hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w_oihw, (bf16_t*)out, cout, cin, ksize, ntot, mode, scale);
