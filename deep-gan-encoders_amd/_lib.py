@@ -61,6 +61,8 @@ SIGNATURES = {
     "dge_in_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dge_chan_sum": [_P, _P, _I, _I, _I, _F, _I, _P],
     "dge_fromrgb_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dge_head_entry_size": [],
+    "dge_heads_bwd": [_P, _I, _I, _P, _I, _P, _P, _P, _P, _I, _I, _P],
     "dge_dense_wgrad": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
     "dge_lpips_prep": [_P, _P, _I, _I, _I, _P, _P, _I, _P],
     "dge_lpips_prep_bwd": [_P, _P, _I, _I, _I, _P, _F, _I, _I, _P],

@@ -38,6 +38,39 @@ def draw_noises(E, B, R, device):
     return out
 
 
+def heads_layout(E, B, dev):
+    """Static layout of the encoder's `inver_mod` heads for the grouped backward (dge_heads_bwd): entry order = (inver_mod1,
+    inver_mod2) per block; statistics / their gradients in one flat buffer, parameter gradients in another; the device-side
+    table holds the weight pointers (parameter storage does not move) and the column of each head in w (E.py:130-134)."""
+    import numpy as np
+    lins = []
+    L = E.layer_count
+    for j, blk in enumerate(E.decode_block):
+        lins.append((blk.inver_mod1, 2 * (L - 1 - j) + 1))
+        lins.append((blk.inver_mod2, 2 * (L - 1 - j)))
+    key = (B, str(dev), tuple(l.weight.data_ptr() for l, _ in lins))
+    lay = E.__dict__.get("_heads_layout")
+    if lay is not None and lay["key"] == key:
+        return lay
+    O = lins[0][0].weight.shape[0]
+    rec = np.dtype([("W", "u8"), ("moff", "i8"), ("woff", "i8"), ("I", "i4"), ("gcol", "i4"), ("boff", "i4"), ("pad", "i4")])
+    assert rec.itemsize == ops.lib().dge_head_entry_size()
+    tab = np.zeros(len(lins), dtype=rec)
+    moff = woff = 0
+    items = []
+    for i, (lin, col) in enumerate(lins):
+        I = lin.weight.shape[1]
+        assert lin.weight.shape[0] == O and lin.weight.is_contiguous()
+        tab[i] = (lin.weight.data_ptr(), moff, woff, I, col * O, i * O, 0)
+        items.append((moff, woff, i * O, I))
+        moff += B * I
+        woff += O * I
+    lay = dict(key=key, tab=torch.from_numpy(tab.view(np.uint8).copy()).to(dev), items=items, n=len(lins), O=O, total_m=moff,
+               total_w=woff, max_I=max(it[3] for it in items))
+    E.__dict__["_heads_layout"] = lay
+    return lay
+
+
 def encoder_forward(E, img, noises=None, save=False):
     """BE.forward (reference model/E/E.py:122-136) + BEBlock.forward (:50-85)."""
     dt = _dt(E.compute_dtype)
@@ -53,18 +86,26 @@ def encoder_forward(E, img, noises=None, save=False):
     saved = {"img": img, "x0": x, "blocks": []} if save else None
     ws, ni = [], 0
     L = E.layer_count
+    lay = heads_layout(E, B, dev)
+    musig_all = torch.empty(lay["total_m"], dtype=torch.float32, device=dev)     # all (mean, std) vectors, flat: grouped backward
+    if save:
+        saved["musig_all"] = musig_all
+
+    def ms_slot(i):
+        moff, _, _, I = lay["items"][i]
+        return musig_all[moff:moff + B * I].view(B, I)
     for j, blk in enumerate(E.decode_block):
         Cc, C2 = blk.inputs, blk.outputs
         H = R >> j
         last = not blk.has_last_conv
-        musig1, sc1, sh1 = ops.stats_finalize(stats, H * H)
+        musig1, sc1, sh1 = ops.stats_finalize(stats, H * H, musig_out=ms_slot(2 * j))
         w1 = ops.linear(musig1, blk.inver_mod1.weight.detach(), blk.inver_mod1.bias.detach())
         n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
         st1 = zeros(Cc)
         x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
                         noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
                         act=ops.ACT_LRELU, stats=st1)
-        musig2, sc2, sh2 = ops.stats_finalize(st1, H * H)
+        musig2, sc2, sh2 = ops.stats_finalize(st1, H * H, musig_out=ms_slot(2 * j + 1))
         w2 = ops.linear(musig2, blk.inver_mod2.weight.detach(), blk.inver_mod2.bias.detach())
         rec = dict(x=x, musig1=musig1, sc1=sc1, sh1=sh1, n1=n1, x1=x1, musig2=musig2, sc2=sc2, sh2=sh2) if save else None
         has3 = Cc != C2

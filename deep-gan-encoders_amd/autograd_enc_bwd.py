@@ -9,7 +9,7 @@ reference's behaviour.
 import torch
 
 from . import ops
-from .autograd_enc import _packed
+from .autograd_enc import _packed, heads_layout
 
 
 def _linear_backward(lin, g_w, musig, grads, name):
@@ -38,6 +38,24 @@ def encoder_backward(E, saved, g_w):
     g_out = None
     R = saved["img"].shape[2]
     dt = ops.dtype_of(saved["x0"])
+    # every inver_mod head at once (their gradient g_w is complete before the backward starts): two launches instead of 4 per block
+    heads = None
+    if saved.get("musig_all") is not None:
+        lay = heads_layout(E, B, dev)
+        if g_w.stride(2) != 1 or g_w.stride(1) != lay["O"]:
+            g_w = g_w.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        gms_all, gw_all = torch.empty(lay["total_m"], **f32), torch.empty(lay["total_w"], **f32)
+        gb_all = torch.empty(lay["n"] * lay["O"], **f32)
+        ops.check(ops.lib().dge_heads_bwd(ops._p(lay["tab"]), lay["n"], lay["max_I"], ops._f32(g_w), g_w.stride(0),
+                                          ops._f32(saved["musig_all"]), ops._p(gms_all), ops._p(gw_all), ops._p(gb_all), B, lay["O"],
+                                          ops._stream()), "dge_heads_bwd")
+
+        def heads(i, name):
+            moff, woff, boff, I = lay["items"][i]
+            grads[name + ".weight"] = gw_all[woff:woff + lay["O"] * I].view(lay["O"], I)
+            grads[name + ".bias"] = gb_all[boff:boff + lay["O"]]
+            return gms_all[moff:moff + B * I].view(B, I)
     for j in range(L - 1, -1, -1):
         blk = E.decode_block[j]
         rec = saved["blocks"][j]
@@ -49,8 +67,11 @@ def encoder_backward(E, saved, g_w):
         has3 = Cc != C2
         # w index map (E.py:130-134): w[:, 2(L-1-j)] = w2_j, w[:, 2(L-1-j)+1] = w1_j
         g_w2, g_w1 = g_w[:, 2 * (L - 1 - j)], g_w[:, 2 * (L - 1 - j) + 1]
-        gms2 = _linear_backward(blk.inver_mod2, g_w2, rec["musig2"], grads, pre + "inver_mod2")
-        gms1 = _linear_backward(blk.inver_mod1, g_w1, rec["musig1"], grads, pre + "inver_mod1")
+        if heads is not None:
+            gms2, gms1 = heads(2 * j + 1, pre + "inver_mod2"), heads(2 * j, pre + "inver_mod1")
+        else:
+            gms2 = _linear_backward(blk.inver_mod2, g_w2, rec["musig2"], grads, pre + "inver_mod2")
+            gms1 = _linear_backward(blk.inver_mod1, g_w1, rec["musig1"], grads, pre + "inver_mod1")
         x, x1 = rec["x"], rec["x1"]
         extra, extra_pool, extra_scale = None, False, 1.0
         if not last:

@@ -574,6 +574,59 @@ __global__ void dense_wgrad_kernel(const float* __restrict__ gy, int ldgy, const
     if (gb && i == 0) gb[o] = accumulate ? gb[o] + sb : sb;
 }
 
+// ------------------------------------------------------------------ all inver_mod heads of the encoder backward at once
+// The gradient of every head w_l = musig_l @ W_l^T + b_l is known when the backward starts (g_w [B, NL, O] comes from the loss),
+// so the 2 x NL per-layer launches (transposed dense layer + parameter gradients) collapse into two:
+//   gms_l[b,k]  = sum_o g_w[b, col_l + o] * W_l[o,k]                               (head_bwd_data_kernel)
+//   gW_l[o,i]   = sum_b g_w[b, col_l + o] * musig_l[b,i],  gb_l[o] = sum_b g_w[..]  (head_bwd_param_kernel)
+// musig_l / gms_l live at moff_l in flat [sum_l B*I_l] buffers, gW_l at woff_l, gb_l at boff_l of flat buffers.
+struct HeadEntry { const float* W; long moff, woff; int I, gcol, boff, pad; };
+__global__ __launch_bounds__(1024) void head_bwd_data_kernel(const HeadEntry* __restrict__ tab, const float* __restrict__ g, int ldg,
+                                                             float* __restrict__ gms_all, int O) {
+    __shared__ float part[16][64];
+    const HeadEntry e = tab[blockIdx.z];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + lane, b = blockIdx.y;
+    if (blockIdx.x * 64 >= e.I) return;                    // block-uniform
+    const int per = (O + 15) / 16, o0 = wave * per, o1 = min(O, o0 + per);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    if (k < e.I) {
+        const float* gr = g + (size_t)b * ldg + e.gcol;
+        int o = o0;
+        for (; o + 7 < o1; o += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += gr[o + j] * e.W[(size_t)(o + j) * e.I + k];
+        }
+        for (; o < o1; o++) acc[0] += gr[o] * e.W[(size_t)o * e.I + k];
+    }
+    part[wave][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (wave == 0 && k < e.I) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += part[j][lane];
+        gms_all[e.moff + (size_t)b * e.I + k] = s;
+    }
+}
+__global__ void head_bwd_param_kernel(const HeadEntry* __restrict__ tab, const float* __restrict__ g, int ldg,
+                                      const float* __restrict__ musig_all, float* __restrict__ gw_all, float* __restrict__ gb_all,
+                                      int B, int O) {
+    const HeadEntry e = tab[blockIdx.y];
+    const int total = O * e.I;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int o = idx / e.I, i = idx - o * e.I;
+        float s = 0.f, sb = 0.f;
+        for (int b = 0; b < B; b++) {
+            const float gv = g[(size_t)b * ldg + e.gcol + o];
+            s += gv * musig_all[e.moff + (size_t)b * e.I + i]; sb += gv;
+        }
+        gw_all[e.woff + idx] = s;
+        if (i == 0) gb_all[e.boff + o] = sb;
+    }
+}
+
 // =================================================================== C ABI
 #define CHAN_OK(C, ep) ((C) % (ep) == 0 && (C) / (ep) <= 256 && 256 % ((C) / (ep)) == 0)
 
@@ -599,6 +652,17 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     else { if (ksize == 3) WG(float, 3); else WG(float, 1); }
 #undef WG
     DGE_LAUNCH_CHECK("conv_wgrad");
+    return 0;
+}
+
+extern "C" int dge_head_entry_size(void) { return (int)sizeof(HeadEntry); }
+extern "C" int dge_heads_bwd(const void* dev_entries, int n, int max_I, const float* g, int ldg, const float* musig_all, float* gms_all,
+                             float* gw_all, float* gb_all, int B, int O, hipStream_t s) {
+    DGE_CHECK(n >= 1 && n <= 65535 && B >= 1 && B <= 65535 && O >= 1 && max_I >= 1, "heads_bwd: bad sizes");
+    hipLaunchKernelGGL(head_bwd_data_kernel, dim3((max_I + 63) / 64, B, n), dim3(1024), 0, s, (const HeadEntry*)dev_entries, g, ldg, gms_all, O);
+    hipLaunchKernelGGL(head_bwd_param_kernel, dim3(64, n), dim3(256), 0, s, (const HeadEntry*)dev_entries, g, ldg, musig_all, gw_all,
+                       gb_all, B, O);
+    DGE_LAUNCH_CHECK("heads_bwd");
     return 0;
 }
 

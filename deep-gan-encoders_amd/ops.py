@@ -259,14 +259,14 @@ def fromrgb(img, w, bias, dtype, stats=None):
     return y
 
 
-def stats_finalize(stats, npix, eps=1e-8):
-    """stats: [B,C,2] tensor or SlotStats"""
+def stats_finalize(stats, npix, eps=1e-8, musig_out=None):
+    """stats: [B,C,2] tensor or SlotStats; musig_out: optional preallocated [B, 2C] destination of (mean, std)"""
     nslot = 1
     if isinstance(stats, SlotStats):
         B, Cc, nslot, stats = stats.B, stats.C, stats.nslot, stats.buf
     else:
         B, Cc, _ = stats.shape
-    musig = torch.empty((B, 2 * Cc), dtype=torch.float32, device=stats.device)
+    musig = torch.empty((B, 2 * Cc), dtype=torch.float32, device=stats.device) if musig_out is None else musig_out
     sc = torch.empty((B, Cc), dtype=torch.float32, device=stats.device)
     sh = torch.empty((B, Cc), dtype=torch.float32, device=stats.device)
     check(lib().dge_stats_finalize_slots(_f32(stats), nslot, _p(musig), _p(sc), _p(sh), B, Cc, int(npix), float(eps), _stream()),

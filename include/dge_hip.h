@@ -214,6 +214,13 @@ int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, i
  * per-sample partial sums [B,C,4], pre-zeroed, summed over b by the caller */
 int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img, float* out4, int B, int HW, int C, int dtype,
                     dge_stream_t stream);
+/* Backward of all `inver_mod` heads of the encoder (E.py:51-53,66-68: w_l = Linear(mean/std statistics)) in two launches.
+ * dev_entries: n records {const float* W [O][I]; long moff, woff; int I, gcol, boff, pad} in DEVICE memory
+ * (dge_head_entry_size() bytes); g [B][ldg] holds the gradient of head l at columns gcol .. gcol+O;
+ * gms_all[moff + b*I + k] = sum_o g*W, gw_all[woff + o*I + i] = sum_b g*musig_all[moff + b*I + i], gb_all[boff + o] = sum_b g */
+int dge_head_entry_size(void);
+int dge_heads_bwd(const void* dev_entries, int n, int max_I, const float* g, int ldg, const float* musig_all, float* gms_all,
+                  float* gw_all, float* gb_all, int B, int O, dge_stream_t stream);
 /* gw[o][i] (+)= sum_b gy[b][o]*x[b][i]; gb[o] (+)= sum_b gy[b][o]   (ln.Linear parameter gradients) */
 int dge_dense_wgrad(const float* gy, int ldgy, const float* x, int ldx, float* gw, float* gb, int B, int O, int I,
                     int accumulate, dge_stream_t stream);
