@@ -44,6 +44,7 @@ SIGNATURES = {
     "dge_loss_reduce": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_crop_pool": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_ssim_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "dge_ssim_box7": [_P, _P, _P, _I, _I, _I, _F, _F, _F, _P],
     "dge_ssim_bwd": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "dge_space_loss_finalize": [_P, _P, _P, _P, _F, _F, _I, _P],
     "dge_space_loss_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _I, _P],

@@ -217,6 +217,54 @@ extern "C" int dge_crop_pool(const float* src, float* dst, int BC, int H, int W,
     return 0;
 }
 
+// skimage.measure.compare_ssim(X, Y, data_range=R, multichannel=True) as comparing-baseline.py:25 calls it (defaults: 7x7 uniform
+// window, K1 = 0.01, K2 = 0.03, sample covariance i.e. cov_norm = 49/48, mean of the SSIM map with a 3-pixel border cropped, mean
+// over the channels): sums[bc] (pre-zeroed) += sum of the map over the interior of plane bc.  `scale`/`shift` map the stored pixel
+// values to the metric's scale (x*scale + shift), R is the data range there.
+__global__ __launch_bounds__(256) void ssim_box7_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ sums,
+                                                         int h, int w, float scale, float shift, float R) {
+    __shared__ float ta[22][23], tb[22][23];
+    __shared__ float red[4];
+    const int bc = blockIdx.z, x0 = blockIdx.x * 16, y0 = blockIdx.y * 16;       // output (interior) coordinates: pixel (y+3, x+3)
+    const float* pa = a + (size_t)bc * h * w; const float* pb = b + (size_t)bc * h * w;
+    for (int i = threadIdx.x; i < 22 * 22; i += 256) {
+        const int ty = i / 22, tx = i % 22, gy = y0 + ty, gx = x0 + tx;
+        const bool in = gy < h && gx < w;
+        ta[ty][tx] = in ? pa[(size_t)gy * w + gx] * scale + shift : 0.f;
+        tb[ty][tx] = in ? pb[(size_t)gy * w + gx] * scale + shift : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % 16, ly = threadIdx.x / 16;
+    float S = 0.f;
+    if (x0 + lx < w - 6 && y0 + ly < h - 6) {
+        float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int i = 0; i < 7; i++)
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const float av = ta[ly + i][lx + j], bv = tb[ly + i][lx + j];
+                sx += av; sy += bv; sxx += av * av; syy += bv * bv; sxy += av * bv;
+            }
+        const float inv = 1.f / 49.f, cn = 49.f / 48.f;
+        const float ux = sx * inv, uy = sy * inv;
+        const float vx = cn * (sxx * inv - ux * ux), vy = cn * (syy * inv - uy * uy), vxy = cn * (sxy * inv - ux * uy);
+        const float C1 = (0.01f * R) * (0.01f * R), C2 = (0.03f * R) * (0.03f * R);
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+    S = wave_sum(S);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = S;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sums + bc, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int dge_ssim_box7(const float* a, const float* b, float* sums, int BC, int h, int w, float scale, float shift, float data_range,
+                             hipStream_t s) {
+    DGE_CHECK(BC >= 1 && h >= 7 && w >= 7 && data_range > 0.f, "ssim_box7: planes must be at least 7x7 (got %dx%d)", h, w);
+    hipLaunchKernelGGL(ssim_box7_kernel, dim3((w - 6 + 15) / 16, (h - 6 + 15) / 16, BC), dim3(256), 0, s, a, b, sums, h, w, scale, shift,
+                       data_range);
+    DGE_LAUNCH_CHECK("ssim_box7");
+    return 0;
+}
+
 extern "C" int dge_ssim_fwd(const float* a, const float* b, float* ssim_sum, float* dmap, int BC, int h, int w, hipStream_t s) {
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3((w + 15) / 16, (h + 15) / 16, BC), dim3(256), 0, s, a, b, ssim_sum, dmap, BC, h, w, gauss11());
     DGE_LAUNCH_CHECK("ssim_fwd");

@@ -3,9 +3,9 @@
 * `reconstruct`   - inferE.py:101-141 / rec_real_img.py / synthesized_IMG.py: G(z) -> E -> G(w2) once, no gradients;
 * `edit_latent`   - embeded_img_edit.py:28-41: w[start:start+end] = (w + bonus*direction)[start:start+end] on a W+ code,
                     then one Gs.forward(w, lod);
-* `image_metrics` - comparing-baseline.py:21-45 on device: PSNR / MSE on [0,255], cosine on [-1,1] and LPIPS (the skimage SSIM
-                    of that script - 7x7 uniform window, data_range 255 - is a different statistic from pytorch_ssim and is not
-                    provided; `losses.space_loss` reports the reference's training SSIM);
+* `image_metrics` - comparing-baseline.py:21-45 on device: PSNR / MSE on [0,255], cosine on [-1,1], LPIPS and the skimage SSIM of
+                    that script (`ssim_skimage`: 7x7 uniform window, sample covariance, data_range 255 - a different statistic
+                    from the training loss's pytorch_ssim, which `losses.space_loss` reports);
 * `save_image`    - torchvision.utils.save_image(img*0.5+0.5, path) for a single image batch laid out in one row.
 """
 import math
@@ -55,9 +55,24 @@ def image_metrics(img1, img2, lpips_model=None):
     n = float(a.numel())
     mse255 = s[0] / n * (127.5 * 127.5)                      # x255 = (x + 1) * 127.5
     out = dict(mse=mse255, psnr=10.0 * torch.log10(255.0 * 255.0 / mse255), cosine=s[1] / torch.sqrt(s[2] * s[3]))
+    out["ssim"] = ssim_skimage(a, b).mean()
     if lpips_model is not None:
         out["lpips"], _ = lpips_model.value_and_grad(a, b, need_grad=False)
     return out
+
+
+@torch.no_grad()
+def ssim_skimage(img1, img2):
+    """skimage.measure.compare_ssim(x, y, data_range=255, multichannel=True) of comparing-baseline.py:25 for every image pair of
+    a batch: img1, img2 [B,C,H,W] in [-1,1] on the GPU (taken to the script's [0,255] scale inside the kernel) -> [B]."""
+    a = img1.detach().float().contiguous()
+    b = img2.detach().float().contiguous()
+    B, Cc, H, W = a.shape
+    if H < 7 or W < 7:
+        raise ValueError("win_size exceeds image extent (skimage raises the same for images smaller than 7x7)")
+    sums = torch.zeros(B * Cc, dtype=torch.float32, device=a.device)
+    check(lib().dge_ssim_box7(_f32(a), _f32(b), _p(sums), B * Cc, H, W, 127.5, 127.5, 255.0, _stream()), "dge_ssim_box7")
+    return sums.view(B, Cc).sum(1) / float(Cc * (H - 6) * (W - 6))
 
 
 def save_image(img, path):

@@ -146,6 +146,10 @@ int dge_crop_pool(const float* src, float* dst, int BC, int H, int W, int y0, in
 /* ssim_sum [32] (pre-zeroed slot copies; their total is the sum, dge_space_loss_finalize adds them) += sum of the SSIM map of a,b [BC,h,w]; dmap (optional, [3][BC][h][w]) receives dS/dmu2,
  * dS/dE[b^2], dS/dE[ab] for dge_ssim_bwd, which writes g = scale * dSum/db. */
 int dge_ssim_fwd(const float* a, const float* b, float* ssim_sum, float* dmap, int BC, int h, int w, dge_stream_t stream);
+/* skimage compare_ssim of comparing-baseline.py:25 (7x7 uniform window, sample covariance, 3-pixel border cropped): sums[bc]
+ * (pre-zeroed) += sum of the SSIM map over the interior of plane bc of a,b [BC,h,w]; pixels enter as x*scale + shift, data range R */
+int dge_ssim_box7(const float* a, const float* b, float* sums, int BC, int h, int w, float scale, float shift, float data_range,
+                  dge_stream_t stream);
 int dge_ssim_bwd(const float* a, const float* b, const float* dmap, float* g, int BC, int h, int w, float scale,
                  int accumulate, dge_stream_t stream);
 /* out8 = { 5*mse + 3*cos + (1-ssim) + 2*lpips (:97), mse, mse(mean), mse(std), kl, cos, 1-ssim, lpips } on device */

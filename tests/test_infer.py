@@ -21,6 +21,34 @@ def test_edit_latent_reproduces_the_reference_script_bit_exactly():
         assert d.shape == (1, 512) and abs(float(np.linalg.norm(d)) - 1.0) < 1e-6       # unit boundaries
 
 
+def test_skimage_ssim_restatement_known_answers():
+    from oracle.metrics_ref import skimage_ssim
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 255, (40, 36, 3))
+    assert abs(skimage_ssim(x, x) - 1.0) < 1e-12                                       # identical images
+    assert abs(skimage_ssim(x, 255 - x) - skimage_ssim(255 - x, x)) < 1e-12              # symmetric
+    flat = np.full((20, 20, 3), 100.0)
+    c1 = (0.01 * 255) ** 2                                                               # constant images: only the mean term is left
+    assert abs(skimage_ssim(flat, flat + 20) - (2 * 100 * 120 + c1) / (100 ** 2 + 120 ** 2 + c1)) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 64, 48), (1, 3, 23, 39), (3, 1, 7, 7)])
+def test_ssim_skimage_on_device_vs_oracle(shape):
+    """comparing-baseline.py:25 statistic (7x7 uniform window, sample covariance, cropped border) against the scipy-based
+    restatement; float32 accumulation on the device: 1e-4."""
+    from dge_amd.infer import ssim_skimage
+    from oracle.metrics_ref import skimage_ssim
+    from tests.golden import recipe as R
+    a = R.randn("ssim7.a", shape, 2, 0.5).clamp(-1, 1)
+    b = (a * 0.8 + R.randn("ssim7.b", shape, 2, 0.2)).clamp(-1, 1)
+    got = ssim_skimage(a.cuda(), b.cuda()).cpu().numpy()
+    for i in range(shape[0]):
+        ref = skimage_ssim(((a[i] + 1) * 127.5).permute(1, 2, 0).numpy(), ((b[i] + 1) * 127.5).permute(1, 2, 0).numpy())
+        assert abs(got[i] - ref) < 1e-4, (i, got[i], ref)
+    assert np.allclose(ssim_skimage(a.cuda(), a.cuda()).cpu().numpy(), 1.0, atol=1e-5)
+
+
 @pytest.mark.gpu
 def test_edit_then_synthesis_and_metrics_on_device(tmp_path):
     """embeded_img_edit.py end to end on a StyleGAN1 generator (seeded weights; the FFHQ checkpoint is not shipped): the edited
@@ -44,6 +72,8 @@ def test_edit_then_synthesis_and_metrics_on_device(tmp_path):
     cos = float((a.double().cpu().flatten() @ b.double().cpu().flatten()) / (a.double().norm() * b.double().norm()).cpu())
     assert abs(float(m["mse"]) - mse) < 1e-3 * mse and abs(float(m["psnr"]) - 10 * np.log10(255.0 ** 2 / mse)) < 1e-2
     assert abs(float(m["cosine"]) - cos) < 1e-4
+    from oracle.metrics_ref import skimage_ssim
+    assert abs(float(m["ssim"]) - skimage_ssim(a255[0].permute(1, 2, 0).numpy(), b255[0].permute(1, 2, 0).numpy())) < 1e-4
     same = image_metrics(a, a)
     assert float(same["mse"]) == 0.0 and abs(float(same["cosine"]) - 1.0) < 1e-5       # comparing-baseline.py:88 known answer
     save_image(torch.cat([a, b]), str(tmp_path / "edit.png"))
