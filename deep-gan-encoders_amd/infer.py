@@ -6,6 +6,8 @@
 * `image_metrics` - comparing-baseline.py:21-45 on device: PSNR / MSE on [0,255], cosine on [-1,1], LPIPS and the skimage SSIM of
                     that script (`ssim_skimage`: 7x7 uniform window, sample covariance, data_range 255 - a different statistic
                     from the training loss's pytorch_ssim, which `losses.space_loss` reports);
+* `load_images` / `reconstruct_images` - rec_real_img.py:84-120: image files -> `[N,3,S,S]` batch in [-1,1] (PIL, the script's
+                    Resize + ToTensor; `training_utils.imgPath2loader` with `bicubic=True`) -> E -> G, the "invert this image" path;
 * `save_image`    - torchvision.utils.save_image(img*0.5+0.5, path) for a single image batch laid out in one row.
 """
 import math
@@ -30,6 +32,36 @@ def reconstruct(step, z=None, iteration=4):
     imgs1, w1 = gen.sample(z)
     const2, w2 = E(imgs1, gen.const1) if big else E(imgs1)
     return dict(imgs1=imgs1, w1=w1, const2=const2, w2=w2, imgs2=gen.synth(w2))
+
+
+def load_images(paths, size, bicubic=False, device="cuda"):
+    """rec_real_img.py:84-98: Image.open(p).convert('RGB') -> Resize((size, size)) (PIL bilinear, what torchvision's Resize does
+    to a PIL image) -> ToTensor ([0,1], CHW) -> stacked, then the script's `* 2 - 1` (:101).  bicubic=True is
+    training_utils.imgPath2loader (:11-15: `image.resize((size, size))`, PIL's default filter).  Host-side file I/O."""
+    import numpy as np
+    from PIL import Image
+    out = []
+    for p in paths:
+        img = Image.open(p).convert("RGB")
+        img = img.resize((size, size)) if bicubic else img.resize((size, size), Image.BILINEAR)
+        out.append(torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0))
+    return (torch.stack(out, dim=0) * 2 - 1).to(device)
+
+
+@torch.no_grad()
+def reconstruct_images(step, imgs1):
+    """rec_real_img.py:100-112: real images [N,3,S,S] in [-1,1] -> E -> G, one image at a time as the script does (the
+    encoder's instance statistics are per sample, so batching changes nothing but the noise draws).  Returns (w2, imgs2)."""
+    from .e_align import _BigGANAdapter
+    gen, E = step.gen, step.E
+    if isinstance(gen, _BigGANAdapter):
+        raise ValueError("BigGAN needs the class-conditional vector of the image (rec_real_img.py:104); use E(img, cond) directly")
+    ws, outs = [], []
+    for j in imgs1:
+        _, w2 = E(j.unsqueeze(0))
+        ws.append(w2)
+        outs.append(gen.synth(w2))
+    return torch.cat(ws), torch.cat(outs)
 
 
 def edit_latent(w, direction, bonus=70.0, start=0, end=3):

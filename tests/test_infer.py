@@ -21,6 +21,28 @@ def test_edit_latent_reproduces_the_reference_script_bit_exactly():
         assert d.shape == (1, 512) and abs(float(np.linalg.norm(d)) - 1.0) < 1e-6       # unit boundaries
 
 
+def test_load_images_follows_the_script_transforms(tmp_path):
+    """rec_real_img.py:84-101 / training_utils.py:11-15 on files written here: shapes, range, the `*2-1` scale and both resamplers."""
+    from PIL import Image
+    from dge_amd.infer import load_images
+    rng = np.random.default_rng(1)
+    paths = []
+    for k, (h, w) in enumerate(((40, 56), (64, 64))):
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        p = str(tmp_path / f"img{k}.png")
+        Image.fromarray(arr).save(p)
+        paths.append((p, arr))
+    x = load_images([p for p, _ in paths], 32, device="cpu")
+    assert x.shape == (2, 3, 32, 32) and x.dtype == torch.float32 and float(x.min()) >= -1 and float(x.max()) <= 1
+    same = load_images([paths[1][0]], 64, device="cpu")                                  # no resize needed: exact pixels
+    assert torch.equal(same[0], torch.from_numpy(paths[1][1]).permute(2, 0, 1).float() / 255 * 2 - 1)
+    ref = np.asarray(Image.open(paths[0][0]).convert("RGB").resize((32, 32), Image.BILINEAR), dtype=np.float32) / 255 * 2 - 1
+    assert np.allclose(x[0].permute(1, 2, 0).numpy(), ref, atol=1e-6)
+    bic = load_images([paths[0][0]], 32, bicubic=True, device="cpu")
+    refb = np.asarray(Image.open(paths[0][0]).convert("RGB").resize((32, 32)), dtype=np.float32) / 255 * 2 - 1
+    assert np.allclose(bic[0].permute(1, 2, 0).numpy(), refb, atol=1e-6)
+
+
 def test_skimage_ssim_restatement_known_answers():
     from oracle.metrics_ref import skimage_ssim
     rng = np.random.default_rng(0)
@@ -98,3 +120,7 @@ def test_reconstruct_round_trip_runs_for_stylegan2():
     r = reconstruct(st)
     assert r["imgs1"].shape == r["imgs2"].shape == (2, 3, 64, 64) and r["w2"].shape == r["w1"].shape == (2, 10, 512)
     assert not r["imgs2"].requires_grad and torch.isfinite(r["imgs2"]).all()
+    # rec_real_img.py: images (here the generator's own) -> E -> G one at a time
+    from dge_amd.infer import reconstruct_images
+    w2, imgs2 = reconstruct_images(st, r["imgs1"])
+    assert w2.shape == (2, 10, 512) and imgs2.shape == (2, 3, 64, 64) and torch.isfinite(imgs2).all()
