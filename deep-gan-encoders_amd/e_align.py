@@ -246,6 +246,26 @@ class EAlignStep:
         return self._g_out
 
     # ------------------------------------------------------------------ one iteration
+    def _upload(self, t):
+        """Host tensor -> device without stalling the host: `t.to(device)` from pageable memory waits for the stream to drain
+        (the whole previous step), after which the GPU idles until the host has queued work again.  z (drawn on the CPU after
+        set_seed, like the reference, E_align_s2.py:103-104) goes through a small ring of pinned staging buffers instead; a
+        buffer is reused only after the copy that read it has completed."""
+        if t.is_cuda:
+            return t.to(self.dev)
+        ring = self.__dict__.setdefault("_pin_ring", {"i": 0, "slots": [None] * 4})
+        k = ring["i"] = (ring["i"] + 1) % len(ring["slots"])
+        slot = ring["slots"][k]
+        if slot is None or slot[0].shape != t.shape or slot[0].dtype != t.dtype:
+            slot = ring["slots"][k] = [torch.empty(t.shape, dtype=t.dtype, pin_memory=True), None]
+        if slot[1] is not None:
+            slot[1].synchronize()
+        slot[0].copy_(t)
+        out = slot[0].to(self.dev, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
+
     def step(self, iteration, z=None, noises=None, gen_noises=(None, None)):
         """`noises`: optional encoder noise tensors; `gen_noises`: optional (first, second) generator noise lists for
         generators that draw noise per call (StyleGAN1) -- both only for parity runs against captured reference noise."""
@@ -260,7 +280,7 @@ class EAlignStep:
             # every rank draws the same global z and takes its slice
             zg = self.gen.draw(iteration, B * self.world, self.dev) if big else torch.randn(B * self.world, self.z_dim)
             z = zg[self.rank * B:(self.rank + 1) * B]
-        z = z.to(self.dev)
+        z = self._upload(z)
         with torch.no_grad():
             imgs1, w1 = self.gen.sample(z, gen_noises[0])
         if noises is None and self.reference_noise:

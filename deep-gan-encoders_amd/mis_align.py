@@ -34,7 +34,7 @@ class MisAlignStep(EAlignStep):
         if z is None:
             zg = self.gen.draw(iteration, B * self.world, self.dev) if big else torch.randn(B * self.world, self.z_dim)
             z = zg[self.rank * B:(self.rank + 1) * B]
-        z = z.to(self.dev)
+        z = self._upload(z)
         with torch.no_grad():
             imgs1, w1 = self.gen.sample(z, gen_noises[0])
         if noises is None and self.reference_noise:
