@@ -16,18 +16,25 @@ else:
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     lo, hi = t0 + (t1 - t0) * f0, t0 + (t1 - t0) * f1
     rows = [r for r in rows if r[0] >= lo and r[1] <= hi]
-busy, cur_s, cur_e, gaps = 0, rows[0][0], rows[0][1], []
-for s, e, _ in rows[1:]:
+busy, cur_s, cur_e, gaps, big = 0, rows[0][0], rows[0][1], [], []
+prev_name = rows[0][2]
+for s, e, nm in rows[1:]:
     if s > cur_e:
-        busy += cur_e - cur_s; gaps.append(s - cur_e); cur_s, cur_e = s, e
+        busy += cur_e - cur_s; gaps.append(s - cur_e)
+        if s - cur_e > 20000:
+            big.append(((s - cur_e) / 1e3, prev_name.split("(")[0][-60:], nm.split("(")[0][-60:]))
+        cur_s, cur_e = s, e
     else:
         cur_e = max(cur_e, e)
+    prev_name = nm
 busy += cur_e - cur_s
 wall = max(r[1] for r in rows) - rows[0][0]
 short = [r for r in rows if r[1] - r[0] < 10000]
 print(f"kernels {len(rows)}, wall {wall/1e6:.2f} ms, busy (union) {busy/1e6:.2f} ms = {100*busy/wall:.1f} %, sum of durations {sum(r[1]-r[0] for r in rows)/1e6:.2f} ms")
 print(f"idle gaps: {len(gaps)}, total {sum(gaps)/1e6:.2f} ms; gaps > 20 us: {sum(1 for g in gaps if g > 20000)} totalling {sum(g for g in gaps if g > 20000)/1e6:.2f} ms")
 print(f"kernels shorter than 10 us: {len(short)} ({100*len(short)/len(rows):.0f} %), their durations sum to {sum(r[1]-r[0] for r in short)/1e6:.2f} ms")
+for g_, a_, b_ in big:
+    print(f"  gap {g_:7.1f} us  after {a_}  before {b_}")
 import collections, re
 cnt = collections.Counter()
 dur = collections.Counter()
