@@ -412,35 +412,44 @@ __global__ __launch_bounds__(256) void in_bwd_kernel(const T* __restrict__ gy, c
         const size_t ci = ((size_t)b * C + chunk * EP + e) * 3;
         A[e] = coef[ci]; Bc[e] = coef[ci + 1]; Cc[e] = coef[ci + 2];
     }
-    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
-        const int p = p0 + slot;
-        if (slot < ppi && p < HW) {
-            const size_t o = ((size_t)b * HW + p) * C + chunk * EP;
-            float g[EP], xv[EP];
-            if (gy) unpack16(*(const uint4*)(gy + o), g, (T*)nullptr);
-            else {
+    // two pixels per thread and iteration, all loads issued before the arithmetic (more bytes in flight per wave)
+    const int stride = gridDim.x * ppi;
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += 2 * stride) {
+        const int pA = p0 + slot, pB = pA + stride;
+        const bool okA = slot < ppi && pA < HW, okB = slot < ppi && pB < HW;
+        uint4 gA = make_uint4(0, 0, 0, 0), gB = gA, xA = gA, xB = gA, eA = gA, eB = gA;
+        const size_t oA = ((size_t)b * HW + pA) * C + chunk * EP, oB = ((size_t)b * HW + pB) * C + chunk * EP;
+        if (okA) { if (gy) gA = *(const uint4*)(gy + oA); xA = *(const uint4*)(X + oA); }
+        if (okB) { if (gy) gB = *(const uint4*)(gy + oB); xB = *(const uint4*)(X + oB); }
+        if (extra) {
+            if (okA) { const int q = extra_pool ? (pA / W / 2) * UW + (pA % W) / 2 : pA; eA = *(const uint4*)(extra + ((size_t)b * UHW + q) * C + chunk * EP); }
+            if (okB) { const int q = extra_pool ? (pB / W / 2) * UW + (pB % W) / 2 : pB; eB = *(const uint4*)(extra + ((size_t)b * UHW + q) * C + chunk * EP); }
+        }
+        float nzA = 0.f, nzB = 0.f;
+        if (act && noise) { if (okA) nzA = noise[(size_t)b * HW + pA]; if (okB) nzB = noise[(size_t)b * HW + pB]; }
 #pragma unroll
-                for (int e = 0; e < EP; e++) g[e] = 0.f;
-            }
-            unpack16(*(const uint4*)(X + o), xv, (T*)nullptr);
+        for (int h2 = 0; h2 < 2; h2++) {
+            if (!(h2 ? okB : okA)) continue;
+            float g[EP], xv[EP];
+            unpack16(h2 ? gB : gA, g, (T*)nullptr);
+            unpack16(h2 ? xB : xA, xv, (T*)nullptr);
 #pragma unroll
             for (int e = 0; e < EP; e++) g[e] = A[e] * g[e] + Bc[e] * xv[e] + Cc[e];
             if (extra) {
-                const int q = extra_pool ? (p / W / 2) * UW + (p % W) / 2 : p;
                 float ex[EP];
-                unpack16(*(const uint4*)(extra + ((size_t)b * UHW + q) * C + chunk * EP), ex, (T*)nullptr);
+                unpack16(h2 ? eB : eA, ex, (T*)nullptr);
 #pragma unroll
                 for (int e = 0; e < EP; e++) g[e] += extra_scale * ex[e];
             }
             if (act) {
-                const float nz = noise ? noise[(size_t)b * HW + p] : 0.f;
+                const float nz = h2 ? nzB : nzA;
 #pragma unroll
                 for (int e = 0; e < EP; e++) {
                     g[e] *= (xv[e] > 0.f ? 1.f : 0.2f);
                     s[0][e] += g[e]; s[1][e] += g[e] * nz;
                 }
             }
-            *(uint4*)(gout + o) = pack16(g, (T*)nullptr);
+            *(uint4*)(gout + (h2 ? oB : oA)) = pack16(g, (T*)nullptr);
         }
     }
     if (red_out) block_chan_flush<EP, 2>(s, cpt, ppi, red_out + (size_t)b * C * 2, C, red);       // per-sample partial sums
