@@ -91,7 +91,16 @@ def dtype_of(t):
     raise DgeError(f"unsupported activation dtype {t.dtype}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current stream of the current device as a hipStream_t.  torch.cuda.current_stream() builds a Stream object through
+    several Python layers (~4 us); with ~850 launches per step that was a fifth of the host time at batch 2, so the raw
+    handle is fetched directly when this torch exposes it."""
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
