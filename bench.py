@@ -232,10 +232,23 @@ def main():
         except Exception as ex:      # the baseline is informative; never lose the GPU numbers over it
             out["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {ex!r}"}
-    if rank == 0:
-        print(json.dumps(out))
+    # The JSON line must be the LAST line of stdout: RCCL writes a version banner through C stdio (block-buffered when stdout is a
+    # pipe), which would otherwise be flushed at process exit, after Python's print.  Tear the group down, flush C stdio, then print.
+    def flush_c():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+
+    flush_c()                                  # every rank empties its C stdio buffers ...
     if dist.is_initialized():
+        dist.barrier()                         # ... before rank 0 is allowed past this point
         dist.destroy_process_group()
+    flush_c()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
