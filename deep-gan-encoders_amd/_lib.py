@@ -124,9 +124,15 @@ def lib():
             fn = getattr(_lib, name)
             fn.argtypes = args
             fn.restype = C.c_int
-        _lib.dge_last_error.restype = C.c_char_p
-        _lib.dge_last_error.argtypes = []
+        for name in ("dge_last_error", "dge_last_kernel"):
+            getattr(_lib, name).restype = C.c_char_p
+            getattr(_lib, name).argtypes = []
     return _lib
+
+
+def last_kernel():
+    """Name of the kernel instantiation the last conv-family call of this thread selected (include/dge_hip.h)."""
+    return lib().dge_last_kernel().decode()
 
 
 def check(rc, what=""):

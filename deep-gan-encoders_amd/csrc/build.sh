@@ -1,19 +1,27 @@
 #!/bin/bash
 # Builds libdge_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+# Every object is compiled to a temporary name and renamed on success, and every compile job is waited for by pid:
+# a failed compile stops the build instead of linking a stale object.
 set -e
 cd "$(dirname "$0")"
 OUT=../libdge_hip.so
 SRCS="capi.hip conv_igemm.hip s2_kernels.hip $(ls *_kernels.hip | grep -v s2_kernels.hip || true)"
+mkdir -p build
 objs=""
+pids=""
 for f in $SRCS; do
   o="build/${f%.hip}.o"
-  mkdir -p build
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ ../../include/dge_hip.h -nt "$o" ]; then
     echo "hipcc $f"
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$f" -o "$o" &
+    rm -f "$o"
+    ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$f" -o "$o.tmp.$$" && mv "$o.tmp.$$" "$o" ) &
+    pids="$pids $!"
   fi
   objs="$objs $o"
 done
-wait
-hipcc --offload-arch=gfx950 -shared -fPIC $objs -o $OUT
+for p in $pids; do
+  wait "$p" || { echo "build.sh: a compile job failed" >&2; rm -f build/*.tmp.$$; exit 1; }
+done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$OUT.tmp.$$"
+mv "$OUT.tmp.$$" $OUT
 echo "built $OUT"

@@ -10,6 +10,11 @@ void dge_set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 extern "C" const char* dge_last_error(void) { return g_err; }
+static thread_local char g_kernel[160] = "";
+void dge_note_kernel(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap); va_end(ap);
+}
+extern "C" const char* dge_last_kernel(void) { return g_kernel; }
 extern "C" int dge_version(void) { return 100; }
 
 extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {

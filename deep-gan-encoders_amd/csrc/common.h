@@ -120,6 +120,8 @@ __device__ __forceinline__ float2 sum_slot_pairs(const float* __restrict__ base,
 
 // error plumbing shared by the C ABI translation units
 void dge_set_error(const char* fmt, ...);
+// name of the kernel instantiation the calling thread's last conv-family entry point selected (dge_last_kernel)
+void dge_note_kernel(const char* fmt, ...);
 #define DGE_CHECK(cond, ...) do { if (!(cond)) { dge_set_error(__VA_ARGS__); return -1; } } while (0)
 #define DGE_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); \
     if (e_ != hipSuccess) { dge_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return -3; } } while (0)

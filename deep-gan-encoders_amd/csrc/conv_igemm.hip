@@ -502,6 +502,7 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     p.tiles_y = (p.H + TH - 1) / TH;
     const int ntiles = (p.Ntot + BN - 1) / BN;
     const long grid = (long)p.tiles_x * p.tiles_y * p.B * ntiles;
+    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN);
     hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN>), dim3((unsigned)grid), dim3(256), 0, s, p);
     DGE_LAUNCH_CHECK("conv_igemm");
     return 0;

@@ -651,6 +651,8 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
     int groups = 512 / noi; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;   // few, long-running workgroups: one atomic flush each
     dim3 grid(noi, groups);
+    if (dtype == DGE_BF16) dge_note_kernel("conv_wgrad_tr<%d,%d>", ksize, tall ? 16 : 8);
+    else dge_note_kernel("conv_wgrad<f32,%d>", ksize);
 #define WG(T, KS) hipLaunchKernelGGL((conv_wgrad_kernel<T, KS>), grid, dim3(256), 0, s, (const T*)g, (const T*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups)
     if (dtype == DGE_BF16) {
 #define WT(KS, TH) hipLaunchKernelGGL((conv_wgrad_tr_kernel<KS, TH>), grid, dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)x, in_scale, in_shift, dw, B, H, W, cout, cin, tx, ty, groups)

@@ -76,6 +76,11 @@ typedef struct dge_conv_desc {
     int stats_slots;          /* >=1: workgroups spread their statistics atomics over this many copies (combine with dge_sum_slots) */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
+/* Test / tuning hook: the kernel instantiation the calling thread's last dge_conv2d / dge_upconv_fir / dge_conv_wgrad call
+ * selected, e.g. "conv_igemm<bf16,16,16,128,32,3,2,2>" (pixel tile TH x TW, N tile, K chunk, kernel size, wave grid),
+ * "upconv_fir<bf16>", "conv_wgrad_tr<3,16>".  The parity tests assert by name that the configurations which carry the
+ * benchmark (dispatch rules of csrc/conv_igemm.hip: launch_t) are the ones compared with the oracle. */
+const char* dge_last_kernel(void);
 int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumulate, dge_stream_t stream);
 /* the same sum over slots of [C][NS] partials, written planar: out[k*C + c] */
 int dge_sum_slots_planar(const float* partial, float* out, int nslot, int C, int NS, dge_stream_t stream);

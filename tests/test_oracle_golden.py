@@ -216,3 +216,41 @@ def test_c_oracle_modconv():
                         C.c_float(float(P["noise_strength"]) if not torgb else 0.0), C.c_void_p(ptr(y)),
                         2, cin, cout, res, k, int(up), int(not torgb), int(not torgb))
         close(y, g[f"c{ci}_y"])
+
+
+def test_conv_ref_layer_oracle_pinned_on_reference_blocks():
+    """oracle/conv_ref.py (the per-launch oracle of tests/test_fullsize_gpu.py) reproduces the outputs of the reference's own
+    ModulateConvBlock (stride-1, up, toRGB) and its data gradients agree with autograd through the same lines."""
+    import math
+    from oracle import conv_ref as CR
+    from tests.helpers import modconv_shapes
+    g = golden("s2_blocks.npz")
+    for ci in range(6):
+        cin, cout, res, up, k = [int(v) for v in g[f"c{ci}_cfg"]]
+        torgb = (k == 1)
+        P = R.fill_s2(modconv_shapes(cin, cout, res, k, noise=not torgb, up=bool(up)), seed=100 + ci)
+        rin = res // 2 if up else res
+        x = R.randn(f"mc{ci}.x", (2, cin, rin, rin), 7)
+        s = T(g[f"c{ci}_style"])
+        wscale = 1.0 / math.sqrt(cin * k * k)
+        wh = P["weight"] * wscale
+        d = None if torgb else torch.rsqrt((s * s) @ (wh * wh).sum((2, 3)).t() + 1e-8)
+        noise = None if torgb else P["noise"].reshape(1, res, res)
+        ns = None if torgb else float(P["noise_strength"])
+        kw = dict(gain=1.0, slope=1.0) if torgb else {}
+        fn = CR.upconv_fir if up else CR.modconv
+        y = fn(x, P["weight"], s, d, noise, ns, P["bias"], 1.0, wscale, **kw)
+        close(y, g[f"c{ci}_y"])
+    # adjoints used by the data-gradient launches: against autograd of the forward restatements
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 6, 6, generator=gen, requires_grad=True)
+    w = torch.randn(12, 8, 3, 3, generator=gen)
+    gy = torch.randn(2, 12, 6, 6, generator=gen)
+    y = torch.nn.functional.conv2d(x, w * 0.3, padding=1)
+    close(CR.conv_dgrad(gy, w, 0.3), torch.autograd.grad(y, x, gy)[0], rtol=1e-5)
+    wv = (w * 0.3).clone().requires_grad_(True)
+    y = torch.nn.functional.conv2d(x.detach(), wv, padding=1)
+    close(CR.conv_wgrad(gy, x.detach(), 3), torch.autograd.grad(y, wv, gy)[0], rtol=1e-5)
+    gu = torch.randn(2, 12, 12, 12, generator=gen)
+    xu = x.detach().clone().requires_grad_(True)
+    close(CR.up_dgrad(gu, w, 0.3, 6), torch.autograd.grad(CR.up_linear(xu, w, 0.3), xu, gu)[0], rtol=1e-5)
