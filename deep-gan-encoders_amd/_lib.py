@@ -107,6 +107,7 @@ SIGNATURES = {
     "dge_cam_resize": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dge_mask2cam_blocks": [_I],
     "dge_mask2cam": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
+    "dge_randn": [_P, _I, _P, _P, _P, _P, C.c_ulonglong, _P, _P],
     "dge_version": [],
 }
 

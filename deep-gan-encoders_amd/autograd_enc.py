@@ -20,7 +20,8 @@ def _packed(cache, conv, dtype, mode):
 
 def draw_noises(E, B, R, device):
     """The encoder's per-layer noise tensors ([B,1,r,r], two per block, one for the last): one generator launch for all of
-    them, handed out as contiguous slices (the reference draws 17 separate CPU tensors, model/E/E.py:60,73 - quirk Q6)."""
+    them, handed out as contiguous slices (the reference draws 17 separate CPU tensors, model/E/E.py:60,73 - quirk Q6).  Under
+    data parallelism each tensor is the rank's slice of the draw a single process would make for the global batch."""
     shapes = []
     for j in range(E.layer_count):
         r = R >> j
@@ -29,13 +30,7 @@ def draw_noises(E, B, R, device):
             shapes.append((B, 1, r, r))
     if torch.device(device).type == "cpu":        # reference_noise mode: the reference's own sequence of CPU draws
         return [torch.randn(*s) for s in shapes]
-    sizes = [B * s[2] * s[3] for s in shapes]
-    flat = torch.randn(sum(sizes), device=device)
-    out, off = [], 0
-    for s, n in zip(shapes, sizes):
-        out.append(flat[off:off + n].view(s))
-        off += n
-    return out
+    return ops.randn_rows(shapes, device)       # counter-based: the rank's rows of the global-batch draw (csrc/rng_kernels.hip)
 
 
 def heads_layout(E, B, dev):
@@ -143,14 +138,24 @@ def encoder_forward(E, img, noises=None, save=False):
 class EncoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, E, img, noises, *params):
+        if ctx.needs_input_grad[1]:
+            # embedding_v2_styleGAN2.py back-propagates through E(imgs2) into G: only E_Blur has the image gradient here
+            raise ops.DgeError("E.BE: the gradient w.r.t. the input image is not implemented on the HIP path (E_Blur provides it); "
+                               "detach the image or call under torch.no_grad()")
         need = any(ctx.needs_input_grad[3:])
         xo, w, saved = encoder_forward(E, img.detach(), noises, save=need)
         ctx.E, ctx.saved_acts = E, saved
-        ctx.mark_non_differentiable(xo)
+        ctx.set_materialize_grads(False)      # an output that no loss uses arrives as None in backward
         return xo, w
 
     @staticmethod
     def backward(ctx, g_x, g_w):
         from .autograd_enc_bwd import encoder_backward
+        if g_x is not None:
+            # a loss on the const output (space_loss(const2, const3) in embedding_v2_styleGAN2.py): refuse instead of dropping it
+            raise ops.DgeError("E.BE: a gradient arrived through the encoder's activation output, which the hand-written backward "
+                               "does not propagate (the E_align losses use w only, E_align_s2.py:203-221); detach it")
+        if g_w is None:
+            return (None, None, None) + (None,) * len(ctx.needs_input_grad[3:])
         grads = encoder_backward(ctx.E, ctx.saved_acts, g_w.contiguous())
         return (None, None, None) + tuple(grads)

@@ -183,6 +183,9 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
 class BigEncoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, E, img, cond_vector, noises, *params):
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise ops.DgeError("E_BIG: gradients w.r.t. the input image / condition vector are not implemented on the HIP path; "
+                               "detach them")
         need = any(ctx.needs_input_grad[4:])
         _, c_v, z, saved = big_encoder_forward(E, img.detach(), cond_vector, noises, save=need)
         ctx.E, ctx.saved_acts = E, saved

@@ -27,7 +27,7 @@ def blur_noises(E, B, R, dev):
         if blk.has_last_conv:
             if blk.fused_scale:
                 r = (R >> j) // 2
-                noises[ni] = torch.randn(B, 1, r, r, device=dev)
+                noises[ni] = ops.randn((B, 1, r, r), dev)
             ni += 1
     return noises
 

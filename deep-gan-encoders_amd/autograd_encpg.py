@@ -158,6 +158,8 @@ def pg_encoder_backward(E, saved, g_z):
 class PGEncoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, E, img, noises, *params):
+        if ctx.needs_input_grad[1]:
+            raise ops.DgeError("E_PG: the gradient w.r.t. the input image is not implemented on the HIP path; detach the image")
         need = any(ctx.needs_input_grad[3:])
         _, z, saved = pg_encoder_forward(E, img.detach(), noises, save=need)
         ctx.E, ctx.saved_acts = E, saved

@@ -16,7 +16,7 @@ def _layer_fwd(L, x, w_row, randomize_noise):
     s = L.style(w_row)
     d = ops.linear(s, wsq, None, 1.0, 1.0, L.eps, ops.LIN_RSQRT, 1.0, square_input=True)
     if randomize_noise:
-        noise = torch.randn(x.shape[0], L.res, L.res, device=x.device)
+        noise = ops.randn((x.shape[0], L.res, L.res), x.device)
     else:
         noise = L.noise.reshape(1, L.res, L.res)
     y = ops.conv2d(x, packed, L.out_c, 3, up=L.up, in_scale=s, out_scale=d, bias=L.bias, bias_scale=L.bscale,
@@ -90,7 +90,7 @@ def synthesis_run(mod, wp, randomize_noise=False, save=False):
         s = s_of(i, L.in_c)
         d = d_all[tab["d_off"][i]:tab["d_off"][i] + B * L.out_c].view(B, L.out_c)
         if randomize_noise:
-            noise = torch.randn(x.shape[0], L.res, L.res, device=x.device)
+            noise = ops.randn((x.shape[0], L.res, L.res), x.device)
         else:
             noise = L.noise.reshape(1, L.res, L.res)
         y = L.conv(x, s, d, noise, dt)

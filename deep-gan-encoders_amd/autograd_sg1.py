@@ -31,7 +31,7 @@ def decode_run(G, styles, lod, noises=None, save=False):
         if noises is not None:
             t = noises[ni].to(dev).float().reshape(-1, res, res).contiguous()
         else:
-            t = torch.randn(bn, res, res, device=dev)
+            t = ops.randn((bn, res, res), dev)
         ni += 1
         return t
 

@@ -34,6 +34,7 @@ class LREQAdam(Optimizer):
         """Call once before capturing a region that contains `calls_per_replay` step() calls."""
         self._graph_corr = torch.ones(calls_per_replay, dtype=torch.float32, device=device)
         self._graph_call = 0
+        self._graph_t = None            # a second capture starts from the optimizer's current step count again
 
     def graph_advance(self):
         """Before every capture / replay: advance all step counters by the region's step() calls and upload the factors.
@@ -50,6 +51,14 @@ class LREQAdam(Optimizer):
         self._graph_corr.copy_(torch.tensor(vals, dtype=torch.float32))
         self._graph_call = 0
 
+    def graph_count_replay(self):
+        """After every graph replay: the region's step() calls did not run on the host, so advance the per-parameter step
+        counters here (optimizer.state_dict() and a later eager step() then see the true t)."""
+        n = self._graph_corr.numel()
+        for st in self.state.values():
+            if len(st):
+                st["step"] += n
+
     def graph_reset(self):
         """Fresh optimizer state without changing any device address (embedding_img.py:83 between images)."""
         for st in self.state.values():
@@ -61,7 +70,10 @@ class LREQAdam(Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
         """grad_scale: optional device scalar multiplied into every gradient (DDP mean)."""
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():         # the closure re-evaluates the model (torch.optim convention)
+                loss = closure()
         for group in self.param_groups:
             ps, gs, vs, ns, steps = [], [], [], [], []
             keep = []

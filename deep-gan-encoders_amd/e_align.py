@@ -24,6 +24,8 @@ def set_seed(seed):
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+    from . import ops
+    ops.noise_seed(seed)            # the step's device noise is counter-based: (seed, draw number, global element index)
 
 
 class _StyleGAN2Adapter:
@@ -34,8 +36,10 @@ class _StyleGAN2Adapter:
 
     mix_mask = None          # device [L] mask: set by EAlignStep in hipGraph mode (static kernel sequence)
 
+    new_z = None             # parity runs: the reference's own second latent of the style mixing (stylegan2_generator.py:187)
+
     def sample(self, z, noises=None):
-        r = self.G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False, mix_mask=self.mix_mask)
+        r = self.G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False, mix_mask=self.mix_mask, new_z=self.new_z)
         return r["image"], r["wp"]
 
     def synth(self, w, noises=None):
@@ -112,6 +116,32 @@ class _BigGANAdapter:
         return self.G(w, self.conditions, self.truncation)[0]
 
 
+class _StagedWork:
+    """all-reduce of a device tensor through a host copy (gloo builds without device support): wait() writes the result back"""
+
+    def __init__(self, t, host, work):
+        self.t, self.host, self.work = t, host, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.t.copy_(self.host)
+
+
+def _all_reduce(t, async_op=False):
+    """Sum over ranks, in place.  RCCL ("nccl") reduces device tensors directly; with the gloo backend (the 2-process parity
+    test on one GPU, CPU-only debugging) device tensors are staged through the host."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.detach().cpu()
+        work = dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=async_op)
+        st = _StagedWork(t, host, work if async_op else None)
+        if async_op:
+            return st
+        st.wait()
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 class EAlignStep:
     def __init__(self, generator, E, lpips_model, lr=0.0015, beta_1=0.0, batch_size=2, z_dim=512,
                  reference_noise=False, exact_ddp=True, mapping=None):
@@ -143,6 +173,8 @@ class EAlignStep:
         self.last = {}
         if self.dist_on:
             E.__dict__["_early_grad_hook"] = self.early_reduce        # autograd_enc_bwd calls it after the deep blocks
+        from . import ops
+        ops.noise_dp(self.rank, self.world)      # device noise = this rank's rows of the global-batch draw
 
     # ------------------------------------------------------------------ DDP gradient exchange
     def _flat_views(self, early_names=()):
@@ -173,7 +205,7 @@ class EAlignStep:
         if len(names) != len(lay["early"]):
             return                                          # a different set than the layout was built for: leave it to _sync_grads
         torch._foreach_copy_([lay["views"][n] for n in names], [grads[n] for n in names])
-        self._early_work = dist.all_reduce(self._flat[:lay["n_early"]], op=dist.ReduceOp.SUM, async_op=True)
+        self._early_work = _all_reduce(self._flat[:lay["n_early"]], async_op=True)
 
     def _sync_grads(self):
         """All-reduce (sum) of every encoder gradient through the flat bucket; p.grad become views of it."""
@@ -190,10 +222,10 @@ class EAlignStep:
         for n in missing:                                   # parameters without a gradient this phase contribute zeros
             lay["views"][n].zero_()
         if work is not None:
-            dist.all_reduce(self._flat[lay["n_early"]:], op=dist.ReduceOp.SUM)
+            _all_reduce(self._flat[lay["n_early"]:])
             work.wait()
         else:
-            dist.all_reduce(self._flat, op=dist.ReduceOp.SUM)
+            _all_reduce(self._flat)
         for n, p in lay["named"].items():
             if p.grad is not None:
                 p.grad = lay["views"][n]
@@ -210,6 +242,11 @@ class EAlignStep:
         device generator.  `warmup` + 1 real iterations run inside this call."""
         if self.dist_on:
             raise RuntimeError("hipGraph capture is offered for single-process runs only (collectives are not captured)")
+        if isinstance(self.gen, _BigGANAdapter):
+            raise RuntimeError("hipGraph capture is not offered for --mtype 4: z is a scipy truncnorm draw and the class id a host "
+                               "decision of every iteration (E_align_s2.py:139-150); run the eager step")
+        from . import ops
+        ops.noise_graph_begin(self.dev)          # noise kernels read their seed from a device scalar from here on
         B = self.batch_size
         self._g_z = torch.zeros(B, self.z_dim, device=self.dev)
         if isinstance(self.gen, _StyleGAN2Adapter):
@@ -243,6 +280,7 @@ class EAlignStep:
         self._graph_inputs(it)
         self._g_iter = it + 1
         self._graph.replay()
+        self.opt.graph_count_replay()
         return self._g_out
 
     # ------------------------------------------------------------------ one iteration
@@ -266,12 +304,15 @@ class EAlignStep:
         slot[1].record()
         return out
 
-    def step(self, iteration, z=None, noises=None, gen_noises=(None, None)):
+    def step(self, iteration, z=None, noises=None, gen_noises=(None, None), new_z=None):
         """`noises`: optional encoder noise tensors; `gen_noises`: optional (first, second) generator noise lists for
-        generators that draw noise per call (StyleGAN1) -- both only for parity runs against captured reference noise."""
+        generators that draw noise per call (StyleGAN1); `new_z`: the style-mixing latent of StyleGAN2's train mode -- all only
+        for parity runs against captured reference noise."""
         G, E = self.G, self.E
         B = self.batch_size
         from . import ops
+        if isinstance(self.gen, _StyleGAN2Adapter):
+            self.gen.new_z = new_z
         ops.zero_arena_begin(self.dev)       # one memset for all of this step's accumulation buffers
         if z is None or not z.is_cuda:
             set_seed(iteration % 30000)

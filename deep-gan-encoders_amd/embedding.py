@@ -45,27 +45,40 @@ class EmbedStep:
         At batch 1 the eager loop is bound by host launch overhead (31 ms/iteration against ≈8 ms of GPU work at 1024^2);
         `replay()` re-runs the captured iteration on the static input `imgs1` with one graph launch.  The only host-side
         quantity that changes between iterations, Adam's sqrt(1 - beta2^t), is read from a device scalar that
-        `LREQAdam.graph_advance` refreshes before each replay.  Noise is drawn inside the graph from torch's
-        graph-safe device generator unless static `noises` are given.  Note that `warmup` + 1 real iterations run here."""
+        `LREQAdam.graph_advance` refreshes before each replay.  Noise is drawn inside the graph by the counter-based
+        generator (its seed is a device scalar refreshed per replay) unless static `noises` are given.  Note that `warmup` + 1 real iterations run here."""
+        from . import ops
         dev = imgs1.device
         self._g_imgs1 = imgs1.detach().clone()
         self.opt.graph_begin(2, dev)
+        ops.noise_graph_begin(dev)            # the captured noise kernels read their seed from a device scalar
+        self._noise_it = 0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.opt.graph_advance()
+                self._graph_inputs()
                 self.step(self._g_imgs1, noises)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
-        self.opt.graph_advance()
+        self._graph_inputs()
         with torch.cuda.graph(self._graph):
             self._g_out = self.step(self._g_imgs1, noises)
         return self._g_out
 
-    def replay(self):
+    def _graph_inputs(self):
+        """host-side inputs of one captured iteration: Adam's step factors and the noise seed (a new one per iteration)"""
+        from . import ops
         self.opt.graph_advance()
+        base = ops.NOISE.seed if getattr(self, "_noise_base", None) is None else self._noise_base
+        self._noise_base = base if base is not None else 0
+        self._noise_it += 1
+        ops.noise_seed(self._noise_base + self._noise_it)
+
+    def replay(self):
+        self._graph_inputs()
         self._graph.replay()
+        self.opt.graph_count_replay()
         return self._g_out
 
     def step(self, imgs1, noises=(None, None, None)):

@@ -17,8 +17,8 @@ class GlobalBatch:
         self.world = world
 
     def reduce(self, t):
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        from .e_align import _all_reduce
+        _all_reduce(t)
         return t
 
 
@@ -36,25 +36,20 @@ def attention_windows(H, W):
     return [(0, 0, H, W), (0, W // 8, H, W - 2 * (W // 8)), (oy, ox, H - 2 * oy, W - 2 * ox)]
 
 
-def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accumulate, gb=None):
-    """One space_loss evaluation on a window of a,b [B,C,H,W].  Returns out8 (device) and, when
-    g_out is given, adds weight * dloss/db into it."""
+_PK = 48          # floats per window in the packed reduction buffer: [0:8] the 8 sums, [8:40] SSIM slot copies, [40] LPIPS mean
+
+
+def _window_reduce(a, b, win, image_space, lpips_model, need_grad, pk, world):
+    """Pass 1 of one space_loss window: every per-rank partial sum goes into the packed row `pk` ([_PK] view, pre-zeroed), so
+    that a data-parallel run exchanges ALL windows of a phase in one all-reduce.  Returns the state pass 2 needs."""
     B, Cc, H, W = a.shape
     y0, x0, h, w = win
     dev = a.device
     L = lib()
     slots = ops.zeros((16, 8), dev)         # 16 slot copies of the 8 sums (atomics contention), added up below
     check(L.dge_loss_reduce(_f32(a), _f32(b), _p(slots), B, Cc, H, W, y0, x0, h, w, _stream()), "dge_loss_reduce")
-    sums = ops._sum_over_batch(slots)
-    n = float(B * Cc * h * w)
-    world = 1
-    if gb is not None:
-        gb.reduce(sums)
-        world = gb.world
-        n *= world
-    out8 = torch.empty(8, dtype=torch.float32, device=dev)
-    gp, k, npool = None, 1, 1.0
-    ssum = lp = None
+    ops._sum_over_batch(slots, pk[0:8])
+    st = dict(win=win, pk=pk, k=1, npool=1.0, n=float(B * Cc * h * w) * world, lp=None, ap=None)
     if image_space:
         k = _pool_factor(h)
         hp, wp = h // k, w // k
@@ -62,27 +57,56 @@ def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accum
         bp = torch.empty_like(ap)
         check(L.dge_crop_pool(_f32(a), _p(ap), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
         check(L.dge_crop_pool(_f32(b), _p(bp), B * Cc, H, W, y0, x0, h, w, k, _stream()), "dge_crop_pool")
-        npool = float(B * Cc * hp * wp) * world
-        ssum = ops.zeros((32,), dev)          # 32 slot copies of the SSIM sum (atomics contention), added up by the finaliser
-        dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if g_out is not None else None
-        check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(ssum), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
-        if gb is not None:
-            gb.reduce(ssum)
-        if g_out is not None:
-            gp = torch.empty_like(bp)
-            check(L.dge_ssim_bwd(_p(ap), _p(bp), _p(dmap), _p(gp), B * Cc, hp, wp, -1.0 / npool, 0, _stream()), "dge_ssim_bwd")
+        dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if need_grad else None
+        # pk[8:40]: 32 slot copies of the SSIM sum (atomics contention), added up by the finaliser
+        check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(pk[8:40]), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
+        st.update(k=k, npool=float(B * Cc * hp * wp) * world, ap=ap, bp=bp, dmap=dmap, g_lp=None)
         if lpips_model is not None:
-            lp, g_lp = lpips_model.value_and_grad(ap, bp, need_grad=g_out is not None)   # mean over batch, d/dbp
-            if gb is not None:
-                check(L.dge_axpy_scalar(_p(gb.reduce(lp.clone())), None, _p(lp), 1, 1.0 / world, 0, _stream()), "dge_axpy_scalar")
-            if g_out is not None:
-                check(L.dge_axpy_scalar(_p(g_lp), None, _p(gp), gp.numel(), 2.0 / world, 1, _stream()), "dge_axpy_scalar")
-    check(L.dge_space_loss_finalize(_p(sums), _p(ssum), _p(lp), _p(out8), n, npool, 1 if image_space else 0, _stream()),
-          "dge_space_loss_finalize")
+            lp, st["g_lp"] = lpips_model.value_and_grad(ap, bp, need_grad=need_grad)       # mean over the rank's batch, d/dbp
+            if world > 1:      # global mean = sum over ranks of (rank mean / world): joins the packed exchange
+                check(L.dge_axpy_scalar(_p(lp), None, _p(pk[40:41]), 1, 1.0 / world, 0, _stream()), "dge_axpy_scalar")
+                lp = pk[40:41]
+            st["lp"] = lp
+    return st
+
+
+def _window_finish(a, b, st, image_space, weight, g_out, accumulate, world):
+    """Pass 2: loss terms from the (globally reduced) sums and, when g_out is given, weight * dloss/db added into it."""
+    B, Cc, H, W = a.shape
+    y0, x0, h, w = st["win"]
+    dev = a.device
+    L = lib()
+    pk = st["pk"]
+    out8 = torch.empty(8, dtype=torch.float32, device=dev)
+    gp = None
+    if image_space and g_out is not None:
+        bp = st["bp"]
+        gp = torch.empty_like(bp)
+        check(L.dge_ssim_bwd(_p(st["ap"]), _p(bp), _p(st["dmap"]), _p(gp), B * Cc, bp.shape[2], bp.shape[3], -1.0 / st["npool"], 0,
+                             _stream()), "dge_ssim_bwd")
+        if st["g_lp"] is not None:
+            check(L.dge_axpy_scalar(_p(st["g_lp"]), None, _p(gp), gp.numel(), 2.0 / world, 1, _stream()), "dge_axpy_scalar")
+    check(L.dge_space_loss_finalize(_p(pk[0:8]), _p(pk[8:40]) if image_space else None, _p(st["lp"]), _p(out8), st["n"], st["npool"],
+                                    1 if image_space else 0, _stream()), "dge_space_loss_finalize")
     if g_out is not None:
-        check(L.dge_space_loss_bwd(_f32(a), _f32(b), _p(sums), _p(gp), _p(g_out), B * Cc, H, W, y0, x0, h, w, k, n,
+        check(L.dge_space_loss_bwd(_f32(a), _f32(b), _p(pk[0:8]), _p(gp), _p(g_out), B * Cc, H, W, y0, x0, h, w, st["k"], st["n"],
                                    float(weight), 1 if accumulate else 0, _stream()), "dge_space_loss_bwd")
     return out8
+
+
+def _space_loss_windows(a, b, wins, image_space, lpips_model, weights, g_outs, accumulate, gb=None):
+    """space_loss on several windows of a, b [B,C,H,W] (training_utils.py:54-99 each): all reductions first, ONE exchange of the
+    packed partial sums in a data-parallel run (`gb`), then the loss terms and gradients.  Returns the list of out8 tensors."""
+    world = gb.world if gb is not None else 1
+    pack = ops.zeros((len(wins), _PK), a.device)
+    sts = [_window_reduce(a, b, win, image_space, lpips_model, g_outs[i] is not None, pack[i], world) for i, win in enumerate(wins)]
+    if gb is not None:
+        gb.reduce(pack)
+    return [_window_finish(a, b, st, image_space, weights[i], g_outs[i], accumulate, world) for i, st in enumerate(sts)]
+
+
+def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accumulate, gb=None):
+    return _space_loss_windows(a, b, [win], image_space, lpips_model, [weight], [g_out], accumulate, gb)[0]
 
 
 class _ScaledGrad(torch.autograd.Function):
@@ -128,11 +152,9 @@ def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0), glob
     b = imgs2.detach().float().contiguous()
     need = imgs2.requires_grad and torch.is_grad_enabled()
     g = torch.zeros_like(b) if need else None
-    infos = []
-    for i, win in enumerate(attention_windows(a.shape[2], a.shape[3])):
-        # grad_windows[i] False: the window enters the loss VALUE only (embedding_img.py:95-107 detaches both crops)
-        infos.append(_space_loss_window(a, b, win, True, lpips_model, weights[i], g if grad_windows[i] else None, accumulate=True,
-                                        gb=global_batch))
+    # grad_windows[i] False: the window enters the loss VALUE only (embedding_img.py:95-107 detaches both crops)
+    infos = _space_loss_windows(a, b, attention_windows(a.shape[2], a.shape[3]), True, lpips_model, weights,
+                                [g if (need and grad_windows[i]) else None for i in range(3)], accumulate=True, gb=global_batch)
     info = torch.stack(infos)
     loss = info[0, 0] * float(weights[0]) + info[1, 0] * float(weights[1]) + info[2, 0] * float(weights[2])   # no host->device copy
     if need:

@@ -23,10 +23,13 @@ class MisAlignStep(EAlignStep):
         self.gbp = GuidedBackPropagation(vgg16)
         self.fused_attention = fused_attention
 
-    def step(self, iteration, z=None, noises=None, gen_noises=(None, None)):
+    def step(self, iteration, z=None, noises=None, gen_noises=(None, None), new_z=None):
         E = self.E
         B = self.batch_size
         from . import ops
+        from .e_align import _StyleGAN2Adapter
+        if isinstance(self.gen, _StyleGAN2Adapter):
+            self.gen.new_z = new_z
         ops.zero_arena_begin(self.dev)
         if z is None or not z.is_cuda:
             set_seed(iteration % 30000)

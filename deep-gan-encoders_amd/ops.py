@@ -79,6 +79,64 @@ def _sum_over_batch(partial, out=None):
     return out
 
 
+# ------------------------------------------------------------------ counter-based noise (dge_randn)
+class _Noise:
+    """State of the step's noise draws: `seed` (set by e_align.set_seed next to torch / numpy), a draw counter that names the
+    Philox subsequence of each tensor, and the data-parallel position (rank, world): a draw of per-sample rows [B, ...] is the
+    rank's slice of the global-batch tensor [world*B, ...], so N ranks x B reproduce one process at batch N*B exactly."""
+
+    def __init__(self):
+        self.seed, self.counter, self.rank, self.world, self.seed_dev = None, 0, 0, 1, None
+
+
+NOISE = _Noise()
+
+
+def noise_seed(seed):
+    NOISE.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    NOISE.counter = 0
+    if NOISE.seed_dev is not None:
+        # a fresh pageable host tensor per call: staged before copy_ returns, so the host may run replays ahead
+        NOISE.seed_dev.copy_(torch.tensor([NOISE.seed - (1 << 64) if NOISE.seed >= (1 << 63) else NOISE.seed], dtype=torch.int64))
+
+
+def noise_dp(rank, world):
+    NOISE.rank, NOISE.world = int(rank), int(world)
+
+
+def noise_graph_begin(device):
+    """hipGraph mode: from now on the kernels read the seed from a device scalar that noise_seed() refreshes before each replay."""
+    NOISE.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+    if NOISE.seed is not None:
+        noise_seed(NOISE.seed)
+
+
+def randn_rows(shapes, device):
+    """Normal noise tensors of per-sample shapes [(B, ...), ...] in ONE launch (contiguous slices of one buffer).  Tensor k
+    is draw number `counter + k`; its elements are those of rows [rank*B, (rank+1)*B) of the global [world*B, ...] tensor."""
+    if NOISE.seed is None:
+        noise_seed(torch.initial_seed())
+    n = len(shapes)
+    sizes = [int(math.prod(sh)) for sh in shapes]
+    starts, off = [], 0
+    for sz in sizes:
+        starts.append(off)
+        off += (sz + 3) & ~3                       # keep every tensor 16-byte aligned
+    flat = torch.empty(max(off, 1), dtype=torch.float32, device=device)
+    LL, ULL, UI = C.c_longlong * n, C.c_ulonglong * n, C.c_uint * n
+    goff = [NOISE.rank * sz for sz in sizes]
+    sub = [(NOISE.counter + k) & 0xFFFFFFFF for k in range(n)]
+    NOISE.counter += n
+    sd = C.c_void_p(NOISE.seed_dev.data_ptr()) if NOISE.seed_dev is not None else None
+    check(lib().dge_randn(_p(flat), n, LL(*starts), LL(*sizes), ULL(*goff), UI(*sub), C.c_ulonglong(NOISE.seed), sd, _stream()),
+          "dge_randn")
+    return [flat[st:st + sz].view(sh) for st, sz, sh in zip(starts, sizes, shapes)]
+
+
+def randn(shape, device):
+    return randn_rows([tuple(shape)], device)[0]
+
+
 def tdtype(dtype):
     return torch.bfloat16 if dtype == BF16 else torch.float32
 

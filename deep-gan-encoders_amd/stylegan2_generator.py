@@ -206,7 +206,7 @@ class ModulateConvBlock(nn.Module):
         noise = None
         if self.add_noise:
             if randomize_noise:
-                noise = torch.randn(x.shape[0], self.res, self.res, device=x.device)
+                noise = ops.randn((x.shape[0], self.res, self.res), x.device)
             else:
                 noise = self.noise.reshape(1, self.res, self.res)
         return self.conv(x, s, d, noise, dt), s
@@ -284,6 +284,14 @@ class StyleGAN2Generator(nn.Module):
 
     def forward(self, z, label=None, w_moving_decay=0.995, style_mixing_prob=0.9, trunc_psi=None, trunc_layers=None,
                 randomize_noise=False, **_unused_kwargs):
+        """Extra keywords: `mix_mask` (device [L] mask, hipGraph form of the style mixing) and `new_z` (the second latent of the
+        style mixing, reference :187 `torch.randn_like(z)`; default: drawn by the counter-based device generator, which under
+        data parallelism yields the rank's rows of the global-batch draw)."""
+        if z.requires_grad and torch.is_grad_enabled():
+            # the reference lets autograd run through the mapping network (baseline_utils/image2stylegan_w2z_opW.py optimises z);
+            # the HIP mapping has no backward: refuse loudly instead of returning a silently constant w
+            raise ops.DgeError("StyleGAN2Generator.forward: d/dz through the mapping network is not implemented on the HIP path; "
+                               "optimise w / wp (synthesis has a hand-written data gradient) or call under torch.no_grad()")
         with torch.no_grad():
             mapping_results = self.mapping(z, label)
             w = mapping_results["w"]
@@ -293,11 +301,14 @@ class StyleGAN2Generator(nn.Module):
                 import torch.distributed as dist
                 if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                     # the upstream code all_gather'ed w here (reference :178, commented out): global batch mean
-                    dist.all_reduce(batch_w_avg)
+                    from .e_align import _all_reduce
+                    _all_reduce(batch_w_avg)
                     batch_w_avg = batch_w_avg / dist.get_world_size()
                 self.truncation.w_avg.copy_(self.truncation.w_avg * w_moving_decay + batch_w_avg * (1 - w_moving_decay))
             if self.training and style_mixing_prob > 0:
-                new_z = torch.randn_like(z)
+                new_z = _unused_kwargs.get("new_z")
+                if new_z is None:
+                    new_z = ops.randn(tuple(z.shape), z.device)
                 new_w = self.mapping(new_z, label)["w"]
                 mix_mask = _unused_kwargs.get("mix_mask")
                 if mix_mask is not None:

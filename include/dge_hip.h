@@ -279,6 +279,14 @@ int dge_nearest_up2_bwd(const void* ghi, const void* x, void* glow, float* stats
 int dge_sn_group(const void* entries, int n, int maxO, int maxK, float* sigma, float eps, int training, dge_stream_t stream);
 int dge_sn_entry_size(void);
 
+/* ---- counter-based normal noise (Philox4x32-10 + Box-Muller; csrc/rng_kernels.hip) ----
+ * Replaces the torch.randn draws of the training step (model/E/E.py:60,73 encoder noise; stylegan2_generator.py:187 new_z,
+ * :911-913 randomize_noise; model/stylegan1/net.py noise) with draws that are a pure function of (seed, subseq, element index):
+ * segment i fills out[start[i] .. start[i]+count[i]) with elements goff[i].. of draw subseq[i], so a data-parallel rank
+ * generates exactly its rows of the global-batch tensor.  seed_dev (optional device scalar) overrides `seed` (hipGraph replay). */
+int dge_randn(float* out, int nseg, const long long* start, const long long* count, const unsigned long long* goff,
+              const unsigned int* subseq, unsigned long long seed, const unsigned long long* seed_dev, dge_stream_t stream);
+
 /* ---- StyleGAN2 up layer at algorithmic cost (stylegan2_generator.py:879-896 conv_transpose2d + 4x4 FIR, :911-921) ----
  * Transposed conv in phase form on the MFMAs (9 tap-MACs per input pixel instead of the 36 of the folded 3x3-per-phase
  * form of dge_conv2d(up=1)), FIR + demodulation / noise / bias / activation from LDS in the same kernel.
