@@ -30,6 +30,13 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     return *(uint32_t*)&h;
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
+#include <type_traits>
+template <int N, int I = 0> struct StaticFor {
+    template <class F> __device__ static __forceinline__ void run(F&& f) { f(std::integral_constant<int, I>{}); StaticFor<N, I + 1>::run(f); }
+};
+template <int N> struct StaticFor<N, N> { template <class F> __device__ static __forceinline__ void run(F&&) {} };
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int PER16 = 4;

@@ -42,12 +42,6 @@ template <> struct Mma<float> {
     }
 };
 
-// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N)
-template <int N, int I = 0> struct StaticFor {
-    template <class F> __device__ static __forceinline__ void run(F&& f) { f(std::integral_constant<int, I>{}); StaticFor<N, I + 1>::run(f); }
-};
-template <int N> struct StaticFor<N, N> { template <class F> __device__ static __forceinline__ void run(F&&) {} };
-
 // N uint4 values with compile-time-only indexing (keeps prefetch buffers in VGPRs: a plain array
 // indexed inside a lambda was being demoted to scratch / LDS by the compiler).
 template <int N> struct Regs {
@@ -549,6 +543,7 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
 }
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s) {
+    if (dge_conv_stream_eligible(p, dtype, ksize)) return dge_conv_stream_launch(p, s);     // HBM-bound layers: conv_stream.hip
     const int esize = dtype == DGE_BF16 ? 2 : 4;
     DGE_CHECK(ksize == 1 || ksize == 3, "conv: ksize %d unsupported", ksize);
     DGE_CHECK(p.Cin % (32 / esize) == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, 32 / esize);

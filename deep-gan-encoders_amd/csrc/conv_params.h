@@ -33,3 +33,7 @@ struct ConvParams {
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);
 extern "C" int dge_conv_ntile(int ntot);
+
+// conv_stream.hip: the streaming kernel for the HBM-bound small-channel 3x3 layers
+bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize);
+int dge_conv_stream_launch(const ConvParams& p, hipStream_t s);

@@ -42,6 +42,26 @@ def modconv(x, w, s, d, noise, noise_strength, bias, bscale, wscale, gain=2.0 **
     return torch.where(y > 0, y, slope * y) * gain
 
 
+def modconv_folded(x, w, s, d, noise, noise_strength, bias, bscale, wscale, gain=2.0 ** 0.5, slope=0.2, q=_ident):
+    """The same layer in the reference's FUSED-modulation form (:858-864: the style multiplies the weight, one weight per sample):
+    W'[b] = q(w*wscale * s[b,i]); `q` = the storage rounding of the per-sample weight (what csrc/conv_stream.hip holds in
+    registers).  Mathematically identical to `modconv`; the two differ only in where a storage rounding falls."""
+    ys = []
+    for b in range(x.shape[0]):
+        wb = w * wscale
+        if s is not None:
+            wb = q(wb * s[b][None, :, None, None])
+        ys.append(F.conv2d(x[b:b + 1], wb, padding=w.shape[-1] // 2))
+    y = torch.cat(ys)
+    if d is not None:
+        y = y * d[:, :, None, None]
+    if noise is not None:
+        y = y + noise[:, None] * noise_strength
+    if bias is not None:
+        y = y + bias[None, :, None, None] * bscale
+    return torch.where(y > 0, y, slope * y) * gain
+
+
 def upconv_fir(x, w, s, d, noise, noise_strength, bias, bscale, wscale, gain=2.0 ** 0.5, slope=0.2, q=_ident):
     """ModulateConvBlock.forward, scale_factor=2 branch (:879-896): x*style -> conv_transpose2d(flipped kernel, stride 2,
     padding 0) -> 4x4 FIR ([1,3,3,1] outer product, gain 4, pad 1; UpsamplingLayer-style filter :603-615) -> demod -> noise
@@ -82,6 +102,21 @@ def enc_conv(x, w, sc, sh, noise, noise_w, bias, slope=0.2, q=_ident):
     + bias, leaky_relu(0.2).  Returns (y, per-(b,c) sum, sum of squares of y) - the statistics the next norm reads."""
     xn = q(affine(x, sc, sh))
     y = F.conv2d(xn, w, padding=1)
+    y = y + noise_w[None, :, None, None] * noise[:, None] + bias[None, :, None, None]
+    y = torch.where(y > 0, y, slope * y)
+    yd = y.double()
+    return y, yd.sum((2, 3)), (yd * yd).sum((2, 3))
+
+
+def enc_conv_folded(x, w, sc, sh, noise, noise_w, bias, slope=0.2, q=_ident):
+    """enc_conv with the instance-norm scale folded into the weight, W'[b] = q(w * sc[b,i]), applied to x + sh/sc (zero padding
+    after the shift): W'.(x + sh/sc) == w.(sc*x + sh) exactly when q is the identity."""
+    ys = []
+    for b in range(x.shape[0]):
+        wb = q(w * sc[b][None, :, None, None])
+        xs = x[b:b + 1] + (sh[b] / sc[b])[None, :, None, None]
+        ys.append(F.conv2d(xs, wb, padding=1))
+    y = torch.cat(ys)
     y = y + noise_w[None, :, None, None] * noise[:, None] + bias[None, :, None, None]
     y = torch.where(y > 0, y, slope * y)
     yd = y.double()

@@ -68,15 +68,15 @@ SAMPLES = lambda B: sorted({0, B - 1})
 
 # (Cin, Cout, R, B) of the generator's stride-1 layers and the instantiation launch_t must select for them
 G_LAYERS = [
-    (32, 32, 1024, 8, "conv_igemm<bf16,16,16,32,32,3,4,1>"),       # layer16
-    (64, 64, 512, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>"),        # layer14
+    (32, 32, 1024, 8, "conv_stream<bf16,32,32,64,4,plain>"),       # layer16: the streaming kernel of the HBM-bound layers
+    (64, 64, 512, 8, "conv_stream<bf16,64,64,64,2,plain>"),        # layer14
     (128, 128, 256, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),     # layer12: the 128-wide N tile
     (256, 256, 128, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),     # layer10
     (512, 512, 64, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),      # layer8
     (512, 512, 32, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>"),       # layer6
     (512, 512, 16, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),        # layer4: small-tile configuration, 256-byte K chunks
     (512, 512, 4, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),         # layer0
-    (32, 32, 1024, 1, "conv_igemm<bf16,16,16,32,32,3,4,1>"),       # batch 1
+    (32, 32, 1024, 1, "conv_stream<bf16,32,32,64,4,plain>"),       # batch 1
 ]
 
 
@@ -99,9 +99,12 @@ def test_generator_stride1_layer_fullsize(cin, cout, R, B, kernel):
     assert _kernel() == kernel
     # the packed weight is w*wscale rounded to bf16: hand the oracle the same values
     wq = CR.bf16_round(w.cpu() * wscale)
+    # conv_stream folds the style into the per-sample weight (the reference's fused form), conv_igemm scales the activation:
+    # the storage rounding of the exact-arithmetic oracle sits where the kernel's does
+    exact = CR.modconv_folded if kernel.startswith("conv_stream") else CR.modconv
     for b in SAMPLES(B):
         a = (_nchw(x, b), wq, s[b:b + 1].cpu(), d[b:b + 1].cpu(), noise.cpu(), 0.37, bias.cpu(), 1.0, 1.0)
-        assert _one_rounding(_nchw(y, b), CR.modconv(*a, q=CR.bf16_round)) <= 0, b
+        assert _one_rounding(_nchw(y, b), exact(*a, q=CR.bf16_round)) <= 0, b
         e = _relmax(_nchw(y, b), CR.modconv(*a))
         print(f"storage err {cin}->{cout}@{R} b{b}: {e:.2e}")
         assert e < 6e-3, (b, e)            # measured 2.0e-3 .. 3.2e-3
@@ -153,10 +156,12 @@ def test_generator_up_layer_fullsize(cin, cout, Rin, B, kernel):
 
 ENC_CONVS = [
     # (cin, cout, R, B, stats, kernel)
-    (16, 16, 1024, 8, True, "conv_igemm<bf16,16,16,32,16,3,4,1>"),     # block 0 conv_1: 64 statistics slots
-    (16, 32, 1024, 8, False, "conv_igemm<bf16,16,16,32,16,3,4,1>"),    # block 0 conv_2
-    (32, 32, 512, 8, True, "conv_igemm<bf16,16,16,32,32,3,4,1>"),      # block 1 conv_1
-    (32, 64, 512, 8, False, "conv_igemm<bf16,16,16,64,32,3,4,1>"),     # block 1 conv_2
+    (16, 16, 1024, 8, True, "conv_stream<bf16,16,16,64,4,stats>"),     # block 0 conv_1: 64 statistics slots
+    (16, 32, 1024, 8, False, "conv_stream<bf16,16,32,64,4,plain>"),    # block 0 conv_2
+    (32, 32, 512, 8, True, "conv_stream<bf16,32,32,64,4,stats>"),      # block 1 conv_1
+    (32, 64, 512, 8, False, "conv_stream<bf16,32,64,64,2,plain>"),     # block 1 conv_2
+    (64, 64, 256, 8, True, "conv_stream<bf16,64,64,64,2,stats>"),      # block 2 conv_1
+    (64, 128, 256, 8, False, "conv_igemm<bf16,16,16,128,32,3,2,2>"),   # block 2 conv_2: back on the implicit-GEMM kernel
     (512, 512, 8, 8, True, "conv_igemm<bf16,8,8,64,128,3,2,2>"),       # block 7 conv_1
 ]
 
@@ -183,9 +188,10 @@ def test_encoder_conv_fullsize(cin, cout, R, B, stats, kernel):
         if R >= 512:
             assert st.nslot == 64          # the multi-slot statistics path of the large grids
         tot = st.buf.sum(0).cpu()          # [B,C,2]
+    exact = CR.enc_conv_folded if kernel.startswith("conv_stream") else CR.enc_conv
     for b in SAMPLES(B):
         a = (_nchw(x, b), w.cpu(), sc[b:b + 1].cpu(), sh[b:b + 1].cpu(), noise[b:b + 1].cpu(), nw.cpu(), bias.cpu())
-        ref, rs, rq = CR.enc_conv(*a, q=CR.bf16_round)
+        ref, rs, rq = exact(*a, q=CR.bf16_round)
         assert _one_rounding(_nchw(y, b), ref) <= 0, b
         if stats:
             # (sum, sum of squares) over up to 2^20 pixels, accumulated in f32 registers + f32 atomics over the slot copies:
@@ -230,9 +236,11 @@ def test_encoder_skip_conv_fullsize(cin, cout, R, B, kernel):
 
 DGRADS = [
     # (cout_fwd, cin_fwd, R, B, k, out_scale, kernel): data gradient of a forward conv cin_fwd -> cout_fwd
-    (16, 16, 1024, 8, 3, False, "conv_igemm<bf16,16,16,32,16,3,4,1>"),     # encoder block 0 conv_1
-    (32, 16, 1024, 8, 3, False, "conv_igemm<bf16,16,16,32,32,3,4,1>"),     # encoder block 0 conv_2 (K = 32 gradient channels)
-    (32, 32, 1024, 8, 3, True, "conv_igemm<bf16,16,16,32,32,3,4,1>"),      # generator layer16 (scaled by the style afterwards)
+    (16, 16, 1024, 8, 3, False, "conv_stream<bf16,16,16,64,4,dot>"),       # encoder block 0 conv_1
+    (32, 16, 1024, 8, 3, False, "conv_stream<bf16,32,16,64,4,dot>"),       # encoder block 0 conv_2 (K = 32 gradient channels)
+    (32, 32, 1024, 8, 3, True, "conv_stream<bf16,32,32,64,4,dot>"),        # generator layer16 (scaled by the style afterwards)
+    (64, 64, 512, 8, 3, True, "conv_stream<bf16,64,64,64,2,dot>"),         # generator layer14
+    (64, 32, 512, 8, 3, False, "conv_stream<bf16,64,32,32,4,dot>"),        # encoder block 1 conv_2
     (128, 128, 256, 8, 3, True, "conv_igemm<bf16,16,16,128,32,3,2,2>"),    # generator layer12
     (64, 32, 256, 8, 1, False, "conv_igemm<bf16,16,16,32,32,1,4,1>"),      # encoder block 1 conv_3 (1x1)
 ]
@@ -358,7 +366,68 @@ def test_lpips_first_conv_fullsize():
     w = w.to(torch.bfloat16).float()
     bias = 0.05 * torch.randn(64, device=DEV, generator=g)
     y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, 1.0), 64, 3, bias=bias, act=ops.ACT_RELU)
-    assert _kernel() == "conv_igemm<bf16,16,16,64,16,3,4,1>"
+    assert _kernel() == "conv_stream<bf16,16,64,64,2,plain>"
     for b in SAMPLES(B):
         ref = CR.modconv(_nchw(x, b), w.cpu(), None, None, None, 0.0, bias.cpu(), 1.0, 1.0, gain=1.0, slope=0.0)
         assert _one_rounding(_nchw(y, b), ref) <= 0, b
+
+
+RAGGED = [
+    # (B, H, W, cin, cout, flavour): strips that end inside a 64-pixel tile, heights that are no multiple of the row step,
+    # segments of unequal length - the shapes LPIPS' attention crops produce (176^2, 256x192) and odd ones
+    (2, 176, 176, 64, 64, "relu"),
+    (3, 130, 192, 16, 32, "enc"),
+    (2, 100, 172, 32, 32, "enc_stats"),
+    (1, 257, 68, 32, 16, "dot"),
+    (2, 64, 256, 16, 16, "g"),
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,flavour", RAGGED)
+def test_conv_stream_ragged_shapes(B, H, W, cin, cout, flavour):
+    """csrc/conv_stream.hip on ragged geometry, every sample and pixel compared (exact-arithmetic bound)."""
+    from dge_amd import ops
+    g = _gen(9000 + H + W + cin)
+    x = (torch.randn(B, H, W, cin, device=DEV, generator=g)).to(torch.bfloat16)
+    w = (_wgt(cout, cin, 3, g) / math.sqrt(9 * cin)).to(torch.bfloat16).float()
+    xc = x.float().permute(0, 3, 1, 2).cpu()
+    nchw = lambda t: t.float().permute(0, 3, 1, 2).cpu()
+    if flavour == "relu":
+        bias = 0.05 * torch.randn(cout, device=DEV, generator=g)
+        y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, 1.0), cout, 3, bias=bias, act=ops.ACT_RELU)
+        ref = CR.modconv(xc, w.cpu(), None, None, None, 0.0, bias.cpu(), 1.0, 1.0, gain=1.0, slope=0.0)
+    elif flavour == "g":
+        s = 1.0 + 0.3 * torch.randn(B, cin, device=DEV, generator=g)
+        d = 0.5 + torch.rand(B, cout, device=DEV, generator=g)
+        noise = torch.randn(1, H, W, device=DEV, generator=g)
+        bias = 0.2 * torch.randn(cout, device=DEV, generator=g)
+        y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, 1.0), cout, 3, in_scale=s, out_scale=d, bias=bias,
+                       noise=noise, noise_w=torch.tensor([0.37], device=DEV), act=ops.ACT_LRELU, gain=math.sqrt(2.0))
+        ref = CR.modconv_folded(xc, w.cpu(), s.cpu(), d.cpu(), noise.cpu(), 0.37, bias.cpu(), 1.0, 1.0, q=CR.bf16_round)
+    elif flavour in ("enc", "enc_stats"):
+        sc = 0.5 + torch.rand(B, cin, device=DEV, generator=g)
+        sh = 0.3 * torch.randn(B, cin, device=DEV, generator=g)
+        noise = torch.randn(B, H, W, device=DEV, generator=g)
+        nw = 0.1 * torch.randn(cout, device=DEV, generator=g)
+        bias = 0.1 * torch.randn(cout, device=DEV, generator=g)
+        st = ops.SlotStats(B, cout, DEV) if flavour == "enc_stats" else None
+        y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, 1.0), cout, 3, in_scale=sc, in_shift=sh, noise=noise,
+                       noise_w=nw, bias=bias, act=ops.ACT_LRELU, stats=st)
+        ref, rs, rq = CR.enc_conv_folded(xc, w.cpu(), sc.cpu(), sh.cpu(), noise.cpu(), nw.cpu(), bias.cpu(), q=CR.bf16_round)
+        if st is not None:
+            tot = st.buf.sum(0).cpu()
+            assert _stat_close(tot[:, :, 0], rs, ref.double().abs().sum((2, 3))) < 1e-5
+            assert _stat_close(tot[:, :, 1], rq) < 1e-5
+    else:
+        xin = (torch.randn(B, H, W, cout, device=DEV, generator=g)).to(torch.bfloat16)
+        dots = ops.SlotStats(B, cout, DEV)
+        y = ops.conv2d(x, ops.pack_conv_weight(w.permute(1, 0, 2, 3).contiguous(), ops.PACK_DGRAD, ops.BF16, 1.0), cout, 3,
+                       stats=dots, dot_src=xin)
+        ref = CR.conv_dgrad(xc, w.permute(1, 0, 2, 3).contiguous().cpu())
+        tot = dots.buf.sum(0).cpu().double()
+        xb = nchw(xin).double()
+        rd = ref.double()
+        assert _stat_close(tot[:, :, 0], (rd * xb).sum((2, 3)), (rd * xb).abs().sum((2, 3))) < 1e-5
+        assert _stat_close(tot[:, :, 1], rd.sum((2, 3)), rd.abs().sum((2, 3))) < 1e-5
+    assert _kernel().startswith("conv_stream<bf16,%d,%d," % (cin, cout)), _kernel()
+    assert _one_rounding(nchw(y), ref) <= 0

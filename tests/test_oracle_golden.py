@@ -254,3 +254,25 @@ def test_conv_ref_layer_oracle_pinned_on_reference_blocks():
     gu = torch.randn(2, 12, 12, 12, generator=gen)
     xu = x.detach().clone().requires_grad_(True)
     close(CR.up_dgrad(gu, w, 0.3, 6), torch.autograd.grad(CR.up_linear(xu, w, 0.3), xu, gu)[0], rtol=1e-5)
+
+
+def test_conv_ref_folded_forms_equal_the_unfused_ones():
+    """modconv_folded / enc_conv_folded (weight-side modulation, the reference's fused form :858-864) are the same functions
+    as modconv / enc_conv when no storage rounding is applied."""
+    from oracle import conv_ref as CR
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 9, 7, generator=gen)
+    w = torch.randn(6, 8, 3, 3, generator=gen)
+    s = 1 + 0.3 * torch.randn(2, 8, generator=gen)
+    d = 0.5 + torch.rand(2, 6, generator=gen)
+    nz = torch.randn(1, 9, 7, generator=gen)
+    bias = torch.randn(6, generator=gen)
+    close(CR.modconv_folded(x, w, s, d, nz, 0.3, bias, 1.0, 0.1), CR.modconv(x, w, s, d, nz, 0.3, bias, 1.0, 0.1), rtol=1e-5)
+    sc = 0.5 + torch.rand(2, 8, generator=gen)
+    sh = torch.randn(2, 8, generator=gen)
+    nzb = torch.randn(2, 9, 7, generator=gen)
+    nw = torch.randn(6, generator=gen)
+    a = CR.enc_conv_folded(x, w, sc, sh, nzb, nw, bias)
+    b = CR.enc_conv(x, w, sc, sh, nzb, nw, bias)
+    for u, v in zip(a, b):
+        close(u, v, rtol=2e-5)
