@@ -1,27 +1,28 @@
 // Streaming 3x3 convolution for the HBM-bound layers (Cin, Cout <= 64 at >= 128^2; bf16), gfx950.
 //
 // The 512^2 / 1024^2 layers of the generator (64 / 32 channels) and the first encoder blocks (16 / 32 channels) sit far
-// under the MFMA ridge: 107-288 flop/B.  conv_igemm_kernel ran them at 2.5-4x their HBM floor because every 16x16 tile is
-// one latency chain (halo load -> VALU prologue -> LDS -> MFMA -> LDS transpose -> store) with the weights re-fetched per tile.
-// This kernel is organised around the byte stream instead:
+// under the MFMA ridge (107-288 flop/B): their floor is the byte stream.  conv_igemm_kernel ran them at 2.5-4x that floor
+// because every 16x16 tile is one latency chain, and the first streaming version (a 4-wave workgroup sharing a strip, one
+// barrier per step) was bound by instruction issue: ~1400 instructions per step against 36 MFMAs.  This version is built
+// around the instruction count:
 //
-//   * a workgroup owns a column strip (TW pixels wide) of one sample and marches DOWN it, RS rows per step: activations
-//     enter a ring of NR = 4*RS halo rows in LDS, every row crosses HBM once per strip (horizontal halo only: (TW+2)/TW);
-//   * rows arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip, no VALU), three groups of RS rows ahead of the
-//     MFMAs, retired with counted s_waitcnt vmcnt; out-of-image halo pixels are read from a zero page (no border pass);
-//   * the prologue affine is folded into the WEIGHTS: W'[b][o][i] = bf16(W[o][i] * sc[b][i]) once per workgroup (a strip
-//     lies inside one sample) - the reference's own fused-modulation form (stylegan2_generator.py:858-864).  An additive
-//     in_shift (instance norm, model/E/E.py:57,68) becomes W'.(x + sh/sc): a per-(b,o) constant inside the image and a
-//     9-entry table T[o][tap] subtracted at border pixels (zero padding follows the norm);
-//   * the whole W' lives in REGISTERS as MFMA A operands (D[o][p] = sum_k W'[o][k] X[p][k]: out channels are the M rows,
-//     pixels the N columns), so the K loop reads ONE ds_read_b128 per MFMA (activation fragment, XOR-swizzled image) and no
-//     weights; each lane ends up with 16 channels of one pixel;
-//   * epilogue from registers: demodulation scale, noise (DMA'd rows, LDS), bias, lrelu/relu, gain; bf16 pack;
-//     v_permlane32_swap pairs give every lane 16 contiguous bytes -> two global_store_dwordx4 per 32x32 tile, no LDS
-//     transpose; (sum, sum of squares) statistics accumulate in registers over the whole strip and leave as one atomic per
-//     channel per workgroup; the data-gradient mode reads the `dot_src` rows from a third DMA ring.
-//
-// One barrier per step.  LDS 34-70 KB -> 2-4 workgroups per CU, each with two row groups in flight.
+//   * ONE WAVE owns a strip 32 pixels wide (the MFMA N tile) and marches down it one output row per step; its halo rows
+//     (34 pixels) live in a wave-private LDS ring of NR rows.  No workgroup barrier anywhere (Cout = 64 with Cin = 64 is
+//     the exception: the 288 weight registers are split over a 2-wave team that shares the ring, one 2-wave barrier per step);
+//   * rows arrive by LDS-DMA through a BUFFER descriptor of exactly one image row (buffer_load_dwordx4 ... offen lds):
+//     lanes left / right of the image are out of range and the hardware writes zeros for them, rows above / below the
+//     image use a zero-length descriptor - zero padding costs no instruction.  The immediate offset of the instruction
+//     advances the global AND the LDS address, so a row is 2-5 instructions behind one M0 write; the partial last piece
+//     runs under an EXEC mask (tools/probes/probe_ldsdma.hip pins all three properties on the hardware);
+//   * the ring period is unrolled: every ds_read_b128 of the K loop is `lane offset register + immediate`, no address
+//     arithmetic; fragments are prefetched PF reads ahead of their MFMA;
+//   * every per-channel scale is folded into the WEIGHTS, held in registers as MFMA A operands:
+//     W'[b][o][i] = bf16(W[o][i] * in_scale[b][i] * out_scale[b][o] * gain) - the reference's own fused-modulation form
+//     (stylegan2_generator.py:858-864: the style multiplies the weight, the demodulation divides it).  The bias (times gain,
+//     plus the interior value of a folded instance-norm shift, model/E/E.py:57,68) is the C operand of the first MFMA;
+//   * the rows of the M tile are PERMUTED so that a lane's 16 accumulators are two runs of 8 consecutive channels:
+//     bf16 pack -> two global_store_dwordx4 straight from registers (no LDS transpose, no cross-lane moves);
+//   * noise rows and (data-gradient mode) `dot_src` rows ride the same DMA stream through their own small rings.
 //
 // Reference math: model/stylegan2_generator.py:855-922 (stride-1 branch), model/E/E.py:50-85.
 #include <type_traits>
@@ -29,429 +30,534 @@
 #include <stdlib.h>
 #include "conv_params.h"
 
-__device__ __attribute__((aligned(256))) unsigned char dge_zero_page[2048];     // source of every out-of-image DMA lane
-
 namespace {
 
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
-}
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+
+__device__ __forceinline__ unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned lds_off(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
-enum { SMODE_PLAIN = 0, SMODE_STATS = 1, SMODE_DOT = 2 };
+// raw buffer descriptor (gfx9 layout): base, stride 0, num_records in bytes, DATA_FORMAT = 32
+__device__ __forceinline__ rsrc_t make_rsrc(unsigned long long base, unsigned bytes) {
+    rsrc_t r;
+    r[0] = rfl((unsigned)base); r[1] = rfl((unsigned)(base >> 32) & 0xffffu); r[2] = rfl(bytes); r[3] = 0x00020000u;
+    return r;
+}
 
-template <int CIN, int COUT, int TW, int RS, int WSPLIT, int MODE>
-struct SCfg {
-    static constexpr int PXB = CIN * 2, CH = PXB / 16, LOGCH = ilog2(CH);
-    static constexpr int HWP = TW + 2;
-    static constexpr int ROWB = HWP * PXB;
-    static constexpr int NG = 4;                                  // ring = NG groups of RS rows
-    static constexpr int GROUPB = RS * ROWB;
-    static constexpr int XPIECES = (GROUPB + 1023) / 1024, XPW = (XPIECES + 3) / 4;
-    static constexpr int KS = CIN / 16;
-    static constexpr int MT = (COUT + 31) / 32;
-    static constexpr int NTW = TW / 32;
-    static constexpr int NGROUPB = RS * TW * 4;                    // noise rows of a group (f32)
-    static constexpr int NPW = 1;                                   // one DMA slot per wave per group (only wave 0's is real)
-    static constexpr int CPB = COUT * 2;                            // dot_src bytes per pixel
-    static constexpr int DGROUPB = RS * TW * CPB;
-    static constexpr int DPIECES = (DGROUPB + 1023) / 1024, DPW = MODE == SMODE_DOT ? (DPIECES + 3) / 4 : 0;
-    static constexpr int NDMA = XPW + NPW + DPW;                    // DMA instructions per wave per group (uniform)
+// ---- LDS-DMA statements.  M0 (LDS base of the row) is written in the statement that uses it; the immediate offset moves the
+//      global and the LDS address together.  The partial last piece of a row runs under an EXEC mask (saved / restored in
+//      the statement; the code around it is wave-uniform).
+// one halo row of 34 pixels: 1088 B (Cin 16), 2176 B (Cin 32), 4352 B (Cin 64)
+template <int CIN> __device__ __forceinline__ void dma_row(unsigned voff, unsigned voff_b, unsigned voff_c, rsrc_t rs, unsigned m0v) {
+    unsigned long long keep;
+    if constexpr (CIN == 16) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xf\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen offset:1024 lds\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+    } else if constexpr (CIN == 32) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen offset:1024 lds\n\t"
+                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xff\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen offset:2048 lds\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+    } else {
+        // 8 pixels per piece, the chunk swizzle has a period of 16 pixels: odd pieces use the second offset register;
+        // piece 4 lies beyond the 12-bit offset field: second M0 value, third offset register
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %4, %3, 0 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen offset:2048 lds\n\t"
+                     "buffer_load_dwordx4 %4, %3, 0 offen offset:3072 lds\n\t"
+                     "s_mov_b32 m0, %6\n\t"
+                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\t"
+                     "buffer_load_dwordx4 %5, %3, 0 offen lds\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs), "v"(voff_b), "v"(voff_c), "s"(m0v + 4096u) : "memory");
+    }
+}
+// the same row split over a 2-wave team (Cin = 64): wave 0 pieces 0, 2, 4; wave 1 pieces 1, 3 and one zero-length piece
+// (both waves count three loads per row)
+__device__ __forceinline__ void dma_row64_team(int wave, unsigned voff, unsigned voff_b, unsigned voff_c, rsrc_t rs, rsrc_t rs_null,
+                                               unsigned m0v, unsigned m0_dummy) {
+    unsigned long long keep;
+    if (wave == 0) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %1, %3, 0 offen offset:2048 lds\n\t"
+                     "s_mov_b32 m0, %5\n\t"
+                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\t"
+                     "buffer_load_dwordx4 %4, %3, 0 offen lds\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs), "v"(voff_c), "s"(m0v + 4096u) : "memory");
+    } else {
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %2, 0 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %0, %2, 0 offen offset:3072 lds\n\t"
+                     "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %0, %3, 0 offen lds"
+                     : : "v"(voff_b), "s"(m0v), "s"(rs), "s"(rs_null), "s"(m0_dummy) : "memory");
+    }
+}
+// 4 bytes per lane (noise row: 32 pixels, lanes >= 32 are out of range)
+__device__ __forceinline__ void dma_dword(unsigned voff, rsrc_t rs, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %0, %2, 0 offen lds" : : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+}
+// dot_src row of this wave: NP pieces of 1 KB (32 pixels x 16 / 32 / 32 channels)
+template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigned voff1, rsrc_t rs, unsigned m0v) {
+    if constexpr (NP == 1)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds\n\t"
+                     "buffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds" : : "v"(voff), "s"(m0v), "s"(rs), "v"(voff1) : "memory");
+}
+
+enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3 };
+// FL_GEN:       uniform noise weight (or none), no input shift, no statistics            (generator forward, LPIPS convs)
+// FL_ENC:       per-channel noise weight, folded instance-norm shift with border terms    (encoder forward) - superset of GEN
+// FL_ENC_STATS: + (sum, sum of squares) of the output per (sample, channel)
+// FL_DOT:       data-gradient mode: y = acc * out_scale, statistics (sum acc * dot_src, sum acc); no bias / noise / activation
+
+template <int CIN, int COUT, int FL>
+struct SC {
+    static constexpr int PXB = CIN * 2, CH = PXB / 16, LOGCH = ilog2(CH), KS = CIN / 16;
+    static constexpr int TEAM = (CIN == 64 && COUT == 64) ? 2 : 1;            // waves sharing one strip
+    static constexpr int MT = COUT / 32 > 0 ? COUT / 32 : 1;                   // M tiles of the strip (Cout 16: one half-empty tile)
+    static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
+    static constexpr int HW = 34, RB = HW * PXB;
+    static constexpr int PIECES = (RB + 1023) / 1024;
+    static constexpr bool DOT = FL == FL_DOT, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS;
+    static constexpr bool NOISE = !DOT;
+    static constexpr int NR = 6;                                               // ring rows = unroll period
+    static constexpr int D = DOT ? 2 : 3;                                      // rows in flight ahead of the newest live row (<= NR - 3)
+    static constexpr int DR = DOT ? D + 1 : NR;                                         // dot ring rows (must divide NR); the noise ring has NR rows
+    static_assert(NR % DR == 0, "dot ring period");
+    static constexpr int CPB = COUT * 2;
+    static constexpr int CW = COUT / TEAM >= 32 ? 32 : 16;                      // channels of one wave's M tile set that are real (per tile)
+    static constexpr int DCH = CW * MTW * 2 / 16;                                // 16-byte chunks of this wave's channels per pixel
+    static constexpr int LOGDCH = ilog2(DCH);
+    static constexpr int DROWB = 32 * DCH * 16, DPIECES = DROWB / 1024;
+    static_assert(!DOT || MTW == 1, "data-gradient mode: one M tile per wave");
+    static constexpr int XPW = TEAM == 2 ? 3 : PIECES;                          // x loads per wave per row
+    static constexpr int LPR = XPW + (NOISE ? 1 : 0) + (DOT ? DPIECES : 0);    // loads per wave per step
     static constexpr int X_OFF = 0;
-    static constexpr int N_OFF = X_OFF + NG * XPIECES * 1024;      // groups are padded to whole pieces
-    static constexpr int D_OFF = N_OFF + NG * 1024;
-    static constexpr int DUMMY_OFF = D_OFF + (MODE == SMODE_DOT ? NG * DPIECES * 1024 : 0);
-    static constexpr int T_OFF = DUMMY_OFF + 1024;                  // T table [COUT][12] f32 (9 taps, sum) + reduce scratch
-    static constexpr int T_BYTES = 64 * 12 * 4 + 3 * 64 * 4 + 4 * 64 * 4;   // + epilogue constants osc / bg / nwg [64] + border sums [4][64]
-    static constexpr int R_OFF = T_OFF + T_BYTES;                   // statistics reduction scratch [4 waves][64 ch][2]
-    static constexpr int LDS_BYTES = R_OFF + 4 * 64 * 2 * 4;
-    static constexpr int XGROUP_STRIDE = XPIECES * 1024;
-    static constexpr int DGROUP_STRIDE = DPIECES * 1024;
-    static_assert(MT % WSPLIT == 0 && MT / WSPLIT == 1, "one M tile (32 out channels) per wave");
-    static_assert(RS * WSPLIT == 4, "4 waves = RS pixel rows x WSPLIT channel halves");
-    static_assert(NGROUPB <= 1024, "noise group is one DMA piece");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static constexpr int XRING = NR * RB;
+    static constexpr int N_OFF = (XRING + 1023) / 1024 * 1024;                  // per wave: noise ring NR x 256 B
+    static constexpr int NRING = NOISE ? NR * 256 : 0;
+    static constexpr int D_OFF = N_OFF + TEAM * NRING;                           // per wave: dot ring DR x DROWB
+    static constexpr int DRING = DOT ? DR * DROWB : 0;
+    static constexpr int T_OFF = D_OFF + TEAM * DRING;                           // per wave: T table [32*MTW][12] f32 + epilogue constants [3][32*MTW]
+    static constexpr int TBYTES = 32 * MTW * 16 * 4;
+    static constexpr int DUMMY_OFF = T_OFF + TEAM * TBYTES;
+    static constexpr int LDS_BYTES = DUMMY_OFF + (TEAM == 2 ? 1024 : 0);
+    static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + 36;
+    static constexpr int WPE = NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2);
+    static_assert(D <= NR - 3, "the slot of the row being fetched must be dead");
+    static_assert((D - 1) * LPR < 64, "vmcnt range");
 };
 
-// swizzle of the 16-byte channel chunks of a pixel in the LDS image (conflict-free ds_read_b128 of 16 consecutive pixels)
-template <int LOGCH> __device__ __forceinline__ int chunk_swz(int px) { return (px >> (4 - LOGCH)) & ((1 << LOGCH) - 1); }
+// swizzle of the 16-byte chunks of a pixel in an LDS image with 2^LOGC chunks per pixel (conflict-free ds_read_b128 of 16
+// consecutive pixels): applied on the SOURCE address of the DMA and on the read address
+template <int LOGC> __device__ __forceinline__ int chunk_swz(int px) { return (px >> (4 - LOGC)) & ((1 << LOGC) - 1); }
 
-template <int CIN, int COUT, int TW, int RS, int WSPLIT, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_stream_kernel(ConvParams p, int nseg, int seg_rows) {
-    using C = SCfg<CIN, COUT, TW, RS, WSPLIT, MODE>;
-    extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
+// channel of row m of the (permuted) M tile.  The accumulator of lane (pixel, kh) holds rows 8j + 4kh + i (j, i < 4) in
+// register 4j + i; with this map registers 0-7 are channels 8kh .. 8kh+7 and registers 8-15 channels 16+8kh .. 16+8kh+7
+// (16-channel tile: registers 0-7 = channels 8kh .. 8kh+7, rows >= 16 empty).
+template <int CW> __device__ __forceinline__ int chan_of_row(int m) {
+    const int j = m >> 3, k = (m >> 2) & 1, i = m & 3;
+    if (CW == 16) return j < 2 ? 8 * k + 4 * j + i : -1;
+    return 16 * (j >> 1) + 8 * k + 4 * (j & 1) + i;
+}
+
+template <int CIN, int COUT, int FL>
+__global__ __launch_bounds__((64 * SC<CIN, COUT, FL>::TEAM), (SC<CIN, COUT, FL>::WPE))
+void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int njobs, int jobs_per_xcd) {
+    using C = SC<CIN, COUT, FL>;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const unsigned lds0 = lds_off(lds);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int prow = wave % RS, mh = wave / RS;               // this wave's row within a step, its 32-channel half
+    const int lane = threadIdx.x & 63;
+    const int wave = C::TEAM == 2 ? (int)rfl(threadIdx.x >> 6) : 0;
     const int n31 = lane & 31, kh = lane >> 5;
 
-    // ---- job: (sample, strip, segment)
-    const int nstrips = (p.W + TW - 1) / TW;
-    int job = blockIdx.x;
-    const int seg = job % nseg; job /= nseg;
-    const int strip = job % nstrips;
-    const int b = job / nstrips;
-    const int x0 = strip * TW;
+    // ---- job: blocks of one XCD (blockIdx % 8) take a contiguous range of (sample, segment, strip): neighbouring strips
+    //      share their halo columns through that XCD's L2
+    int job = (blockIdx.x & 7) * jobs_per_xcd + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= jobs_per_xcd || job >= njobs) return;
+    const int strip = job % nstrips; job /= nstrips;
+    const int seg = job % nseg;
+    const int b = job / nseg;
+    const int x0 = strip * 32;
     const int r0 = seg * seg_rows;
-    const int rows = min(seg_rows, p.H - r0);                  // output rows of this segment (> 0 by construction)
-    const int nsteps = (rows + RS - 1) / RS;
-    const int glast = (rows + 1) / RS;                         // last group holding a needed halo row (halo index rows + 1)
+    const int rows = min(seg_rows, p.H - r0);
+    const bool full_strip = x0 + 32 <= p.W;
+    const bool edge_strip = x0 == 0 || x0 + 32 >= p.W;
 
-    const bf16_t* __restrict__ Xb = (const bf16_t*)p.x + (size_t)b * p.H * p.W * CIN;
-    bf16_t* __restrict__ Yb = (bf16_t*)p.y + (size_t)b * p.H * p.W * COUT;
-    const bf16_t* __restrict__ DOTb = (MODE == SMODE_DOT) ? (const bf16_t*)p.dot_src + (size_t)b * p.H * p.W * COUT : nullptr;
-    const float* __restrict__ NZb = p.noise ? p.noise + (size_t)b * p.noise_bstride : nullptr;
+    const unsigned xrow_bytes = (unsigned)p.W * C::PXB, yrow_bytes = (unsigned)p.W * C::CPB;
+    const unsigned long long Xb = (unsigned long long)p.x + (unsigned long long)b * p.H * xrow_bytes;
+    unsigned char* __restrict__ Yb = (unsigned char*)p.y + (size_t)b * p.H * yrow_bytes;
+    const unsigned long long NZb = p.noise ? (unsigned long long)(p.noise + (size_t)b * p.noise_bstride) : Xb;
+    const unsigned nzrow_bytes = p.noise ? (unsigned)p.W * 4 : 0;
+    const unsigned long long DOTb = C::DOT ? (unsigned long long)p.dot_src + (unsigned long long)b * p.H * yrow_bytes : Xb;
 
-    // ---- weights -> registers, prologue affine folded in:  W'[o][k] = bf16(W[o][k] * sc[b][k])
-    uint4 wf[9][C::KS];
+    // ---- DMA lane offsets.  x row: 16-byte unit u = lane (+ 64 per piece) = (halo pixel, chunk); source chunk swizzled
+    unsigned voff, voff_b = 0, voff_c = 0;
+    {
+        const int px = lane >> C::LOGCH, cs = lane & (C::CH - 1);
+        const int gx = x0 - 1 + px;
+        voff = (unsigned)(gx * C::PXB + ((cs ^ chunk_swz<C::LOGCH>(px)) << 4));      // negative (left of the image) = out of range
+        if constexpr (CIN == 64) {
+            voff_b = (unsigned)(gx * C::PXB + ((cs ^ chunk_swz<C::LOGCH>(px + 8)) << 4));   // odd pieces: pixel + 8 (the offset adds the rest)
+            voff_c = voff + 4096;                                                     // piece 4 (even), beyond the 12-bit offset field
+        }
+    }
+    const unsigned nvoff = lane < 32 ? (unsigned)((x0 + lane) * 4) : 0xfffffff0u;
+    unsigned dvoff = 0, dvoff1 = 0;
+    if constexpr (C::DOT) {
+        const int px = lane >> C::LOGDCH, cs = lane & (C::DCH - 1);
+        const int chunk0 = wave * 4;                                                   // first chunk of this wave's channels
+        dvoff = (unsigned)((x0 + px) * C::CPB + ((chunk0 + (cs ^ chunk_swz<C::LOGDCH>(px))) << 4));
+        constexpr int PPP = 64 / C::DCH;                                                // pixels per piece
+        dvoff1 = (unsigned)((x0 + px + PPP) * C::CPB + ((chunk0 + (cs ^ chunk_swz<C::LOGDCH>(px + PPP))) << 4)) - 1024u;
+    }
+    const rsrc_t rs_null = make_rsrc(Xb, 0);
+
+    // ---- issue of (x halo row h, noise row h-2, dot row h-2) into ring slot `slot` / `slot2`
+    // row pointers of the NEXT row to fetch (advance one image row per issue; rows outside the image are never dereferenced:
+    // their descriptor has length zero)
+    unsigned long long xptr = Xb + (unsigned long long)(long long)(r0 - 1) * xrow_bytes;
+    unsigned long long nptr = NZb + (unsigned long long)(long long)(r0 - 2) * nzrow_bytes;
+    unsigned long long dptr = DOTb + (unsigned long long)(long long)(r0 - 2) * yrow_bytes;
+    auto issue = [&](int h, int slot, int slot_n, int slot_d) {
+        const int gy = r0 - 1 + h;
+        const bool xv = (unsigned)gy < (unsigned)p.H && h <= rows + 1;
+        const rsrc_t rx = make_rsrc(xptr, xv ? xrow_bytes : 0u);
+        xptr += xrow_bytes;
+        const unsigned m0x = lds0 + C::X_OFF + slot * C::RB;
+        if constexpr (C::TEAM == 2) dma_row64_team(wave, voff, voff_b, voff_c, rx, rs_null, m0x, lds0 + C::DUMMY_OFF);
+        else dma_row<CIN>(voff, voff_b, voff_c, rx, m0x);
+        const bool ov = h >= 2 && h <= rows + 1;                                        // output row gy - 1 lies inside the segment
+        if constexpr (C::NOISE) {
+            const rsrc_t rn = make_rsrc(nptr, ov ? nzrow_bytes : 0u);
+            nptr += nzrow_bytes;
+            dma_dword(nvoff, rn, lds0 + C::N_OFF + wave * C::NRING + slot_n * 256);
+        }
+        if constexpr (C::DOT) {
+            const rsrc_t rd = make_rsrc(dptr, ov ? yrow_bytes : 0u);
+            dptr += yrow_bytes;
+            dma_dot<C::DPIECES>(dvoff, dvoff1, rd, lds0 + C::D_OFF + wave * C::DRING + slot_d * C::DROWB);
+        }
+    };
+    // rows 0 .. D+1 start before the weights are touched
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    StaticFor<C::D + 2>::run([&](auto hc) { constexpr int h = decltype(hc)::value; issue(h, h % C::NR, (h + C::NR - 2) % C::NR, (h + C::NR - 2) % C::NR % C::DR); });
+    // (noise / dot rows -2 and -1 are zero-length; their slot index only has to be in range)
+
+    // ---- weights -> registers, every scale folded in:  W'[o][k] = bf16(W[o][k] * in_scale[b][k] * out_scale[b][o] * gain)
+    //      (data-gradient mode keeps out_scale for the epilogue: its statistics are those of the unscaled accumulator)
+    uint4 wf[C::MTW][9][C::KS];
+    float* __restrict__ TT = (float*)(lds + C::T_OFF + wave * C::TBYTES);              // [32*MTW][16]: taps 0..8 | 9: all taps | 10 / 11: left / right tap column | 12: bias' | 13: noise weight | 14: out scale
     {
         const bf16_t* __restrict__ Wp = (const bf16_t*)p.w;
-        const int o = mh * 32 + n31;
-        float sc[C::KS][8], rt[C::KS][8];                       // scale and shift/scale of this lane's input channels
+        float sc[C::KS][8], rt[C::KS][8];
 #pragma unroll
         for (int ks = 0; ks < C::KS; ks++) {
             const int k0 = ks * 16 + kh * 8;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 sc[ks][e] = p.in_scale ? p.in_scale[b * CIN + k0 + e] : 1.f;
-                const float sh = p.in_shift ? p.in_shift[b * CIN + k0 + e] : 0.f;
+                const float sh = (C::ENC && p.in_shift) ? p.in_shift[b * CIN + k0 + e] : 0.f;
                 rt[ks][e] = sc[ks][e] != 0.f ? sh / sc[ks][e] : 0.f;
             }
         }
-        float* __restrict__ T = (float*)(lds + C::T_OFF);      // [64][12]: taps 0..8, [9] = sum over the taps
-        float tall = 0.f;
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            float tt = 0.f;
+        for (int mt = 0; mt < C::MTW; mt++) {
+            const int cl = chan_of_row<C::CW>(n31);                                       // channel within the tile, -1: empty row
+            const int o = (wave * C::MTW + mt) * 32 + cl;
+            const bool ov = cl >= 0 && o < COUT;
+            float osc = p.gain;
+            if (!C::DOT && p.out_scale && ov) osc *= p.out_scale[b * COUT + o];
+            float tall = 0.f, tleft = 0.f, tright = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < C::KS; ks++) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (o < p.Ntot) v = *(const uint4*)(Wp + ((size_t)(tap * p.Ntot + o) * CIN + ks * 16 + kh * 8));
-                if (p.in_scale || p.in_shift) {
+            for (int tap = 0; tap < 9; tap++) {
+                float tt = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < C::KS; ks++) {
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (ov) v = *(const uint4*)(Wp + ((size_t)(tap * p.Ntot + o) * CIN + ks * 16 + kh * 8));
                     float f[8];
                     unpack16(v, f, (bf16_t*)nullptr);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) f[e] *= sc[ks][e];
+                    for (int e = 0; e < 8; e++) f[e] *= sc[ks][e] * osc;
                     v = pack16(f, (bf16_t*)nullptr);
-                    if (p.in_shift) {                           // T uses the ROUNDED weights: W'.(x + sh/sc) is then exact in W'
+                    if constexpr (C::ENC) {                 // T uses the ROUNDED weights: W'.(x + sh/sc) is then exact in W'
                         unpack16(v, f, (bf16_t*)nullptr);
 #pragma unroll
                         for (int e = 0; e < 8; e++) tt += f[e] * rt[ks][e];
                     }
+                    wf[mt][tap][ks] = v;
                 }
-                wf[tap][ks] = v;
+                if constexpr (C::ENC) {
+                    tt += __shfl_xor(tt, 32, 64);                                           // the two K halves of the row
+                    if (kh == 0 && ov) TT[(mt * 32 + cl) * 16 + tap] = tt;
+                    tall += tt;
+                    if (tap % 3 == 0) tleft += tt;
+                    if (tap % 3 == 2) tright += tt;
+                }
             }
-            if (p.in_shift) {
-                tt += __shfl_xor(tt, 32, 64);                   // the two K halves of the row
-                if (kh == 0) T[o * 12 + tap] = tt;
-                tall += tt;
+            if (kh == 0 && ov) {
+                const int e = (mt * 32 + cl) * 16;
+                float bb = (!C::DOT && p.bias) ? p.bias[o] * p.bias_scale * p.gain : 0.f;
+                if constexpr (C::ENC) { TT[e + 9] = tall; TT[e + 10] = tleft; TT[e + 11] = tright; bb += tall; }
+                TT[e + 12] = bb;
+                TT[e + 13] = (C::NOISE && p.noise) ? p.noise_w[o * p.noise_w_stride] * p.gain : 0.f;
+                TT[e + 14] = (C::DOT && p.out_scale) ? p.out_scale[b * COUT + o] : 1.f;
             }
         }
-        if (p.in_shift && kh == 0) T[o * 12 + 9] = tall;
     }
-    __syncthreads();
-
-    // ---- per-channel epilogue constants in LDS (read back as float4 per group of 4 channels: keeps 48 registers free)
-    float* __restrict__ EPC = (float*)(lds + C::T_OFF + 64 * 12 * 4);      // osc[64] | bg[64] | nwg[64]
-    if (tid < 64) {
-        const float* __restrict__ T = (const float*)(lds + C::T_OFF);
-        const int ch = tid;
-        const bool cv = ch < COUT;
-        const float sc_o = (p.out_scale && cv) ? p.out_scale[b * COUT + ch] : 1.f;
-        const float o_ = sc_o * p.gain;
-        float bb = (p.bias && cv) ? p.bias[ch] * p.bias_scale * p.gain : 0.f;
-        if (p.in_shift && cv) bb += T[ch * 12 + 9] * o_;                    // interior value of the folded shift
-        EPC[ch] = o_;
-        EPC[64 + ch] = bb;
-        EPC[128 + ch] = (p.noise && cv) ? p.noise_w[ch * p.noise_w_stride] * p.gain : 0.f;
-        if (p.in_shift) {
-            float* __restrict__ BRD = EPC + 192;                             // [4][64]: left column, right column, top row, bottom row
-            BRD[ch] = T[ch * 12 + 0] + T[ch * 12 + 3] + T[ch * 12 + 6];
-            BRD[64 + ch] = T[ch * 12 + 2] + T[ch * 12 + 5] + T[ch * 12 + 8];
-            BRD[128 + ch] = T[ch * 12 + 0] + T[ch * 12 + 1] + T[ch * 12 + 2];
-            BRD[192 + ch] = T[ch * 12 + 6] + T[ch * 12 + 7] + T[ch * 12 + 8];
+    // channel (within the wave's tile set) of accumulator register r of this lane
+    auto chan_of_reg = [&](int mt, int r) { return mt * 32 + (C::CW == 16 ? 8 * kh + r : 16 * (r >> 3) + 8 * kh + (r & 7)); };
+    constexpr int NREG = C::CW == 16 ? 8 : 16;                                               // live accumulator registers per tile
+    f32x16_t biasv[C::MTW], zero16;
+#pragma unroll
+    for (int r = 0; r < 16; r++) zero16[r] = 0.f;
+    float nwv[C::MTW][C::ENC ? 16 : 1], oscv[C::DOT ? 16 : 1];
+#pragma unroll
+    for (int mt = 0; mt < C::MTW; mt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const bool live = r < NREG;
+            biasv[mt][r] = live ? TT[chan_of_reg(mt, r) * 16 + 12] : 0.f;
+            if constexpr (C::ENC) nwv[mt][r] = live ? TT[chan_of_reg(mt, r) * 16 + 13] : 0.f;
+            if constexpr (C::DOT) oscv[r] = live ? TT[chan_of_reg(mt, r) * 16 + 14] : 0.f;
         }
-    }
-    __syncthreads();
+    const float nw_uniform = (!C::ENC && C::NOISE && p.noise) ? p.noise_w[0] * p.gain : 0.f;
     const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
 
-    // ---- B-fragment byte offsets inside a halo row (N tile 0; tile 1 adds 32 pixels), per dx.  The k step only changes the
-    //      chunk bits: chunk = (ks*2 + kh) ^ swz(px), and every other term of the address is a multiple of the pixel pitch,
-    //      so address(ks) = address(0) ^ (ks << 5): one v_xor per read instead of KS registers per dx.
-    int boff[3];
+    // ---- B-fragment lane offsets: halo pixel n31 + dx, chunk (ks*2 + kh) ^ swizzle
+    unsigned loff[3][C::KS];
 #pragma unroll
-    for (int dx = 0; dx < 3; dx++) {
-        const int px = n31 + dx;
-        boff[dx] = px * C::PXB + ((kh ^ chunk_swz<C::LOGCH>(px)) << 4);
+    for (int dx = 0; dx < 3; dx++)
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ks++) {
+            const int px = n31 + dx;
+            loff[dx][ks] = lds0 + C::X_OFF + px * C::PXB + (((ks * 2 + kh) ^ chunk_swz<C::LOGCH>(px)) << 4);
+        }
+    const unsigned nzoff = lds0 + C::N_OFF + wave * C::NRING + n31 * 4;
+    unsigned doff[2] = {0, 0};
+    if constexpr (C::DOT) {
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            doff[q] = lds0 + C::D_OFF + wave * C::DRING + n31 * C::DCH * 16 + (((2 * q + kh) ^ chunk_swz<C::LOGDCH>(n31)) << 4);
     }
-    static_assert(C::ROWB % C::PXB == 0 && (C::PXB & (C::PXB - 1)) == 0, "pixel pitch is a power of two dividing every row offset");
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) u32x4_t* lds_u4p;
+    typedef const __attribute__((address_space(3))) float* lds_fp;
+    auto lds_u4 = [&](unsigned a) { const u32x4_t t = *(lds_u4p)a; return make_uint4(t[0], t[1], t[2], t[3]); };
+    auto lds_f = [&](unsigned a) { return *(lds_fp)a; };
 
-    // ---- DMA descriptors (per lane, per instruction slot; constant over the groups except the row)
-    int x_hr[C::XPW], x_col[C::XPW];                             // row within the group, byte offset within the image row (-1: outside)
-#pragma unroll
-    for (int i = 0; i < C::XPW; i++) {
-        const int pc = wave + 4 * i;
-        const int u = pc * 64 + lane;
-        const int per_row = C::HWP * C::CH;
-        const int hr = u / per_row, rem = u - hr * per_row;
-        const int px = rem >> C::LOGCH, cs = rem & (C::CH - 1);
-        const int gx = x0 - 1 + px;
-        const bool ok = (pc < C::XPIECES) && (hr < RS) && ((unsigned)gx < (unsigned)p.W);
-        x_hr[i] = hr;
-        x_col[i] = ok ? gx * C::PXB + ((cs ^ chunk_swz<C::LOGCH>(px)) << 4) : -1;
-    }
-    // noise: one piece per group (wave 0): lane -> 4 consecutive pixels of one row
-    const int nz_row = lane / (TW / 4), nz_px = (lane % (TW / 4)) * 4;
-    const bool nz_ok = (wave == 0) && p.noise && (nz_row < RS) && (x0 + nz_px < p.W);
-    int d_hr[C::DPW > 0 ? C::DPW : 1], d_col[C::DPW > 0 ? C::DPW : 1];
-    if constexpr (MODE == SMODE_DOT) {
-#pragma unroll
-        for (int i = 0; i < C::DPW; i++) {
-            const int pc = wave + 4 * i;
-            const int u = pc * 64 + lane;                           // 16-byte unit of the group's [RS][TW][COUT] bf16 image
-            constexpr int per_row = TW * C::CPB / 16;
-            const int hr = u / per_row, rem = u - hr * per_row;
-            const int px = rem / (C::CPB / 16), cs = rem % (C::CPB / 16);
-            const bool ok = (pc < C::DPIECES) && (hr < RS) && (x0 + px < p.W);
-            d_hr[i] = hr;
-            d_col[i] = ok ? (x0 + px) * C::CPB + cs * 16 : -1;
-        }
-    }
-    const unsigned char* zero = dge_zero_page + lane * 16;
-    const size_t xrow_bytes = (size_t)p.W * C::PXB, drow_bytes = (size_t)p.W * C::CPB;
+    const int gx = x0 + n31;
+    const bool pv = gx < p.W;
+    // output byte offset of this lane inside an image row: pixel, this wave's channels, this lane's first run of 8
+    const unsigned yoff = (unsigned)gx * C::CPB + (unsigned)(wave * C::MTW * 32 * 2) + kh * 16;
 
-    auto issue_group = [&](int g) {
-        const int slot = g & (C::NG - 1);
-        const bool live = g <= glast;
-        const int hrow0 = r0 - 1 + g * RS;                          // image row of the group's first halo row
+    float s0[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s1[C::MTW][(C::STATS || C::DOT) ? 16 : 1];
+    if constexpr (C::STATS || C::DOT) {
 #pragma unroll
-        for (int i = 0; i < C::XPW; i++) {
-            const int pc = wave + 4 * i;
-            const int row = hrow0 + x_hr[i];
-            const bool ok = live && x_col[i] >= 0 && (unsigned)row < (unsigned)p.H;
-            const unsigned char* src = ok ? (const unsigned char*)Xb + (size_t)row * xrow_bytes + x_col[i] : zero;
-            const unsigned dst = pc < C::XPIECES ? lds0 + C::X_OFF + slot * C::XGROUP_STRIDE + pc * 1024 : lds0 + C::DUMMY_OFF;
-            glds16(src, __builtin_amdgcn_readfirstlane(dst));
-        }
-        {   // noise rows of the OUTPUT rows r0 + g*RS .. (they are consumed at step g)
-            const int row = r0 + g * RS + nz_row;
-            const bool ok = live && nz_ok && row < p.H;
-            const unsigned char* src = ok ? (const unsigned char*)(NZb + (size_t)row * p.W + x0 + nz_px) : zero;
-            const unsigned dst = wave == 0 ? lds0 + C::N_OFF + slot * 1024 : lds0 + C::DUMMY_OFF;
-            glds16(src, __builtin_amdgcn_readfirstlane(dst));
-        }
-        if constexpr (MODE == SMODE_DOT) {
+        for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
-            for (int i = 0; i < C::DPW; i++) {
-                const int pc = wave + 4 * i;
-                const int row = r0 + g * RS + d_hr[i];
-                const bool ok = live && d_col[i] >= 0 && row < p.H;
-                const unsigned char* src = ok ? (const unsigned char*)DOTb + (size_t)row * drow_bytes + d_col[i] : zero;
-                const unsigned dst = pc < C::DPIECES ? lds0 + C::D_OFF + slot * C::DGROUP_STRIDE + pc * 1024 : lds0 + C::DUMMY_OFF;
-                glds16(src, __builtin_amdgcn_readfirstlane(dst));
+            for (int r = 0; r < 16; r++) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; }
+    }
+
+    // ---- one output row.  I = position in the ring period (compile time): halo rows in slots I, I+1, I+2 (mod NR)
+    auto step = [&](auto ic, int s) {
+        constexpr int I = decltype(ic)::value;
+        // row s+2 (and the noise / dot row s) has landed when at most (D-1) rows' loads are still in flight
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"((C::D - 1) * C::LPR) : "memory");
+        if constexpr (C::TEAM == 2) __builtin_amdgcn_s_barrier();     // the partner's pieces landed; it finished step s-1
+        issue(s + 2 + C::D, (I + 2 + C::D) % C::NR, (I + C::D) % C::NR, (I + C::D) % C::DR);
+
+        const int gy = r0 + s;
+        constexpr int NQ = 9 * C::KS;
+        constexpr int PF = NQ < 6 ? NQ : 6;
+        auto frag_addr = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int tap = q / C::KS, ks = q % C::KS, dy = tap / 3, dx = tap % 3;
+            return loff[dx][ks] + (unsigned)(((I + dy) % C::NR) * C::RB);
+        };
+        float nz = 0.f;
+        if constexpr (C::NOISE) nz = lds_f(nzoff + (I % C::NR) * 256);
+        uint4 bq[PF];
+        StaticFor<PF>::run([&](auto qc) { bq[decltype(qc)::value] = lds_u4(frag_addr(qc)); });
+        f32x16_t acc[C::MTW];
+        StaticFor<NQ>::run([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int tap = q / C::KS, ks = q % C::KS;
+            const bf16x8_t bf = *(const bf16x8_t*)&bq[q % PF];
+#pragma unroll
+            for (int mt = 0; mt < C::MTW; mt++)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[mt][tap][ks], bf, q == 0 ? (C::DOT ? zero16 : biasv[mt]) : acc[mt], 0, 0, 0);
+            if constexpr (q + PF < NQ) bq[q % PF] = lds_u4(frag_addr(std::integral_constant<int, q + PF>{}));
+        });
+
+        // pin the issue order: PF (+ noise) reads, then one read per MTW MFMAs, then the last PF fragments' MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, PF + (C::NOISE ? 1 : 0), 0);
+        StaticFor<NQ - PF>::run([&](auto) {
+            __builtin_amdgcn_sched_group_barrier(0x008, C::MTW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, PF * C::MTW, 0);
+        // ---------------- epilogue: this lane = pixel gx, NREG channels per tile
+        unsigned char* __restrict__ yrow = Yb + (size_t)gy * yrow_bytes;
+#pragma unroll
+        for (int mt = 0; mt < C::MTW; mt++) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = acc[mt][r];
+            if constexpr (C::ENC) {
+                // zero padding follows the norm: taps that fall outside the image do not carry the folded shift
+                const bool top = gy == 0, bot = gy == p.H - 1;
+                if (edge_strip | top | bot) {
+                    const float cl = gx == 0 ? 1.f : 0.f, cr = gx == p.W - 1 ? 1.f : 0.f;
+#pragma unroll
+                    for (int r = 0; r < NREG; r++) {
+                        const float* __restrict__ T = TT + chan_of_reg(mt, r) * 16;
+                        float corr = cl * T[10] + cr * T[11];
+                        if (top) corr += T[0] + T[1] + T[2] - cl * T[0] - cr * T[2];
+                        if (bot) corr += T[6] + T[7] + T[8] - cl * T[6] - cr * T[8];
+                        v[r] -= corr;
+                    }
+                }
+            }
+            if constexpr (C::DOT) {
+                uint4 dd[2];
+                dd[0] = lds_u4(doff[0] + (I % C::DR) * C::DROWB);
+                if constexpr (NREG == 16) dd[1] = lds_u4(doff[1] + (I % C::DR) * C::DROWB);
+#pragma unroll
+                for (int q = 0; q < NREG / 8; q++) {
+                    float d[8];
+                    unpack16(dd[q], d, (bf16_t*)nullptr);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { s0[mt][8 * q + e] = fmaf(v[8 * q + e], d[e], s0[mt][8 * q + e]); s1[mt][8 * q + e] += v[8 * q + e]; }
+                }
+#pragma unroll
+                for (int r = 0; r < NREG; r++) v[r] *= oscv[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < NREG; r++) {
+                    float t;
+                    if constexpr (C::ENC) t = fmaf(nwv[mt][r], nz, v[r]);
+                    else t = fmaf(nw_uniform, nz, v[r]);
+                    v[r] = fmaxf(t, t * slope);
+                }
+                if constexpr (C::STATS) {
+#pragma unroll
+                    for (int r = 0; r < NREG; r++) { s0[mt][r] += v[r]; s1[mt][r] = fmaf(v[r], v[r], s1[mt][r]); }
+                }
+            }
+            uint4 o0 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+            uint4 o1 = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
+            unsigned char* dst = yrow + yoff + mt * 64;
+            if (full_strip) {
+                *(uint4*)dst = o0;
+                if constexpr (NREG == 16) *(uint4*)(dst + 32) = o1;
+            } else if (pv) {
+                *(uint4*)dst = o0;
+                if constexpr (NREG == 16) *(uint4*)(dst + 32) = o1;
             }
         }
     };
 
-    float s0[16], s1[16];                                         // statistics over the whole strip segment (registers)
-#pragma unroll
-    for (int r = 0; r < 16; r++) { s0[r] = 0.f; s1[r] = 0.f; }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // parameter loads are done before the counted DMA stream starts
-    issue_group(0); issue_group(1); issue_group(2);
-
-    for (int s = 0; s < nsteps; s++) {
-        // groups s and s+1 must have landed (step s reads halo rows s*RS .. s*RS+RS+1); group s+2 may stay in flight.
-        // vmcnt counts this wave's stores too: they only make the wait conservative (loads retire in order among loads).
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(C::NDMA) : "memory");
-        __builtin_amdgcn_s_barrier();                              // every wave's pieces landed; every wave finished step s-1
-        if (!(p.dbg & 1)) issue_group(s + 3);                      // into the slot of group s-1, dead since the barrier
-        else { for (int i = 0; i < C::NDMA; i++) glds16(zero, __builtin_amdgcn_readfirstlane(lds0 + C::DUMMY_OFF)); }
-
-        const int ro = s * RS + prow;                              // output row (segment relative); halo rows ro .. ro+2
-        const int gy = r0 + ro;
-        if (ro < rows) {
-            unsigned rowbase[3];
-#pragma unroll
-            for (int dy = 0; dy < 3; dy++) {
-                const int hr = ro + dy;
-                rowbase[dy] = C::X_OFF + ((hr / RS) & (C::NG - 1)) * C::XGROUP_STRIDE + (hr % RS) * C::ROWB;
+    for (int s0_ = 0; s0_ < rows; s0_ += C::NR) {
+        bool done = false;
+        StaticFor<C::NR>::run([&](auto ic) {
+            constexpr int I = decltype(ic)::value;
+            if (!done) {
+                if (s0_ + I < rows) step(ic, s0_ + I);
+                else done = true;
             }
-            const float* __restrict__ nzrow = (const float*)(lds + C::N_OFF + (s & (C::NG - 1)) * 1024) + prow * TW;
-            const unsigned char* __restrict__ drow = lds + C::D_OFF + (s & (C::NG - 1)) * C::DGROUP_STRIDE + prow * TW * C::CPB;
-#pragma unroll 1
-            for (int nt = 0; nt < C::NTW; nt++) {
-                f32x16_t acc;
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[r] = 0.f;
-                const unsigned char* base = lds + nt * 32 * C::PXB;
-                // software pipelined: the fragment of step q+1 is read before the MFMA of step q
-                constexpr int NQ = 9 * C::KS;
-                uint4 bfr[2];
-                bfr[0] = *(const uint4*)(base + rowbase[0] + boff[0]);
-                if (!(p.dbg & 2))
-                StaticFor<NQ>::run([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    if constexpr (q + 1 < NQ) {
-                        constexpr int t1 = (q + 1) / C::KS, k1 = (q + 1) % C::KS;
-                        bfr[(q + 1) & 1] = *(const uint4*)(base + ((rowbase[t1 / 3] + boff[t1 % 3]) ^ (k1 << 5)));
-                    }
-                    constexpr int t = q / C::KS, k = q % C::KS;
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[t][k], *(const bf16x8_t*)&bfr[q & 1], acc, 0, 0, 0);
-                });
-                // ---------------- epilogue of the 32 (channels) x 32 (pixels) tile: this lane = pixel px, 16 channels
-                const int px = nt * 32 + n31;
-                const int gx = x0 + px;
-                const bool pv = gx < p.W;
-                const float nz = p.noise ? nzrow[px] : 0.f;
-                float v[16];
-                if (p.in_shift) {
-                    // zero padding follows the norm: at border pixels the taps that fall outside do not carry the shift.
-                    // BRD = [4][64] per-channel sums of T over the left / right tap column and the top / bottom tap row.
-                    const float* __restrict__ BRD = (const float*)(lds + C::T_OFF + 64 * 12 * 4 + 3 * 64 * 4);
-                    const float* __restrict__ T = (const float*)(lds + C::T_OFF);
-                    const bool top = gy == 0, bot = gy == p.H - 1;                   // wave-uniform (one row per wave)
-                    const float cl = gx == 0 ? 1.f : 0.f, cr = gx == p.W - 1 ? 1.f : 0.f;
-                    if (__builtin_amdgcn_ballot_w64((cl + cr) != 0.f)) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const int ch0 = mh * 32 + 8 * j + 4 * kh;
-                            const float4 l4 = *(const float4*)(BRD + ch0), r4 = *(const float4*)(BRD + 64 + ch0);
-                            acc[4 * j] -= cl * l4.x + cr * r4.x; acc[4 * j + 1] -= cl * l4.y + cr * r4.y;
-                            acc[4 * j + 2] -= cl * l4.z + cr * r4.z; acc[4 * j + 3] -= cl * l4.w + cr * r4.w;
-                        }
-                    }
-                    if (top | bot) {
-                        const int side = top ? 2 : 3;
-                        const int c0 = top ? 0 : 6;                                  // corner taps of that row: c0 (left), c0 + 2 (right)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int ch = mh * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                            float corr = BRD[side * 64 + ch] - cl * T[ch * 12 + c0] - cr * T[ch * 12 + c0 + 2];
-                            if (top & bot) corr += BRD[3 * 64 + ch] - cl * T[ch * 12 + 6] - cr * T[ch * 12 + 8];   // H == 1
-                            acc[r] -= corr;
-                        }
-                    }
-                }
-                if constexpr (MODE == SMODE_DOT) {
-                    // data-gradient mode: (sum acc*dot_src, sum acc) of the raw accumulator, then the per-channel scale
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint2 dd = *(const uint2*)(drow + px * C::CPB + (mh * 32 + 8 * j + 4 * kh) * 2);
-                        const float d0 = __uint_as_float(dd.x << 16), d1 = __uint_as_float(dd.x & 0xffff0000u);
-                        const float d2 = __uint_as_float(dd.y << 16), d3 = __uint_as_float(dd.y & 0xffff0000u);
-                        const float a0 = pv ? acc[4 * j] * p.gain : 0.f, a1 = pv ? acc[4 * j + 1] * p.gain : 0.f;
-                        const float a2 = pv ? acc[4 * j + 2] * p.gain : 0.f, a3 = pv ? acc[4 * j + 3] * p.gain : 0.f;
-                        s0[4 * j] += a0 * d0; s0[4 * j + 1] += a1 * d1; s0[4 * j + 2] += a2 * d2; s0[4 * j + 3] += a3 * d3;
-                        s1[4 * j] += a0; s1[4 * j + 1] += a1; s1[4 * j + 2] += a2; s1[4 * j + 3] += a3;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int ch0 = mh * 32 + 8 * j + 4 * kh;
-                    const float4 o4 = *(const float4*)(EPC + ch0), b4 = *(const float4*)(EPC + 64 + ch0), n4 = *(const float4*)(EPC + 128 + ch0);
-                    const float oo[4] = {o4.x, o4.y, o4.z, o4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float t = fmaf(acc[4 * j + q], oo[q], fmaf(nn[q], nz, bb[q]));
-                        v[4 * j + q] = fmaxf(t, t * slope);
-                    }
-                }
-                if constexpr (MODE == SMODE_STATS) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) { const float t = pv ? v[r] : 0.f; s0[r] += t; s1[r] += t * t; }
-                }
-                // bf16 pack; v_permlane32_swap pairs: lanes < 32 end up with channels 8k..8k+7, lanes >= 32 with 8(k+1)..8(k+1)+7
-                unsigned w[8];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { w[2 * j] = pack2bf(v[4 * j], v[4 * j + 1]); w[2 * j + 1] = pack2bf(v[4 * j + 2], v[4 * j + 3]); }
-#pragma unroll
-                for (int k = 0; k < 4; k += 2) {
-                    // groups k (channels 8k + 4kh ..) and k+1
-                    auto r0_ = __builtin_amdgcn_permlane32_swap(w[2 * k], w[2 * k + 2], false, false);
-                    auto r1_ = __builtin_amdgcn_permlane32_swap(w[2 * k + 1], w[2 * k + 3], false, false);
-                    const uint4 o16 = make_uint4(r0_[0], r1_[0], r0_[1], r1_[1]);
-                    const int chb = mh * 32 + 8 * (k + kh);                 // first of this lane's 8 contiguous channels
-                    if (pv && chb < COUT && !(p.dbg & 4))
-                        *(uint4*)(Yb + ((size_t)gy * p.W + gx) * COUT + chb) = o16;
-                }
-            }
-        }
+        });
     }
+    // no DMA may land after the wave has given its LDS back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- statistics: reduce over the 32 pixel lanes, combine the row waves in LDS, one atomic per channel per workgroup
-    if constexpr (MODE != SMODE_PLAIN) {
+    // ---- statistics: reduce over the 32 pixel lanes, one atomic per channel per wave
+    if constexpr (C::STATS || C::DOT) {
         if (p.stats) {
+            // lanes right of the image (ragged strips) accumulated values of pixels that do not exist: a lane is one pixel
+            // column, so the whole column is dropped here instead of masking every step
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
-                for (int m = 1; m < 32; m <<= 1) { s0[r] += __shfl_xor(s0[r], m, 64); s1[r] += __shfl_xor(s1[r], m, 64); }
-            }
-            float* __restrict__ red = (float*)(lds + C::R_OFF);              // [wave][64 ch][2]
-            if (n31 == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int ch = mh * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
-                    red[(wave * 64 + ch) * 2] = s0[r]; red[(wave * 64 + ch) * 2 + 1] = s1[r];
-                }
-            }
-            __syncthreads();
+                for (int r = 0; r < 16; r++) { if (!pv) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; } }
             float* __restrict__ ST = p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2;
-            for (int i = tid; i < COUT * 2; i += 256) {
-                const int ch = i >> 1, k = i & 1;
-                const int m = ch >> 5;                                       // waves holding this channel: mh == m
-                float a = 0.f;
-                for (int wv = 0; wv < 4; wv++) if (wv / RS == m) a += red[(wv * 64 + ch) * 2 + k];
-                atomicAdd(ST + i, a);
-            }
+#pragma unroll
+            for (int mt = 0; mt < C::MTW; mt++)
+#pragma unroll
+                for (int r = 0; r < NREG; r++) {
+                    float a = s0[mt][r], c = s1[mt][r];
+#pragma unroll
+                    for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m, 64); c += __shfl_xor(c, m, 64); }
+                    if (n31 == 0) {
+                        const int ch = wave * C::MTW * 32 + chan_of_reg(mt, r);
+                        atomicAdd(ST + ch * 2, a);
+                        atomicAdd(ST + ch * 2 + 1, c);
+                    }
+                }
         }
     }
 }
 
-template <int CIN, int COUT, int TW, int RS, int WSPLIT, int MODE>
+template <int CIN, int COUT, int FL>
 int launch_stream(const ConvParams& p0, hipStream_t s) {
-    using C = SCfg<CIN, COUT, TW, RS, WSPLIT, MODE>;
+    using C = SC<CIN, COUT, FL>;
     ConvParams p = p0;
-    { const char* e = getenv("DGE_STREAM_DBG"); p.dbg = e ? atoi(e) : 0; }
-    const int nstrips = (p.W + TW - 1) / TW;
-    // segments: enough workgroups to fill the chip about twice at the LDS-limited residency, segments >= 8 steps long
-    int nseg = (2 * 2 * 256 + p.B * nstrips - 1) / (p.B * nstrips);
+    auto kern = conv_stream_kernel<CIN, COUT, FL>;
+    static int cap = 0;                                          // resident workgroups of this instantiation on the device
+    if (!cap) {
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        int occ = 0, dev = 0, ncu = 256;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * C::TEAM, C::LDS_BYTES) != hipSuccess || occ < 1) occ = 4;
+        cap = occ * ncu;
+    }
+    const int nstrips = (p.W + 31) / 32;
+    // segments: all workgroups resident at once when the strips alone do not fill the device; at least 16 rows each
+    int nseg = cap / (p.B * nstrips);
     { const char* e = getenv("DGE_STREAM_NSEG"); if (e) nseg = atoi(e); }
-    int maxseg = p.H / (8 * RS); if (maxseg < 1) maxseg = 1;
+    int maxseg = p.H / 16; if (maxseg < 1) maxseg = 1;
     if (nseg > maxseg) nseg = maxseg;
     if (nseg < 1) nseg = 1;
-    int seg_rows = ((p.H + nseg - 1) / nseg + RS - 1) / RS * RS;
+    int seg_rows = (p.H + nseg - 1) / nseg;
     nseg = (p.H + seg_rows - 1) / seg_rows;
-    const long grid = (long)p.B * nstrips * nseg;
-    auto kern = conv_stream_kernel<CIN, COUT, TW, RS, WSPLIT, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
-    }
-    dge_note_kernel("conv_stream<bf16,%d,%d,%d,%d,%s>", CIN, COUT, TW, RS, MODE == SMODE_PLAIN ? "plain" : (MODE == SMODE_STATS ? "stats" : "dot"));
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), C::LDS_BYTES, s, p, nseg, seg_rows);
+    const int njobs = p.B * nstrips * nseg;
+    const int jobs_per_xcd = (njobs + 7) / 8;
+    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : "dot"));
+    dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM), C::LDS_BYTES, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
     return 0;
 }
 
-template <int CIN, int COUT, int TW, int RS, int WSPLIT>
-int launch_mode(const ConvParams& p, hipStream_t s) {
-    if (p.dot_src) return launch_stream<CIN, COUT, TW, RS, WSPLIT, SMODE_DOT>(p, s);
-    if (p.stats) return launch_stream<CIN, COUT, TW, RS, WSPLIT, SMODE_STATS>(p, s);
-    return launch_stream<CIN, COUT, TW, RS, WSPLIT, SMODE_PLAIN>(p, s);
+template <int CIN, int COUT>
+int launch_flavour(const ConvParams& p, hipStream_t s) {
+    if (p.dot_src) {
+        if constexpr (COUT == 64 && CIN != 64) { dge_set_error("conv_stream: data-gradient mode %d -> %d is not built", CIN, COUT); return -1; }
+        else return launch_stream<CIN, COUT, FL_DOT>(p, s);
+    }
+    if (p.stats) return launch_stream<CIN, COUT, FL_ENC_STATS>(p, s);
+    if (p.in_shift || (p.noise && p.noise_w_stride != 0)) return launch_stream<CIN, COUT, FL_ENC>(p, s);
+    return launch_stream<CIN, COUT, FL_GEN>(p, s);
 }
 
 }  // namespace
-
-// compile-time loop helper shared with conv_igemm.hip (kept local: separate translation units)
-// (StaticFor is defined in common.h)
 
 // Eligibility of the streaming kernel for a launch (bf16, 3x3, stride 1, no fused resampling / addend / ReLU prologue).
 bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
@@ -459,17 +565,18 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64) || !(p.Cout == 16 || p.Cout == 32 || p.Cout == 64)) return false;
     if (p.W % 4 != 0 || p.W < 64 || p.H < 32) return false;
     if ((long)p.H * p.W < 128L * 128) return false;
+    if ((long)p.W * p.Cin * 2 >= (1L << 31) || (long)p.H * p.W * 64 * 2 >= (1L << 40)) return false;
     if (p.dot_src && !p.stats) return false;
+    if (p.dot_src && p.Cout == 64 && p.Cin != 64) return false;
+    if (p.dot_src && (p.bias || p.noise || p.in_shift || p.act != DGE_ACT_NONE)) return false;
     if (p.noise && p.noise_w == nullptr) return false;
     if (getenv("DGE_NO_STREAM")) return false;
     return true;
 }
 
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s) {
-#define GO(CI, CO, TW, RS, WS) if (p.Cin == CI && p.Cout == CO) return launch_mode<CI, CO, TW, RS, WS>(p, s)
-    GO(16, 16, 64, 4, 1); GO(16, 32, 64, 4, 1); GO(32, 16, 64, 4, 1); GO(32, 32, 64, 4, 1);
-    GO(64, 16, 32, 4, 1); GO(64, 32, 32, 4, 1);
-    GO(16, 64, 64, 2, 2); GO(32, 64, 64, 2, 2); GO(64, 64, 64, 2, 2);
+#define GO(CI, CO) if (p.Cin == CI && p.Cout == CO) return launch_flavour<CI, CO>(p, s)
+    GO(16, 16); GO(16, 32); GO(16, 64); GO(32, 16); GO(32, 32); GO(32, 64); GO(64, 16); GO(64, 32); GO(64, 64);   // DGE_ONLY
 #undef GO
     dge_set_error("conv_stream: unsupported channel configuration %d -> %d", p.Cin, p.Cout);
     return -1;

@@ -43,23 +43,23 @@ def modconv(x, w, s, d, noise, noise_strength, bias, bscale, wscale, gain=2.0 **
 
 
 def modconv_folded(x, w, s, d, noise, noise_strength, bias, bscale, wscale, gain=2.0 ** 0.5, slope=0.2, q=_ident):
-    """The same layer in the reference's FUSED-modulation form (:858-864: the style multiplies the weight, one weight per sample):
-    W'[b] = q(w*wscale * s[b,i]); `q` = the storage rounding of the per-sample weight (what csrc/conv_stream.hip holds in
-    registers).  Mathematically identical to `modconv`; the two differ only in where a storage rounding falls."""
+    """The same layer in the reference's FUSED-modulation form (:858-864: the style multiplies the weight, the demodulation
+    divides it, one weight per sample): W'[b][o][i] = q(w*wscale * (s[b,i] * (gain * d[b,o]))); `q` = the storage rounding of the
+    per-sample weight (what csrc/conv_stream.hip holds in registers; the f32 products are associated as the kernel's).  The
+    activation gain is folded as well - lrelu(g*t) = g*lrelu(t) for g > 0 - so noise and bias carry it.  Mathematically identical
+    to `modconv`; the two differ only in where a storage rounding falls."""
     ys = []
     for b in range(x.shape[0]):
-        wb = w * wscale
-        if s is not None:
-            wb = q(wb * s[b][None, :, None, None])
+        sb = torch.ones(w.shape[1]) if s is None else s[b]
+        db = torch.full((w.shape[0],), float(gain)) if d is None else gain * d[b]
+        wb = q((w * wscale) * (sb[None, :] * db[:, None])[:, :, None, None])
         ys.append(F.conv2d(x[b:b + 1], wb, padding=w.shape[-1] // 2))
     y = torch.cat(ys)
-    if d is not None:
-        y = y * d[:, :, None, None]
     if noise is not None:
-        y = y + noise[:, None] * noise_strength
+        y = y + noise[:, None] * (noise_strength * gain)
     if bias is not None:
-        y = y + bias[None, :, None, None] * bscale
-    return torch.where(y > 0, y, slope * y) * gain
+        y = y + (bias * bscale * gain)[None, :, None, None]
+    return torch.where(y > 0, y, slope * y)
 
 
 def upconv_fir(x, w, s, d, noise, noise_strength, bias, bscale, wscale, gain=2.0 ** 0.5, slope=0.2, q=_ident):

@@ -68,15 +68,15 @@ SAMPLES = lambda B: sorted({0, B - 1})
 
 # (Cin, Cout, R, B) of the generator's stride-1 layers and the instantiation launch_t must select for them
 G_LAYERS = [
-    (32, 32, 1024, 8, "conv_stream<bf16,32,32,64,4,plain>"),       # layer16: the streaming kernel of the HBM-bound layers
-    (64, 64, 512, 8, "conv_stream<bf16,64,64,64,2,plain>"),        # layer14
+    (32, 32, 1024, 8, "conv_stream<bf16,32,32,gen>"),       # layer16: the streaming kernel of the HBM-bound layers
+    (64, 64, 512, 8, "conv_stream<bf16,64,64,gen>"),        # layer14
     (128, 128, 256, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),     # layer12: the 128-wide N tile
     (256, 256, 128, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),     # layer10
     (512, 512, 64, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),      # layer8
     (512, 512, 32, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>"),       # layer6
     (512, 512, 16, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),        # layer4: small-tile configuration, 256-byte K chunks
     (512, 512, 4, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),         # layer0
-    (32, 32, 1024, 1, "conv_stream<bf16,32,32,64,4,plain>"),       # batch 1
+    (32, 32, 1024, 1, "conv_stream<bf16,32,32,gen>"),       # batch 1
 ]
 
 
@@ -156,11 +156,11 @@ def test_generator_up_layer_fullsize(cin, cout, Rin, B, kernel):
 
 ENC_CONVS = [
     # (cin, cout, R, B, stats, kernel)
-    (16, 16, 1024, 8, True, "conv_stream<bf16,16,16,64,4,stats>"),     # block 0 conv_1: 64 statistics slots
-    (16, 32, 1024, 8, False, "conv_stream<bf16,16,32,64,4,plain>"),    # block 0 conv_2
-    (32, 32, 512, 8, True, "conv_stream<bf16,32,32,64,4,stats>"),      # block 1 conv_1
-    (32, 64, 512, 8, False, "conv_stream<bf16,32,64,64,2,plain>"),     # block 1 conv_2
-    (64, 64, 256, 8, True, "conv_stream<bf16,64,64,64,2,stats>"),      # block 2 conv_1
+    (16, 16, 1024, 8, True, "conv_stream<bf16,16,16,enc_stats>"),     # block 0 conv_1: 64 statistics slots
+    (16, 32, 1024, 8, False, "conv_stream<bf16,16,32,enc>"),    # block 0 conv_2
+    (32, 32, 512, 8, True, "conv_stream<bf16,32,32,enc_stats>"),      # block 1 conv_1
+    (32, 64, 512, 8, False, "conv_stream<bf16,32,64,enc>"),     # block 1 conv_2
+    (64, 64, 256, 8, True, "conv_stream<bf16,64,64,enc_stats>"),      # block 2 conv_1
     (64, 128, 256, 8, False, "conv_igemm<bf16,16,16,128,32,3,2,2>"),   # block 2 conv_2: back on the implicit-GEMM kernel
     (512, 512, 8, 8, True, "conv_igemm<bf16,8,8,64,128,3,2,2>"),       # block 7 conv_1
 ]
@@ -236,11 +236,11 @@ def test_encoder_skip_conv_fullsize(cin, cout, R, B, kernel):
 
 DGRADS = [
     # (cout_fwd, cin_fwd, R, B, k, out_scale, kernel): data gradient of a forward conv cin_fwd -> cout_fwd
-    (16, 16, 1024, 8, 3, False, "conv_stream<bf16,16,16,64,4,dot>"),       # encoder block 0 conv_1
-    (32, 16, 1024, 8, 3, False, "conv_stream<bf16,32,16,64,4,dot>"),       # encoder block 0 conv_2 (K = 32 gradient channels)
-    (32, 32, 1024, 8, 3, True, "conv_stream<bf16,32,32,64,4,dot>"),        # generator layer16 (scaled by the style afterwards)
-    (64, 64, 512, 8, 3, True, "conv_stream<bf16,64,64,64,2,dot>"),         # generator layer14
-    (64, 32, 512, 8, 3, False, "conv_stream<bf16,64,32,32,4,dot>"),        # encoder block 1 conv_2
+    (16, 16, 1024, 8, 3, False, "conv_stream<bf16,16,16,dot>"),       # encoder block 0 conv_1
+    (32, 16, 1024, 8, 3, False, "conv_stream<bf16,32,16,dot>"),       # encoder block 0 conv_2 (K = 32 gradient channels)
+    (32, 32, 1024, 8, 3, True, "conv_stream<bf16,32,32,dot>"),        # generator layer16 (scaled by the style afterwards)
+    (64, 64, 512, 8, 3, True, "conv_stream<bf16,64,64,dot>"),         # generator layer14
+    (64, 32, 512, 8, 3, False, "conv_stream<bf16,64,32,dot>"),        # encoder block 1 conv_2
     (128, 128, 256, 8, 3, True, "conv_igemm<bf16,16,16,128,32,3,2,2>"),    # generator layer12
     (64, 32, 256, 8, 1, False, "conv_igemm<bf16,16,16,32,32,1,4,1>"),      # encoder block 1 conv_3 (1x1)
 ]
@@ -366,7 +366,7 @@ def test_lpips_first_conv_fullsize():
     w = w.to(torch.bfloat16).float()
     bias = 0.05 * torch.randn(64, device=DEV, generator=g)
     y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, 1.0), 64, 3, bias=bias, act=ops.ACT_RELU)
-    assert _kernel() == "conv_stream<bf16,16,64,64,2,plain>"
+    assert _kernel() == "conv_stream<bf16,16,64,gen>"
     for b in SAMPLES(B):
         ref = CR.modconv(_nchw(x, b), w.cpu(), None, None, None, 0.0, bias.cpu(), 1.0, 1.0, gain=1.0, slope=0.0)
         assert _one_rounding(_nchw(y, b), ref) <= 0, b
