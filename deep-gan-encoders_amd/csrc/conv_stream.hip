@@ -33,6 +33,11 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+#ifdef DGE_SC_NTLOAD
+#define DGE_LDS " nt lds\n\t"
+#else
+#define DGE_LDS " lds\n\t"
+#endif
 
 __device__ __forceinline__ unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned lds_off(const void* p) {
@@ -50,65 +55,48 @@ __device__ __forceinline__ rsrc_t make_rsrc(unsigned long long base, unsigned by
 // ---- LDS-DMA statements.  M0 (LDS base of the row) is written in the statement that uses it; the immediate offset moves the
 //      global and the LDS address together.  The partial last piece of a row runs under an EXEC mask (saved / restored in
 //      the statement; the code around it is wave-uniform).
-// one halo row of 34 pixels: 1088 B (Cin 16), 2176 B (Cin 32), 4352 B (Cin 64)
-template <int CIN> __device__ __forceinline__ void dma_row(unsigned voff, unsigned voff_b, unsigned voff_c, rsrc_t rs, unsigned m0v) {
+// One halo row of 34 pixels: 1088 B (Cin 16), 2176 B (Cin 32), 4352 B (Cin 64) = 2 / 3 / 5 pieces of 1 KB, the last one
+// partial.  TEAM = 2: the pieces alternate between the two waves (wave 1 pads with a zero-length piece where the counts
+// differ, so that both waves count the same number of loads per row).
+// Cin = 64: 8 pixels per piece while the chunk swizzle has a period of 16 pixels -> odd pieces use the second offset
+// register; piece 4 lies beyond the 12-bit offset field -> second M0 value, third offset register.
+#define DGE_P(off) "buffer_load_dwordx4 %1, %3, 0 offen offset:" #off " lds\n\t"
+#define DGE_PB(off) "buffer_load_dwordx4 %4, %3, 0 offen offset:" #off " lds\n\t"
+#define DGE_M0 "s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+#define DGE_MASK(m) "s_mov_b64 %0, exec\n\ts_mov_b64 exec, " #m "\n\t"
+#define DGE_UNMASK "s_mov_b64 exec, %0"
+template <int CIN, int TEAM>
+__device__ __forceinline__ void dma_row(int wave, unsigned voff, unsigned voff_b, unsigned voff_c, rsrc_t rs, rsrc_t rs_null,
+                                        unsigned m0v, unsigned m0_dummy) {
     unsigned long long keep;
-    if constexpr (CIN == 16) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xf\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen offset:1024 lds\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
-    } else if constexpr (CIN == 32) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen offset:1024 lds\n\t"
-                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xff\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen offset:2048 lds\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
-    } else {
-        // 8 pixels per piece, the chunk swizzle has a period of 16 pixels: odd pieces use the second offset register;
-        // piece 4 lies beyond the 12-bit offset field: second M0 value, third offset register
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-                     "buffer_load_dwordx4 %4, %3, 0 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen offset:2048 lds\n\t"
-                     "buffer_load_dwordx4 %4, %3, 0 offen offset:3072 lds\n\t"
-                     "s_mov_b32 m0, %6\n\t"
-                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\t"
-                     "buffer_load_dwordx4 %5, %3, 0 offen lds\n\t"
-                     "s_mov_b64 exec, %0"
+    if constexpr (CIN == 16 && TEAM == 1) {
+        asm volatile(DGE_M0 DGE_P(0) DGE_MASK(0xf) DGE_P(1024) DGE_UNMASK : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+    } else if constexpr (CIN == 16 && TEAM == 2) {
+        if (wave == 0) asm volatile(DGE_M0 DGE_P(0) : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+        else asm volatile(DGE_M0 DGE_MASK(0xf) DGE_P(1024) DGE_UNMASK : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+    } else if constexpr (CIN == 32 && TEAM == 1) {
+        asm volatile(DGE_M0 DGE_P(0) DGE_P(1024) DGE_MASK(0xff) DGE_P(2048) DGE_UNMASK : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+    } else if constexpr (CIN == 32 && TEAM == 2) {
+        if (wave == 0) asm volatile(DGE_M0 DGE_P(0) DGE_MASK(0xff) DGE_P(2048) DGE_UNMASK : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+        else asm volatile(DGE_M0 DGE_P(1024) "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, 0 offen lds"
+                          : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs), "s"(rs_null), "s"(m0_dummy) : "memory");
+    } else if constexpr (CIN == 64 && TEAM == 1) {
+        asm volatile(DGE_M0 DGE_P(0) DGE_PB(1024) DGE_P(2048) DGE_PB(3072)
+                     "s_mov_b32 m0, %6\n\t" DGE_MASK(0xffff) "buffer_load_dwordx4 %5, %3, 0 offen lds\n\t" DGE_UNMASK
                      : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs), "v"(voff_b), "v"(voff_c), "s"(m0v + 4096u) : "memory");
-    }
-}
-// the same row split over a 2-wave team (Cin = 64): wave 0 pieces 0, 2, 4; wave 1 pieces 1, 3 and one zero-length piece
-// (both waves count three loads per row)
-__device__ __forceinline__ void dma_row64_team(int wave, unsigned voff, unsigned voff_b, unsigned voff_c, rsrc_t rs, rsrc_t rs_null,
-                                               unsigned m0v, unsigned m0_dummy) {
-    unsigned long long keep;
-    if (wave == 0) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
-                     "buffer_load_dwordx4 %1, %3, 0 offen offset:2048 lds\n\t"
-                     "s_mov_b32 m0, %5\n\t"
-                     "s_mov_b64 %0, exec\n\ts_mov_b64 exec, 0xffff\n\t"
-                     "buffer_load_dwordx4 %4, %3, 0 offen lds\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs), "v"(voff_c), "s"(m0v + 4096u) : "memory");
     } else {
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %0, %2, 0 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %0, %2, 0 offen offset:3072 lds\n\t"
-                     "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %0, %3, 0 offen lds"
-                     : : "v"(voff_b), "s"(m0v), "s"(rs), "s"(rs_null), "s"(m0_dummy) : "memory");
+        if (wave == 0)
+            asm volatile(DGE_M0 DGE_P(0) DGE_P(2048)
+                         "s_mov_b32 m0, %5\n\t" DGE_MASK(0xffff) "buffer_load_dwordx4 %4, %3, 0 offen lds\n\t" DGE_UNMASK
+                         : "=&s"(keep) : "v"(voff), "s"(m0v), "s"(rs), "v"(voff_c), "s"(m0v + 4096u) : "memory");
+        else
+            asm volatile(DGE_M0 DGE_P(1024) DGE_P(3072) "s_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %4, 0 offen lds"
+                         : "=&s"(keep) : "v"(voff_b), "s"(m0v), "s"(rs), "s"(rs_null), "s"(m0_dummy) : "memory");
     }
 }
-// 4 bytes per lane (noise row: 32 pixels, lanes >= 32 are out of range)
-__device__ __forceinline__ void dma_dword(unsigned voff, rsrc_t rs, unsigned m0v) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %0, %2, 0 offen lds" : : "v"(voff), "s"(m0v), "s"(rs) : "memory");
+// one full piece (8 noise rows of 32 pixels: lane = (row, 4 pixels))
+__device__ __forceinline__ void dma_piece(unsigned voff, rsrc_t rs, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" : : "v"(voff), "s"(m0v), "s"(rs) : "memory");
 }
 // dot_src row of this wave: NP pieces of 1 KB (32 pixels x 16 / 32 / 32 channels)
 template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigned voff1, rsrc_t rs, unsigned m0v) {
@@ -128,16 +116,28 @@ enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3 };
 template <int CIN, int COUT, int FL>
 struct SC {
     static constexpr int PXB = CIN * 2, CH = PXB / 16, LOGCH = ilog2(CH), KS = CIN / 16;
-    static constexpr int TEAM = (CIN == 64 && COUT == 64) ? 2 : 1;            // waves sharing one strip
+    static constexpr int TEAM = COUT == 64 ? 2 : 1;                            // waves sharing one strip: 32 output channels each
+#ifndef DGE_SC_WAVES
+#define DGE_SC_WAVES 4
+#endif
+    static constexpr int TPW = DGE_SC_WAVES / TEAM;                            // independent teams per workgroup (one wave per SIMD)
     static constexpr int MT = COUT / 32 > 0 ? COUT / 32 : 1;                   // M tiles of the strip (Cout 16: one half-empty tile)
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
     static constexpr bool DOT = FL == FL_DOT, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS;
     static constexpr bool NOISE = !DOT;
-    static constexpr int NR = 6;                                               // ring rows = unroll period
-    static constexpr int D = DOT ? 2 : 3;                                      // rows in flight ahead of the newest live row (<= NR - 3)
-    static constexpr int DR = DOT ? D + 1 : NR;                                         // dot ring rows (must divide NR); the noise ring has NR rows
+#ifndef DGE_SC_NR
+#define DGE_SC_NR 6
+#define DGE_SC_D 2
+#endif
+#ifndef DGE_SC_NR_DOT
+#define DGE_SC_NR_DOT 6
+#endif
+    static constexpr int NR = DOT ? DGE_SC_NR_DOT : DGE_SC_NR;                 // ring rows = unroll period
+    static constexpr int dot_depth(int nr) { for (int d = 4; d >= 1; d--) if (d <= nr - 3 && nr % (d + 1) == 0) return d; return 1; }
+    static constexpr int D = DOT ? dot_depth(DGE_SC_NR_DOT) : DGE_SC_D;            // rows in flight ahead of the newest live row (<= NR - 3)
+    static constexpr int DR = DOT ? D + 1 : NR;                                // dot ring rows (must divide NR)
     static_assert(NR % DR == 0, "dot ring period");
     static constexpr int CPB = COUT * 2;
     static constexpr int CW = COUT / TEAM >= 32 ? 32 : 16;                      // channels of one wave's M tile set that are real (per tile)
@@ -145,12 +145,13 @@ struct SC {
     static constexpr int LOGDCH = ilog2(DCH);
     static constexpr int DROWB = 32 * DCH * 16, DPIECES = DROWB / 1024;
     static_assert(!DOT || MTW == 1, "data-gradient mode: one M tile per wave");
-    static constexpr int XPW = TEAM == 2 ? 3 : PIECES;                          // x loads per wave per row
-    static constexpr int LPR = XPW + (NOISE ? 1 : 0) + (DOT ? DPIECES : 0);    // loads per wave per step
+    static constexpr int XPW = TEAM == 2 ? (PIECES + 1) / 2 : PIECES;           // x loads per wave per row
+    static constexpr int LPR = XPW + (DOT ? DPIECES : 0);                       // loads per wave per step (+ 1 noise piece when I == 0)
     static constexpr int X_OFF = 0;
     static constexpr int XRING = NR * RB;
-    static constexpr int N_OFF = (XRING + 1023) / 1024 * 1024;                  // per wave: noise ring NR x 256 B
-    static constexpr int NRING = NOISE ? NR * 256 : 0;
+    static constexpr int N_OFF = (XRING + 1023) / 1024 * 1024;                  // per wave: two noise buffers of 8 rows x 32 pixels f32
+    static constexpr int NRING = NOISE ? 2048 : 0;
+    static_assert(NR <= 8, "a noise piece holds 8 rows");
     static constexpr int D_OFF = N_OFF + TEAM * NRING;                           // per wave: dot ring DR x DROWB
     static constexpr int DRING = DOT ? DR * DROWB : 0;
     static constexpr int T_OFF = D_OFF + TEAM * DRING;                           // per wave: T table [32*MTW][12] f32 + epilogue constants [3][32*MTW]
@@ -160,7 +161,7 @@ struct SC {
     static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + 36;
     static constexpr int WPE = NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2);
     static_assert(D <= NR - 3, "the slot of the row being fetched must be dead");
-    static_assert((D - 1) * LPR < 64, "vmcnt range");
+    static_assert((D - 1) * LPR + 1 < 64, "vmcnt range");
 };
 
 // swizzle of the 16-byte chunks of a pixel in an LDS image with 2^LOGC chunks per pixel (conflict-free ds_read_b128 of 16
@@ -177,18 +178,21 @@ template <int CW> __device__ __forceinline__ int chan_of_row(int m) {
 }
 
 template <int CIN, int COUT, int FL>
-__global__ __launch_bounds__((64 * SC<CIN, COUT, FL>::TEAM), (SC<CIN, COUT, FL>::WPE))
+__global__ __launch_bounds__((64 * SC<CIN, COUT, FL>::TEAM * SC<CIN, COUT, FL>::TPW), (SC<CIN, COUT, FL>::WPE))
 void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int njobs, int jobs_per_xcd) {
     using C = SC<CIN, COUT, FL>;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const unsigned lds0 = lds_off(lds);
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds_all[];
     const int lane = threadIdx.x & 63;
-    const int wave = C::TEAM == 2 ? (int)rfl(threadIdx.x >> 6) : 0;
+    const int wid = (int)rfl(threadIdx.x >> 6);
+    const int team = wid / C::TEAM;                                              // teams of a workgroup never synchronise with each other
+    const int wave = wid % C::TEAM;
+    unsigned char* __restrict__ lds = lds_all + team * C::LDS_BYTES;
+    const unsigned lds0 = lds_off(lds_all) + team * C::LDS_BYTES;
     const int n31 = lane & 31, kh = lane >> 5;
 
     // ---- job: blocks of one XCD (blockIdx % 8) take a contiguous range of (sample, segment, strip): neighbouring strips
     //      share their halo columns through that XCD's L2
-    int job = (blockIdx.x & 7) * jobs_per_xcd + (blockIdx.x >> 3);
+    int job = ((blockIdx.x & 7) * jobs_per_xcd + (blockIdx.x >> 3)) * C::TPW + team;
     if ((blockIdx.x >> 3) >= jobs_per_xcd || job >= njobs) return;
     const int strip = job % nstrips; job /= nstrips;
     const int seg = job % nseg;
@@ -217,7 +221,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             voff_c = voff + 4096;                                                     // piece 4 (even), beyond the 12-bit offset field
         }
     }
-    const unsigned nvoff = lane < 32 ? (unsigned)((x0 + lane) * 4) : 0xfffffff0u;
+    const unsigned nvoff = (unsigned)(((lane >> 3) * p.W + x0 + (lane & 7) * 4) * 4);   // noise piece: 8 rows x 32 pixels (pixels right of the image read the next row: never stored)
     unsigned dvoff = 0, dvoff1 = 0;
     if constexpr (C::DOT) {
         const int px = lane >> C::LOGDCH, cs = lane & (C::DCH - 1);
@@ -232,31 +236,34 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     // row pointers of the NEXT row to fetch (advance one image row per issue; rows outside the image are never dereferenced:
     // their descriptor has length zero)
     unsigned long long xptr = Xb + (unsigned long long)(long long)(r0 - 1) * xrow_bytes;
-    unsigned long long nptr = NZb + (unsigned long long)(long long)(r0 - 2) * nzrow_bytes;
     unsigned long long dptr = DOTb + (unsigned long long)(long long)(r0 - 2) * yrow_bytes;
-    auto issue = [&](int h, int slot, int slot_n, int slot_d) {
+    auto issue = [&](int h, int slot, int slot_d) {
         const int gy = r0 - 1 + h;
         const bool xv = (unsigned)gy < (unsigned)p.H && h <= rows + 1;
         const rsrc_t rx = make_rsrc(xptr, xv ? xrow_bytes : 0u);
+#ifndef DGE_SC_SAMEROW
         xptr += xrow_bytes;
+#endif
         const unsigned m0x = lds0 + C::X_OFF + slot * C::RB;
-        if constexpr (C::TEAM == 2) dma_row64_team(wave, voff, voff_b, voff_c, rx, rs_null, m0x, lds0 + C::DUMMY_OFF);
-        else dma_row<CIN>(voff, voff_b, voff_c, rx, m0x);
+        dma_row<CIN, C::TEAM>(wave, voff, voff_b, voff_c, rx, rs_null, m0x, lds0 + C::DUMMY_OFF);
         const bool ov = h >= 2 && h <= rows + 1;                                        // output row gy - 1 lies inside the segment
-        if constexpr (C::NOISE) {
-            const rsrc_t rn = make_rsrc(nptr, ov ? nzrow_bytes : 0u);
-            nptr += nzrow_bytes;
-            dma_dword(nvoff, rn, lds0 + C::N_OFF + wave * C::NRING + slot_n * 256);
-        }
         if constexpr (C::DOT) {
             const rsrc_t rd = make_rsrc(dptr, ov ? yrow_bytes : 0u);
             dptr += yrow_bytes;
             dma_dot<C::DPIECES>(dvoff, dvoff1, rd, lds0 + C::D_OFF + wave * C::DRING + slot_d * C::DROWB);
         }
     };
+    // noise rows q .. q+7 of the segment (one piece; NR of them are used) into buffer `buf_off` (0 / 1024)
+    auto issue_noise = [&](int q, unsigned buf_off) {
+        const int gy = r0 + q;
+        const bool v = p.noise != nullptr && gy < p.H && q < rows;
+        const rsrc_t rn = make_rsrc(NZb + (unsigned long long)(v ? gy : 0) * nzrow_bytes, v ? (unsigned)(p.H - gy) * nzrow_bytes : 0u);
+        dma_piece(nvoff, rn, lds0 + C::N_OFF + wave * C::NRING + buf_off);
+    };
     // rows 0 .. D+1 start before the weights are touched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    StaticFor<C::D + 2>::run([&](auto hc) { constexpr int h = decltype(hc)::value; issue(h, h % C::NR, (h + C::NR - 2) % C::NR, (h + C::NR - 2) % C::NR % C::DR); });
+    if constexpr (C::NOISE) issue_noise(0, 0u);
+    StaticFor<C::D + 2>::run([&](auto hc) { constexpr int h = decltype(hc)::value; issue(h, h % C::NR, (h + C::NR - 2) % C::NR % C::DR); });
     // (noise / dot rows -2 and -1 are zero-length; their slot index only has to be in range)
 
     // ---- weights -> registers, every scale folded in:  W'[o][k] = bf16(W[o][k] * in_scale[b][k] * out_scale[b][o] * gain)
@@ -376,35 +383,79 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     }
 
     // ---- one output row.  I = position in the ring period (compile time): halo rows in slots I, I+1, I+2 (mod NR)
-    auto step = [&](auto ic, int s) {
+#ifdef DGE_SC_TIMING
+    long long* tlog = (long long*)(lds + C::T_OFF);      // [16 steps][5] of job 0 (the table is dead once the constants are in registers)
+    const bool tjob = blockIdx.x == 64 && wid == 0;
+#define DGE_T(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); \
+                      if (tjob && s >= 40 && s < 56 && lane == 0) tlog[(s - 40) * 5 + k] = t_; } while (0)
+#else
+#define DGE_T(k)
+#endif
+    auto step = [&](auto ic, int s, unsigned npar) {
         constexpr int I = decltype(ic)::value;
+        DGE_T(0);
         // row s+2 (and the noise / dot row s) has landed when at most (D-1) rows' loads are still in flight
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"((C::D - 1) * C::LPR) : "memory");
+#ifndef DGE_SC_NOWAIT
+        // loads issued after row s+2's: the rows of the D-1 steps before this one, plus the noise piece if one of them was
+        // a period start (ring position 0)
+        constexpr int NAFTER = (C::D - 1) * C::LPR + ((C::NOISE && I >= 1 && I <= C::D - 1) ? 1 : 0);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NAFTER) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#endif
         if constexpr (C::TEAM == 2) __builtin_amdgcn_s_barrier();     // the partner's pieces landed; it finished step s-1
-        issue(s + 2 + C::D, (I + 2 + C::D) % C::NR, (I + C::D) % C::NR, (I + C::D) % C::DR);
+        DGE_T(1);
+        if constexpr (C::NOISE && I == 0) issue_noise(s + C::NR, npar ^ 1024u);   // the next period's rows into the other buffer
+        issue(s + 2 + C::D, (I + 2 + C::D) % C::NR, (I + C::D) % C::DR);
+#ifdef DGE_SC_NOMFMA
+        if (p.dbg != 12345) return;
+#endif
+        DGE_T(2);
 
         const int gy = r0 + s;
         constexpr int NQ = 9 * C::KS;
-        constexpr int PF = NQ < 6 ? NQ : 6;
+#ifndef DGE_SC_PF
+#define DGE_SC_PF 6
+#endif
+        constexpr int PF = NQ < DGE_SC_PF ? NQ : DGE_SC_PF;
         auto frag_addr = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int tap = q / C::KS, ks = q % C::KS, dy = tap / 3, dx = tap % 3;
             return loff[dx][ks] + (unsigned)(((I + dy) % C::NR) * C::RB);
         };
         float nz = 0.f;
-        if constexpr (C::NOISE) nz = lds_f(nzoff + (I % C::NR) * 256);
+        if constexpr (C::NOISE) nz = lds_f(nzoff + npar + I * 128);
         uint4 bq[PF];
         StaticFor<PF>::run([&](auto qc) { bq[decltype(qc)::value] = lds_u4(frag_addr(qc)); });
         f32x16_t acc[C::MTW];
+#ifdef DGE_SC_TWOCHAIN
+        f32x16_t acc2[C::MTW];
+#endif
+#ifdef DGE_SC_NOK
+        acc[0] = biasv[0];
+        if (p.dbg == 12345)
+#endif
         StaticFor<NQ>::run([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int tap = q / C::KS, ks = q % C::KS;
             const bf16x8_t bf = *(const bf16x8_t*)&bq[q % PF];
 #pragma unroll
-            for (int mt = 0; mt < C::MTW; mt++)
+            for (int mt = 0; mt < C::MTW; mt++) {
+#ifdef DGE_SC_TWOCHAIN
+                if constexpr (q & 1)
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[mt][tap][ks], bf, q == 1 ? zero16 : acc2[mt], 0, 0, 0);
+                else
+#endif
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[mt][tap][ks], bf, q == 0 ? (C::DOT ? zero16 : biasv[mt]) : acc[mt], 0, 0, 0);
+            }
             if constexpr (q + PF < NQ) bq[q % PF] = lds_u4(frag_addr(std::integral_constant<int, q + PF>{}));
         });
+#ifdef DGE_SC_TWOCHAIN
+#pragma unroll
+        for (int mt = 0; mt < C::MTW; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][r] += acc2[mt][r];
+#endif
 
         // pin the issue order: PF (+ noise) reads, then one read per MTW MFMAs, then the last PF fragments' MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, PF + (C::NOISE ? 1 : 0), 0);
@@ -413,6 +464,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         });
         __builtin_amdgcn_sched_group_barrier(0x008, PF * C::MTW, 0);
+#ifdef DGE_SC_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[0][15]));
+#endif
+        DGE_T(3);
+#ifdef DGE_SC_NOEPI
+        if (acc[0][0] != 12345.f) return;
+#endif
         // ---------------- epilogue: this lane = pixel gx, NREG channels per tile
         unsigned char* __restrict__ yrow = Yb + (size_t)gy * yrow_bytes;
 #pragma unroll
@@ -464,6 +522,27 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             uint4 o0 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             uint4 o1 = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
             unsigned char* dst = yrow + yoff + mt * 64;
+#ifdef DGE_SC_NOSTORE
+            if (o0.x != 0x12345u || o1.y != 0x54321u) continue;
+#endif
+#ifdef DGE_SC_STOREPAT          // timing experiment (wrong placement of the data): 1 = lane-linear 1 KB per instruction,
+                                // 2 = 16 pixels x 64 B per instruction, one chunk per 16-lane row
+            {
+                unsigned char* base = yrow + (size_t)x0 * C::CPB;
+                const unsigned lo = DGE_SC_STOREPAT == 1 ? lane * 16 : (lane & 15) * 64 + (lane >> 4) * 16;
+                *(uint4*)(base + lo) = o0;
+                *(uint4*)(base + lo + 1024) = o1;
+                continue;
+            }
+#endif
+#ifdef DGE_SC_NTSTORE
+            if (full_strip) {
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                const u4v a0 = {o0.x, o0.y, o0.z, o0.w}, a1 = {o1.x, o1.y, o1.z, o1.w};
+                asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(a0) : "memory");
+                if constexpr (NREG == 16) asm volatile("global_store_dwordx4 %0, %1, off offset:32 nt" :: "v"(dst), "v"(a1) : "memory");
+            } else
+#endif
             if (full_strip) {
                 *(uint4*)dst = o0;
                 if constexpr (NREG == 16) *(uint4*)(dst + 32) = o1;
@@ -472,20 +551,25 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 if constexpr (NREG == 16) *(uint4*)(dst + 32) = o1;
             }
         }
+        DGE_T(4);
     };
 
-    for (int s0_ = 0; s0_ < rows; s0_ += C::NR) {
+    unsigned npar = 0;                                                      // noise buffer of the current period (byte offset 0 / 1024)
+    for (int s0_ = 0; s0_ < rows; s0_ += C::NR, npar ^= 1024u) {
         bool done = false;
         StaticFor<C::NR>::run([&](auto ic) {
             constexpr int I = decltype(ic)::value;
             if (!done) {
-                if (s0_ + I < rows) step(ic, s0_ + I);
+                if (s0_ + I < rows) step(ic, s0_ + I, npar);
                 else done = true;
             }
         });
     }
     // no DMA may land after the wave has given its LDS back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DGE_SC_TIMING
+    if (tjob && lane < 40) ((long long*)p.y)[lane * 2] = tlog[lane * 2], ((long long*)p.y)[lane * 2 + 1] = tlog[lane * 2 + 1];
+#endif
 
     // ---- statistics: reduce over the 32 pixel lanes, one atomic per channel per wave
     if constexpr (C::STATS || C::DOT) {
@@ -521,12 +605,12 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     auto kern = conv_stream_kernel<CIN, COUT, FL>;
     static int cap = 0;                                          // resident workgroups of this instantiation on the device
     if (!cap) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES * C::TPW);
         int occ = 0, dev = 0, ncu = 256;
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * C::TEAM, C::LDS_BYTES) != hipSuccess || occ < 1) occ = 4;
-        cap = occ * ncu;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * C::TEAM * C::TPW, C::LDS_BYTES * C::TPW) != hipSuccess || occ < 1) occ = 1;
+        cap = occ * ncu * C::TPW;
     }
     const int nstrips = (p.W + 31) / 32;
     // segments: all workgroups resident at once when the strips alone do not fill the device; at least 16 rows each
@@ -538,10 +622,11 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     int seg_rows = (p.H + nseg - 1) / nseg;
     nseg = (p.H + seg_rows - 1) / seg_rows;
     const int njobs = p.B * nstrips * nseg;
-    const int jobs_per_xcd = (njobs + 7) / 8;
+    const int nwg = (njobs + C::TPW - 1) / C::TPW;
+    const int jobs_per_xcd = (nwg + 7) / 8;                        // workgroups per XCD
     const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : "dot"));
     dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM), C::LDS_BYTES, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM * C::TPW), C::LDS_BYTES * C::TPW, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
     return 0;
 }
@@ -549,11 +634,15 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
 template <int CIN, int COUT>
 int launch_flavour(const ConvParams& p, hipStream_t s) {
     if (p.dot_src) {
-        if constexpr (COUT == 64 && CIN != 64) { dge_set_error("conv_stream: data-gradient mode %d -> %d is not built", CIN, COUT); return -1; }
-        else return launch_stream<CIN, COUT, FL_DOT>(p, s);
+        return launch_stream<CIN, COUT, FL_DOT>(p, s);
     }
-    if (p.stats) return launch_stream<CIN, COUT, FL_ENC_STATS>(p, s);
-    if (p.in_shift || (p.noise && p.noise_w_stride != 0)) return launch_stream<CIN, COUT, FL_ENC>(p, s);
+    const bool enc = p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0);
+    if constexpr (CIN == 64) {       // the encoder flavours of the 64-channel input do not fit the register file next to 144 weight registers
+        if (enc) { dge_set_error("conv_stream: encoder flavour with Cin = 64 is not built"); return -1; }
+    } else {
+        if (p.stats) return launch_stream<CIN, COUT, FL_ENC_STATS>(p, s);
+        if (enc) return launch_stream<CIN, COUT, FL_ENC>(p, s);
+    }
     return launch_stream<CIN, COUT, FL_GEN>(p, s);
 }
 
@@ -567,7 +656,7 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     if ((long)p.H * p.W < 128L * 128) return false;
     if ((long)p.W * p.Cin * 2 >= (1L << 31) || (long)p.H * p.W * 64 * 2 >= (1L << 40)) return false;
     if (p.dot_src && !p.stats) return false;
-    if (p.dot_src && p.Cout == 64 && p.Cin != 64) return false;
+    if (p.Cin == 64 && !p.dot_src && (p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0))) return false;
     if (p.dot_src && (p.bias || p.noise || p.in_shift || p.act != DGE_ACT_NONE)) return false;
     if (p.noise && p.noise_w == nullptr) return false;
     if (getenv("DGE_NO_STREAM")) return false;
@@ -576,7 +665,13 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
 
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s) {
 #define GO(CI, CO) if (p.Cin == CI && p.Cout == CO) return launch_flavour<CI, CO>(p, s)
-    GO(16, 16); GO(16, 32); GO(16, 64); GO(32, 16); GO(32, 32); GO(32, 64); GO(64, 16); GO(64, 32); GO(64, 64);   // DGE_ONLY
+#ifdef DGE_SC_ONLY          // tuning builds: one channel configuration
+#define GO2(...) GO(__VA_ARGS__)
+    GO2(DGE_SC_ONLY);
+#undef GO2
+#else
+    GO(16, 16); GO(16, 32); GO(16, 64); GO(32, 16); GO(32, 32); GO(32, 64); GO(64, 16); GO(64, 32); GO(64, 64);
+#endif
 #undef GO
     dge_set_error("conv_stream: unsupported channel configuration %d -> %d", p.Cin, p.Cout);
     return -1;

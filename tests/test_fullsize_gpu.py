@@ -160,7 +160,7 @@ ENC_CONVS = [
     (16, 32, 1024, 8, False, "conv_stream<bf16,16,32,enc>"),    # block 0 conv_2
     (32, 32, 512, 8, True, "conv_stream<bf16,32,32,enc_stats>"),      # block 1 conv_1
     (32, 64, 512, 8, False, "conv_stream<bf16,32,64,enc>"),     # block 1 conv_2
-    (64, 64, 256, 8, True, "conv_stream<bf16,64,64,enc_stats>"),      # block 2 conv_1
+    (64, 64, 256, 8, True, "conv_igemm<bf16,16,16,64,32,3,4,1>"),      # block 2 conv_1 (encoder flavours stop at Cin = 32: registers)
     (64, 128, 256, 8, False, "conv_igemm<bf16,16,16,128,32,3,2,2>"),   # block 2 conv_2: back on the implicit-GEMM kernel
     (512, 512, 8, 8, True, "conv_igemm<bf16,8,8,64,128,3,2,2>"),       # block 7 conv_1
 ]
