@@ -144,9 +144,16 @@ def _all_reduce(t, async_op=False):
 
 class EAlignStep:
     def __init__(self, generator, E, lpips_model, lr=0.0015, beta_1=0.0, batch_size=2, z_dim=512,
-                 reference_noise=False, exact_ddp=True, mapping=None):
+                 reference_noise=False, exact_ddp=True, mapping=None, stage=2):
         """`generator`: StyleGAN2Generator (mtype 2), the StyleGAN1 synthesis network Gs together with
-        `mapping` = Gm (mtype 1), a PGGANGenerator (mtype 3) or a BigGAN (mtype 4; z_dim is taken from its config)."""
+        `mapping` = Gm (mtype 1), a PGGANGenerator (mtype 3) or a BigGAN (mtype 4; z_dim is taken from its config).
+        `stage`: 2 = E_align_s2.py (image phase 1/5/9-weighted with gradient, then the latent phase); 1 = the stage-1 variant
+        E_align_cropping_s1.py:185-218: the image-space losses are evaluated on detached inputs and summed unweighted (they are
+        reported, not trained on: no gradient reaches E, the script's first optimizer step changes nothing) and only the
+        latent phase updates the encoder."""
+        if stage not in (1, 2):
+            raise ValueError("EAlignStep: stage must be 1 or 2")
+        self.stage = stage
         from .pggan_generator import PGGANGenerator
         from .biggan_generator import BigGAN
         self.G, self.E, self.lpips = generator, E, lpips_model
@@ -331,11 +338,16 @@ class EAlignStep:
         imgs2 = self.gen.synth(w2, gen_noises[1])
 
         gctx = losses.GlobalBatch(self.world) if (self.dist_on and self.exact_ddp) else None
-        loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, global_batch=gctx)
-        self.opt.zero_grad()
-        loss_tsa.backward(retain_graph=True)
-        gs = self._sync_grads()
-        self.opt.step(grad_scale=gs)
+        if self.stage == 1:
+            # E_align_cropping_s1.py:185-203: .detach().clone() on every loss input, loss_tsa = imgs + medium + small
+            with torch.no_grad():
+                loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2.detach(), self.lpips, weights=(1.0, 1.0, 1.0), global_batch=gctx)
+        else:
+            loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, global_batch=gctx)
+            self.opt.zero_grad()
+            loss_tsa.backward(retain_graph=True)
+            gs = self._sync_grads()
+            self.opt.step(grad_scale=gs)
 
         loss_w, info_w = losses.space_loss(w1, w2, image_space=False, global_batch=gctx)
         loss_mtv = loss_w * 0.01
@@ -417,38 +429,92 @@ def build_models_big(config, img_size=256, start_features=64, compute_dtype="bf1
     return G, E, LP
 
 
-def train(tensor_writer=None, args=None):
-    """Reference E_align_s2.train() for --mtype 2 (flags: E_align_s2.py:304-318)."""
+def load_lpips_weights(LP, vgg_weights=None, lin_weights=None, allow_standin=False):
+    """The `2*lpips` term of every image loss (training_utils.py:93) is only the reference's objective with the real
+    LPIPS-VGG16 weights.  With the two files (see LPIPS.load_pretrained / INTEGRATION.md) they are loaded; without them
+    training is refused unless `allow_standin` (benchmarks, smoke runs), and then says so loudly."""
+    if LP is None:
+        return None
+    if vgg_weights:
+        LP.load_pretrained(vgg_weights, lin_weights)
+        return LP
+    msg = ("LPIPS runs on SEEDED STAND-IN weights (no --vgg_weights / --lpips_weights given): the 2*lpips term of the image "
+           "losses is a random-feature distance, NOT the reference's objective")
+    if not allow_standin:
+        raise RuntimeError(msg + "; pass --vgg_weights vgg16-397923af.pth --lpips_weights <lpips>/weights/v0.1/vgg.pth, "
+                           "or --allow_standin_lpips for throughput / plumbing runs")
+    import sys
+    import warnings
+    warnings.warn(msg)
+    print("WARNING: " + msg, file=sys.stderr)
+    return LP
+
+
+def load_models(args, device="cuda", lpips=True):
+    """Models + checkpoints of one --mtype, shared by `train` and the inference entry points (infer.main).  The three
+    checkpoint containers of the reference: mtype 2 / 3 a dict holding `generator_smooth` (or `generator`)
+    (E_align_s2.py:51-55, :67-77); mtype 1 a DIRECTORY with Gs_dict.pth, Gm_dict.pth and center_tensor.pt (:30-35);
+    mtype 4 a bare state_dict next to --config_dir (:79-86); the encoder is a bare state_dict (--checkpoint_dir_E).
+    Everything is read with map_location='cpu' and moved by load_state_dict.  Returns (G, Gm | None, E, LP | None)."""
     cd = getattr(args, "compute_dtype", "bf16")
+    small = {k: getattr(args, k) for k in ("fmaps_base", "fmaps_max", "enc_maxf") if getattr(args, k, None) is not None}
     if args.mtype == 2:
-        G, E, LP = build_models(args.img_size, args.start_features, cd)
+        G, E, LP = build_models(args.img_size, args.start_features, cd, device=device, lpips=lpips, **small)
         Gm = None
         if args.checkpoint_dir_GAN:
             ckpt = torch.load(args.checkpoint_dir_GAN, map_location="cpu")
             G.load_state_dict(ckpt["generator_smooth"] if "generator_smooth" in ckpt else ckpt["generator"])
     elif args.mtype == 1:
-        G, Gm, E, LP = build_models_sg1(args.img_size, args.start_features, cd)
+        G, Gm, E, LP = build_models_sg1(args.img_size, args.start_features, cd, device=device, lpips=lpips)
         if args.checkpoint_dir_GAN:                 # E_align_s2.py:30-35: a directory holding the three files
             G.load_state_dict(torch.load(args.checkpoint_dir_GAN + "Gs_dict.pth", map_location="cpu"))
             Gm.load_state_dict(torch.load(args.checkpoint_dir_GAN + "Gm_dict.pth", map_location="cpu"))
             Gm.buffer1 = torch.load(args.checkpoint_dir_GAN + "./center_tensor.pt", map_location="cpu")
     elif args.mtype == 3:
-        G, E, LP = build_models_pg(args.img_size, args.start_features, cd)
+        G, E, LP = build_models_pg(args.img_size, args.start_features, cd, device=device, lpips=lpips)
         Gm = None
         if args.checkpoint_dir_GAN:
             ckpt = torch.load(args.checkpoint_dir_GAN, map_location="cpu")
             G.load_state_dict(ckpt["generator_smooth"] if "generator_smooth" in ckpt else ckpt["generator"])
     elif args.mtype == 4:
         from .biggan_generator import BigGANConfig
-        G, E, LP = build_models_big(BigGANConfig.from_json_file(args.config_dir), args.img_size, args.start_features, cd)
+        G, E, LP = build_models_big(BigGANConfig.from_json_file(args.config_dir), args.img_size, args.start_features, cd,
+                                    device=device, lpips=lpips)
         Gm = None
         if args.checkpoint_dir_GAN:
             G.load_state_dict(torch.load(args.checkpoint_dir_GAN, map_location="cpu"))
     else:
         raise ValueError("--mtype must be 1 (StyleGAN1), 2 (StyleGAN2), 3 (PGGAN) or 4 (BigGAN)")
-    if args.checkpoint_dir_E is not None:
+    if getattr(args, "checkpoint_dir_E", None) is not None:
         E.load_state_dict(torch.load(args.checkpoint_dir_E, map_location="cpu"))
-    st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm)
+    return G, Gm, E, LP
+
+
+def add_model_args(parser):
+    """The reference's model flags (E_align_s2.py:304-318), shared by the training and inference parsers."""
+    parser.add_argument("--checkpoint_dir_GAN", default=None)
+    parser.add_argument("--config_dir", default=None)
+    parser.add_argument("--checkpoint_dir_E", default=None)
+    parser.add_argument("--img_size", type=int, default=1024)
+    parser.add_argument("--img_channels", type=int, default=3)
+    parser.add_argument("--z_dim", type=int, default=512)
+    parser.add_argument("--mtype", type=int, default=2)
+    parser.add_argument("--start_features", type=int, default=16)
+    parser.add_argument("--compute_dtype", default="bf16")
+    # not in the reference: reduced StyleGAN2 / encoder widths (tests, smoke runs)
+    parser.add_argument("--fmaps_base", type=int, default=None)
+    parser.add_argument("--fmaps_max", type=int, default=None)
+    parser.add_argument("--enc_maxf", type=int, default=None)
+    return parser
+
+
+def train(tensor_writer=None, args=None):
+    """Reference E_align_s2.train() (flags: E_align_s2.py:304-318)."""
+    G, Gm, E, LP = load_models(args)
+    load_lpips_weights(LP, getattr(args, "vgg_weights", None), getattr(args, "lpips_weights", None),
+                       allow_standin=getattr(args, "allow_standin_lpips", False))
+    st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm,
+                    stage=getattr(args, "stage", 2))
     for iteration in range(args.iterations):
         r = st.step(iteration)
         if iteration % 100 == 0:
@@ -467,15 +533,11 @@ def main(argv=None):
     parser.add_argument("--beta_1", type=float, default=0.0)
     parser.add_argument("--batch_size", type=int, default=2)
     parser.add_argument("--experiment_dir", default=None)
-    parser.add_argument("--checkpoint_dir_GAN", default=None)
-    parser.add_argument("--config_dir", default=None)
-    parser.add_argument("--checkpoint_dir_E", default=None)
-    parser.add_argument("--img_size", type=int, default=1024)
-    parser.add_argument("--img_channels", type=int, default=3)
-    parser.add_argument("--z_dim", type=int, default=512)
-    parser.add_argument("--mtype", type=int, default=2)
-    parser.add_argument("--start_features", type=int, default=16)
-    parser.add_argument("--compute_dtype", default="bf16")
+    add_model_args(parser)
+    parser.add_argument("--stage", type=int, default=2, help="2: E_align_s2.py; 1: E_align_cropping_s1.py (latent phase only trains E)")
+    parser.add_argument("--vgg_weights", default=None, help="torchvision vgg16 checkpoint (features.*) or an lpips.LPIPS state_dict")
+    parser.add_argument("--lpips_weights", default=None, help="the lpips package's weights/v0.1/vgg.pth (lin{k}.model.1.weight)")
+    parser.add_argument("--allow_standin_lpips", action="store_true", help="train on seeded stand-in LPIPS weights (NOT the reference objective)")
     return train(None, parser.parse_args(argv))
 
 

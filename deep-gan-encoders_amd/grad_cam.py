@@ -71,6 +71,16 @@ class VGG16(nn.Module):
             self.classifier.add_module(str(k), _Param((o, i), i, gen))
         self._cache = {}
 
+    def load_pretrained(self, weights):
+        """torchvision's vgg16 checkpoint (`features.{i}.weight/bias`, `classifier.{k}.weight/bias`: the names this module
+        uses) from a path or a dict; marks the module `pretrained` (without it the class scores are those of seeded stand-in
+        weights, and a Grad-CAM computed on them is structural only)."""
+        sd = torch.load(weights, map_location="cpu") if isinstance(weights, (str, bytes)) or hasattr(weights, "read") else dict(weights)
+        self.load_state_dict(sd)
+        self._cache.clear()
+        self.pretrained = True
+        return self
+
     @property
     def final_layer(self):
         """Name of the last Conv2d, what E_mis_align_cropping_s1.py:101-104 searches for."""

@@ -113,3 +113,89 @@ def save_image(img, path):
     x = (img.detach().float().cpu() * 0.5 + 0.5).clamp(0, 1)
     x = torch.cat(list(x), dim=2)                              # [3,H,B*W]
     Image.fromarray((x.permute(1, 2, 0) * 255.0 + 0.5).to(torch.uint8).numpy()).save(path)
+
+
+def save_image_grid(imgs, path, nrow=10):
+    """torchvision.utils.save_image(imgs*0.5+0.5, path, nrow=nrow) without torchvision: `nrow` images per row, 2 px padding."""
+    from PIL import Image
+    x = (imgs.detach().float().cpu() * 0.5 + 0.5).clamp(0, 1)
+    n, c, h, w = x.shape
+    cols = min(nrow, n)
+    rows = (n + cols - 1) // cols
+    pad = 2
+    grid = torch.zeros(c, rows * (h + pad) + pad, cols * (w + pad) + pad)
+    for i in range(n):
+        r, q = divmod(i, cols)
+        grid[:, pad + r * (h + pad):pad + r * (h + pad) + h, pad + q * (w + pad):pad + q * (w + pad) + w] = x[i]
+    Image.fromarray((grid.permute(1, 2, 0) * 255.0 + 0.5).to(torch.uint8).numpy()).save(path)
+
+
+def _step_from_args(args, device="cuda"):
+    from .e_align import EAlignStep, load_models
+    G, Gm, E, _ = load_models(args, device=device, lpips=False)
+    G.eval()
+    E.eval()
+    return EAlignStep(G, E, None, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm)
+
+
+def main(argv=None):
+    """Entry points of the reference's inference scripts on the HIP path (`python -m dge_amd.infer <command> ...`), every
+    --mtype and its checkpoint container (e_align.load_models):
+
+    * `infer` - inferE.py:101-141: seed 4, z -> G -> E -> G, writes <out>/v2ep<seed>.png (originals over reconstructions);
+    * `rec`   - rec_real_img.py:84-127: every image of --img_dir -> E -> G, writes <out>/real/%05d_realimg.png and
+                <out>/rec/%05d_mtv_rec.png;
+    * `synth` - synthesized_IMG.py:97-145: for iteration in 30000 .. 30000 + --iterations: set_seed(iteration), z -> G -> E -> G,
+                writes <out>/id<flag>_%05d.png (nrow 10: originals then reconstructions)."""
+    import argparse
+    import os
+    from .e_align import add_model_args, set_seed, _BigGANAdapter
+    parser = argparse.ArgumentParser(prog="dge_amd.infer", description=main.__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    parser.add_argument("command", choices=("infer", "rec", "synth"))
+    add_model_args(parser)
+    parser.add_argument("--batch_size", type=int, default=5)
+    parser.add_argument("--seed", type=int, default=4)
+    parser.add_argument("--iterations", type=int, default=1)
+    parser.add_argument("--img_dir", default=None, help="rec: directory of images (sorted by name)")
+    parser.add_argument("--out", default="./result")
+    args = parser.parse_args(argv)
+    os.makedirs(args.out, exist_ok=True)
+    step = _step_from_args(args)
+    written = []
+    if args.command == "infer":
+        r = reconstruct(step, iteration=args.seed)
+        path = os.path.join(args.out, "v2ep%d.png" % args.seed)
+        save_image_grid(torch.cat((r["imgs1"][:args.batch_size], r["imgs2"][:args.batch_size])), path, nrow=args.batch_size)
+        written.append(path)
+    elif args.command == "rec":
+        if not args.img_dir:
+            parser.error("rec needs --img_dir")
+        names = sorted(n for n in os.listdir(args.img_dir) if n.lower().endswith((".png", ".jpg", ".jpeg", ".bmp")))
+        if not names:
+            parser.error("rec: no images in " + args.img_dir)
+        d1, d2 = os.path.join(args.out, "real"), os.path.join(args.out, "rec")
+        os.makedirs(d1, exist_ok=True)
+        os.makedirs(d2, exist_ok=True)
+        imgs = load_images([os.path.join(args.img_dir, n) for n in names], args.img_size, device=step.dev)
+        set_seed(args.seed)                                   # the encoder draws noise in every forward (model/E/E.py:62,72)
+        _, rec = reconstruct_images(step, imgs)
+        for i in range(imgs.shape[0]):
+            a, b = os.path.join(d1, "%s_realimg.png" % str(i).rjust(5, "0")), os.path.join(d2, "%s_mtv_rec.png" % str(i).rjust(5, "0"))
+            save_image_grid(imgs[i:i + 1], a, nrow=1)
+            save_image_grid(rec[i:i + 1], b, nrow=1)
+            written += [a, b]
+    else:
+        big = isinstance(step.gen, _BigGANAdapter)
+        for iteration in range(30000, 30000 + args.iterations):
+            r = reconstruct(step, iteration=iteration % 30000 if big else iteration)
+            flag = getattr(step.gen, "flag", 0) if big else 0
+            path = os.path.join(args.out, "id%s_%s.png" % (flag, str(iteration - 30000).rjust(5, "0")))
+            save_image_grid(torch.cat((r["imgs1"], r["imgs2"])), path, nrow=10)
+            written.append(path)
+    for w in written:
+        print(w)
+    return written
+
+
+if __name__ == "__main__":
+    main()

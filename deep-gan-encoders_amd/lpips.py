@@ -70,6 +70,42 @@ class LPIPS(nn.Module):
         self._cache = {}
 
     # ---------------------------------------------------------------- weights
+    def load_pretrained(self, vgg_weights, lin_weights=None):
+        """Real LPIPS-VGG weights from the two files a user of the reference already has (training_utils.py:93,
+        requirements.txt:12 `lpips`): `vgg_weights` = torchvision's vgg16 checkpoint (`features.{i}.weight/bias`, what
+        lpips.pretrained_networks.vgg16 wraps) or a full `lpips.LPIPS(net='vgg').state_dict()` (`net.slice{k}.{i}.*`);
+        `lin_weights` = the package's `weights/v0.1/vgg.pth` (`lin{k}.model.1.weight`; the `lins.{k}.*` duplicates that
+        newer versions write are ignored).  Paths or already-loaded dicts.  Sets `self.pretrained = True` only when every
+        convolution and every linear head was found; raises KeyError otherwise."""
+        def _load(src):
+            return torch.load(src, map_location="cpu") if isinstance(src, (str, bytes)) or hasattr(src, "read") else dict(src)
+        sd = self.state_dict()
+        new = {}
+        vgg = _load(vgg_weights)
+        for ci, idx in enumerate(_CONV_IDX):
+            for leaf in ("weight", "bias"):
+                mine = f"net.slice{_SLICE[ci]}.{idx}.{leaf}"
+                src = mine if mine in vgg else f"features.{idx}.{leaf}"
+                if src not in vgg:
+                    raise KeyError(f"LPIPS.load_pretrained: neither {mine} nor features.{idx}.{leaf} in the VGG16 weights")
+                new[mine] = vgg[src]
+        lins = _load(lin_weights) if lin_weights is not None else vgg
+        for k in range(5):
+            mine = f"lin{k}.model.1.weight"
+            src = mine if mine in lins else f"lins.{k}.model.1.weight"
+            if src not in lins:
+                raise KeyError(f"LPIPS.load_pretrained: {mine} missing from the linear-head weights")
+            new[mine] = lins[src]
+        for k in ("scaling_layer.shift", "scaling_layer.scale"):
+            new[k] = vgg.get(k, lins.get(k, sd[k]))
+        for k, v in new.items():
+            if tuple(v.shape) != tuple(sd[k].shape):
+                raise ValueError(f"LPIPS.load_pretrained: {k} has shape {tuple(v.shape)}, expected {tuple(sd[k].shape)}")
+        self.load_state_dict(new)
+        self._cache.clear()
+        self.pretrained = True
+        return self
+
     def _packed(self, ci, dt, mode):
         conv = self.convs[ci]
         key = (ci, dt, mode)

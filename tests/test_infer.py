@@ -124,3 +124,93 @@ def test_reconstruct_round_trip_runs_for_stylegan2():
     from dge_amd.infer import reconstruct_images
     w2, imgs2 = reconstruct_images(st, r["imgs1"])
     assert w2.shape == (2, 10, 512) and imgs2.shape == (2, 3, 64, 64) and torch.isfinite(imgs2).all()
+
+
+def _args(**kw):
+    import argparse
+    from dge_amd.e_align import add_model_args
+    a = add_model_args(argparse.ArgumentParser()).parse_args([])
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+def test_load_models_reads_the_three_checkpoint_containers(tmp_path):
+    """E_align_s2.py:30-35 (mtype 1: directory with Gs_dict.pth / Gm_dict.pth / center_tensor.pt), :51-55 (mtype 2 / 3: dict
+    with `generator_smooth`, falling back to `generator`), bare encoder state_dict: written, read back through
+    e_align.load_models on the host (map_location='cpu'), parameters identical."""
+    from dge_amd.e_align import load_models, build_models, build_models_sg1, build_models_pg
+    # mtype 2
+    G, E, _ = build_models(64, 16, "f32", device="cpu", lpips=False, seed=3, fmaps_base=2048, fmaps_max=128, enc_maxf=64)
+    torch.save({"generator_smooth": G.state_dict(), "generator": {k: v + 1 for k, v in G.state_dict().items()}}, tmp_path / "g2.pth")
+    torch.save(E.state_dict(), tmp_path / "e2.pth")
+    a = _args(mtype=2, img_size=64, start_features=16, compute_dtype="f32", fmaps_base=2048, fmaps_max=128, enc_maxf=64,
+              checkpoint_dir_GAN=str(tmp_path / "g2.pth"), checkpoint_dir_E=str(tmp_path / "e2.pth"))
+    G2, Gm2, E2, LP2 = load_models(a, device="cpu", lpips=False)
+    assert Gm2 is None and LP2 is None
+    assert all(torch.equal(v, G2.state_dict()[k]) for k, v in G.state_dict().items())
+    assert all(torch.equal(v, E2.state_dict()[k]) for k, v in E.state_dict().items())
+    torch.save({"generator": G.state_dict()}, tmp_path / "g2b.pth")                    # no smoothed copy in the file
+    a.checkpoint_dir_GAN = str(tmp_path / "g2b.pth")
+    G3 = load_models(a, device="cpu", lpips=False)[0]
+    assert all(torch.equal(v, G3.state_dict()[k]) for k, v in G.state_dict().items())
+    # mtype 1: a directory (the script concatenates strings: the trailing slash is the caller's)
+    Gs, Gm, E1, _ = build_models_sg1(32, 16, "f32", device="cpu", lpips=False, seed=4)
+    d = tmp_path / "sg1"
+    d.mkdir()
+    torch.save(Gs.state_dict(), d / "Gs_dict.pth")
+    torch.save(Gm.state_dict(), d / "Gm_dict.pth")
+    center = torch.randn(2 * 4, 512)
+    torch.save(center, d / "center_tensor.pt")
+    a1 = _args(mtype=1, img_size=32, start_features=16, compute_dtype="f32", checkpoint_dir_GAN=str(d) + "/")
+    Gs2, Gm2, _, _ = load_models(a1, device="cpu", lpips=False)
+    assert all(torch.equal(v, Gs2.state_dict()[k]) for k, v in Gs.state_dict().items())
+    assert all(torch.equal(v, Gm2.state_dict()[k]) for k, v in Gm.state_dict().items())
+    assert torch.equal(Gm2.buffer1, center)
+    # mtype 3
+    Gp, Ep, _ = build_models_pg(32, 16, "f32", device="cpu", lpips=False, seed=5)
+    torch.save({"generator_smooth": Gp.state_dict()}, tmp_path / "g3.pth")
+    a3 = _args(mtype=3, img_size=32, start_features=16, compute_dtype="f32", checkpoint_dir_GAN=str(tmp_path / "g3.pth"))
+    Gp2 = load_models(a3, device="cpu", lpips=False)[0]
+    assert all(torch.equal(v, Gp2.state_dict()[k]) for k, v in Gp.state_dict().items())
+    with pytest.raises(ValueError):
+        load_models(_args(mtype=7), device="cpu", lpips=False)
+
+
+@pytest.mark.gpu
+def test_inference_entry_points_write_the_reference_file_layout(tmp_path):
+    """`python -m dge_amd.infer infer|rec|synth` (inferE.py:101-141, rec_real_img.py:84-127, synthesized_IMG.py:97-145) from
+    checkpoint files: the written reconstructions equal a direct E -> G call on the same inputs."""
+    import numpy as np
+    from PIL import Image
+    from dge_amd import infer
+    from dge_amd.e_align import build_models
+    G, E, _ = build_models(64, 16, "bf16", device="cuda", lpips=False, seed=3, fmaps_base=2048, fmaps_max=128, enc_maxf=64)
+    torch.save({"generator_smooth": G.state_dict()}, tmp_path / "g.pth")
+    torch.save(E.state_dict(), tmp_path / "e.pth")
+    common = ["--mtype", "2", "--img_size", "64", "--start_features", "16", "--fmaps_base", "2048", "--fmaps_max", "128",
+              "--enc_maxf", "64", "--checkpoint_dir_GAN", str(tmp_path / "g.pth"), "--checkpoint_dir_E", str(tmp_path / "e.pth")]
+    out = infer.main(["infer", "--batch_size", "3", "--out", str(tmp_path / "o1")] + common)
+    assert [p.split("/")[-1] for p in out] == ["v2ep4.png"]
+    assert Image.open(out[0]).size == (3 * 66 + 2, 2 * 66 + 2)
+    out = infer.main(["synth", "--batch_size", "2", "--iterations", "2", "--out", str(tmp_path / "o2")] + common)
+    assert [p.split("/")[-1] for p in out] == ["id0_00000.png", "id0_00001.png"]
+    # rec: two image files -> per-image real / reconstruction PNGs
+    src = tmp_path / "imgs"
+    src.mkdir()
+    rng = np.random.RandomState(0)
+    for i in range(2):
+        Image.fromarray(rng.randint(0, 255, (80, 72, 3), dtype=np.uint8)).save(src / f"im{i}.png")
+    out = infer.main(["rec", "--img_dir", str(src), "--out", str(tmp_path / "o3")] + common)
+    assert [p.split("/")[-1] for p in out] == ["00000_realimg.png", "00000_mtv_rec.png", "00001_realimg.png", "00001_mtv_rec.png"]
+    # same inputs through the library: identical pixels (eval-mode models, deterministic forward)
+    from dge_amd.e_align import EAlignStep
+    G.eval(); E.eval()
+    st = EAlignStep(G, E, None, batch_size=2)
+    imgs = infer.load_images([str(src / "im0.png"), str(src / "im1.png")], 64)
+    from dge_amd.e_align import set_seed
+    set_seed(4)                                               # the entry point's default --seed: same encoder noise draws
+    _, rec = infer.reconstruct_images(st, imgs)
+    want = ((rec[1:2].float().cpu() * 0.5 + 0.5).clamp(0, 1)[0].permute(1, 2, 0) * 255.0 + 0.5).to(torch.uint8).numpy()
+    got = np.asarray(Image.open(out[3]))[2:-2, 2:-2]
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1

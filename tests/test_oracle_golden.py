@@ -185,6 +185,15 @@ def test_shape_tables_match_reference_state_dicts():
     assert len(ek["1024_16_9"]) == 101 and len(ek["256_64_7"]) == 77
 
 
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers():
+    """oracle/Makefile `san-check`: the C restatement compiled with -fsanitize=address,undefined (reports fatal) and driven
+    over the parity shapes and the edge cases by oracle/san_driver.c."""
+    import subprocess
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "san-check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cases clean" in r.stdout
+
+
 def test_c_oracle_modconv():
     """The plain-C restatement of the north-star kernel (oracle/modconv_oracle.c, the reference's
     fused per-sample-weight formulation) against the reference's own outputs."""

@@ -72,6 +72,51 @@ def test_two_phase_step_matches_reference_run():
         assert relerr(G.truncation.w_avg, g[f"it{it}_w_avg"]) < 1e-5
 
 
+def test_stage1_step_matches_reference_run():
+    """stage=1 (E_align_cropping_s1.py:185-218): image losses on detached inputs, unweighted sum, latent phase only trains E;
+    two iterations against the reference modules' own run (tests/golden/step_s1.npz, tools/gen_golden.py step_s1)."""
+    import dge_amd
+    from dge_amd.encoder import BE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.e_align import EAlignStep
+    g = golden("step_s1.npz")
+    G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="f32").cuda()
+    G.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+    G.train()
+    for p in G.parameters():
+        p.requires_grad_(False)
+    E = BE(startf=16, maxf=64, layer_count=5, compute_dtype="f32").cuda()
+    E.load_state_dict(R.fill_encoder(enc_shapes(16, 64, 5), seed=31))
+    LP = LPIPS(compute_dtype="f32").cuda()
+    LP.load_state_dict(LR.seeded_params(0))
+    st = EAlignStep(G, E, LP, lr=0.0015, batch_size=2, stage=1)
+    new_z = R.randn("step.new_z", (2, 512), 1).cuda()
+    for it in range(2):
+        z = R.randn(f"step.z{it}", (2, 512), 1)
+        noises = [R.randn(f"step.it{it}.noise{i}", s, 1).cuda() for i, s in enumerate(O.enc_noise_shapes(5, 2, 64))]
+        r = st.step(it, z=z, noises=noises, new_z=new_z)
+        assert relerr(r["w2"], g[f"it{it}_w2"]) < 2e-3
+        assert relerr(r["imgs2"], g[f"it{it}_imgs2"]) < 2e-3
+        info = r["info_img"].cpu().numpy()
+        got = [float(r["loss_tsa"]), info[0, 0], info[1, 0], info[2, 0], float(r["loss_w"])]
+        for a, b in zip(got, g[f"it{it}_losses"]):
+            assert abs(a - b) < 2e-3 * abs(b), (it, got, g[f"it{it}_losses"])
+        sd = E.state_dict()
+        for key in g.files:
+            if key.startswith(f"it{it}_after_phase2:"):
+                k = key.split(":", 1)[1]
+                assert relerr(sd[k], g[key]) < 1e-4, (it, k)
+                if it == 0:
+                    before = R.fill_encoder(enc_shapes(16, 64, 5), seed=31)[k]
+                    du_ref = torch.as_tensor(g[key]) - before
+                    du = sd[k].cpu() - before
+                    if du_ref.abs().max() > 0:
+                        assert ((du - du_ref).abs().max() / du_ref.abs().max()).item() < 0.05, (it, k)
+        assert abs(R.checksum({k: v.cpu() for k, v in sd.items()}) - float(g[f"it{it}_param_checksum"])) < 1e-5 * float(g[f"it{it}_param_checksum"])
+    with pytest.raises(ValueError):
+        EAlignStep(G, E, LP, stage=3)
+
+
 def test_two_phase_step_bf16_matches_reference_run():
     """The BENCHMARKED precision (bf16 storage, f32 accumulation) through two complete two-phase iterations against the
     reference's own fp32 run (tests/golden/step_s2.npz).  Tolerances = 2x the error measured on MI355X (in the comments),

@@ -382,6 +382,72 @@ def gen_step():
     save_npz("step_s2.npz", **out)
 
 
+def gen_step_s1():
+    """Two iterations of the STAGE-1 variant (E_align_cropping_s1.py:185-218) of the REFERENCE's modules at reduced size: the
+    three image-space losses are computed on `.detach().clone()` inputs and summed unweighted (:185-203) - they carry no
+    gradient to the encoder, so the first backward / optimizer step of the script changes nothing in E (gradients stay None
+    after zero_grad) - and only the latent phase loss_w * 0.01 (:207-218) trains it."""
+    import warnings
+    from model.stylegan2_generator import StyleGAN2Generator
+    import model.E.E as EE
+    import training_utils as TU
+    from model.utils.custom_adam import LREQAdam
+    from oracle import lpips_ref as LR
+
+    G = StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128)
+    G.load_state_dict(R.fill_s2(shapes_of(G.state_dict()), seed=11))
+    E = EE.BE(startf=16, maxf=64, layer_count=5)
+    E.load_state_dict(R.fill_encoder(shapes_of(E.state_dict()), seed=31))
+    LP = LR.seeded_params(0)
+    lp = lambda a, b: LR.lpips(LP, a, b)
+    opt = LREQAdam([{"params": E.parameters()}], lr=0.0015, betas=(0.0, 0.99), weight_decay=0)
+    out = {}
+    B = 2
+    new_z = R.randn("step.new_z", (B, 512), 1)
+    orig_randn_like = torch.randn_like
+    torch.randn_like = lambda t, **kw: new_z.clone()
+    try:
+        for it in range(2):
+            np.random.seed(it)
+            z = R.randn(f"step.z{it}", (B, 512), 1)
+            with torch.no_grad():
+                r = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
+            imgs1, w1 = r["image"], r["wp"]
+            with _NoiseFeeder(f"step.it{it}", 1):
+                const2, w2 = E(imgs1)
+            imgs2 = G.synthesis(w2)["image"]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                l_i, i_i = TU.space_loss(imgs1.detach().clone(), imgs2.detach().clone(), lpips_model=lp)
+                m1 = imgs1[:, :, :, imgs1.shape[3] // 8:-imgs1.shape[3] // 8].detach().clone()
+                m2 = imgs2[:, :, :, imgs2.shape[3] // 8:-imgs2.shape[3] // 8].detach().clone()
+                l_m, i_m = TU.space_loss(m1, m2, lpips_model=lp)
+                o = imgs1.shape[2] // 8 + imgs1.shape[2] // 32
+                s1, s2 = imgs1[:, :, o:-o, o:-o].detach().clone(), imgs2[:, :, o:-o, o:-o].detach().clone()
+                l_s, i_s = TU.space_loss(s1, s2, lpips_model=lp)
+                loss_tsa = l_i + l_m + l_s
+                opt.zero_grad()
+                assert not loss_tsa.requires_grad          # nothing of E is reachable: the script's backward() only touches lpips' own layers
+                opt.step()                                  # all gradients None: no parameter, no Adam state changes
+                l_w, i_w = TU.space_loss(w1, w2, image_space=False)
+                loss_mtv = l_w * 0.01
+                opt.zero_grad()
+                loss_mtv.backward()
+                opt.step()
+            flat = lambda inf: [inf[0][0], inf[0][1], inf[0][2], inf[1], inf[2], inf[3], inf[4]]
+            out[f"it{it}_w2"] = w2.detach()
+            out[f"it{it}_imgs2"] = imgs2.detach()
+            out[f"it{it}_losses"] = np.array([float(loss_tsa), float(l_i), float(l_m), float(l_s), float(l_w)])
+            out[f"it{it}_info"] = np.array([flat(i_i), flat(i_m), flat(i_s), flat(i_w)])
+            out[f"it{it}_param_checksum"] = np.array(R.checksum(E.state_dict()))
+            for k in ("decode_block.0.conv_1.weight", "decode_block.2.conv_2.weight", "decode_block.4.inver_mod2.weight",
+                      "decode_block.1.bias_1", "FromRGB.from_rgb.weight"):
+                out[f"it{it}_after_phase2:{k}"] = E.state_dict()[k].clone()
+    finally:
+        torch.randn_like = orig_randn_like
+    save_npz("step_s1.npz", **out)
+
+
 # --------------------------------------------------------------------------- StyleGAN1
 def gen_sg1():
     import model.stylegan1.net as SG1
@@ -656,6 +722,7 @@ def gen_step_sg1():
 
 
 SECTIONS["step_sg1"] = gen_step_sg1
+SECTIONS["step_s1"] = gen_step_s1
 
 def gen_encblurgrad():
     """Gradients of the reference E_Blur.BE w.r.t. every parameter AND the input image for a seeded linear functional of
