@@ -60,6 +60,10 @@ __device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
+// the same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: no per-lane 64-bit address arithmetic
+__device__ __forceinline__ void glds16_saddr(unsigned voff, unsigned long long sbase, unsigned lds_dst_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst_uniform) : "memory");
+}
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
@@ -243,15 +247,31 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     // ---- weight stage (kernel row `row` of chunk kc): KS taps x BN rows x KC, global -> LDS directly
     // (global_load_lds: no VGPR round trip; the LDS image is lane-linear per 1 KiB piece, so the
     // bank-conflict swizzle is applied to the per-lane SOURCE chunk and undone by the fragment reads)
-    auto dma_b = [&](int kc, int row, int buf) {
+    // The per-lane part of the source address (piece, tap within the row, weight row, swizzled chunk) does not depend on the
+    // stage: it is computed once as a 32-bit byte offset per piece; a stage adds a scalar base (kernel row, K chunk), so a
+    // piece costs one M0 write and one instruction (the address arithmetic used to be ~18 instructions per piece, ~15 % of
+    // the 128-wide configuration's time).
+    constexpr int NPW = (C::B_PIECES + 3) / 4;               // pieces per wave (the last one may not exist for every wave)
+    unsigned boff[NPW];
+    {
         constexpr int RPP = 1024 / C::KCB;                   // weight rows per piece
-        for (int pc = wave; pc < C::B_PIECES; pc += 4) {
+#pragma unroll
+        for (int k = 0; k < NPW; k++) {
+            const int pc = wave + 4 * k;
             const int r = pc * RPP + lane / C::CH;           // row within the stage = t*BN + n
             const int c = (lane % C::CH) ^ ((r / C::RP) % C::CH);
             const int t = r / BN, n = r % BN;
-            const T* src = Wp + ((size_t)((row * KS + t) * p.Ntot + bn0 + n) * p.Cin + kc * KC) + c * EP16;
-            glds16_untracked(src, __builtin_amdgcn_readfirstlane(ldsB_off + buf * C::B_BYTES + pc * 1024));
+            boff[k] = (unsigned)((((size_t)t * p.Ntot + bn0 + n) * p.Cin + c * EP16) * sizeof(T));
         }
+    }
+    auto dma_b = [&](int kc, int row, int buf) {
+        const unsigned long long sb = (unsigned long long)Wp + ((size_t)row * KS * p.Ntot * p.Cin + (size_t)kc * KC) * sizeof(T);
+        StaticFor<NPW>::run([&](auto kcst) {
+            constexpr int k = decltype(kcst)::value;
+            const int pc = wave + 4 * k;
+            if (C::B_PIECES % 4 == 0 || pc < C::B_PIECES)
+                glds16_saddr(boff[k], sb, __builtin_amdgcn_readfirstlane(ldsB_off + buf * C::B_BYTES + pc * 1024));
+        });
     };
 
     // ---- prologue: first halo tile, first NBUF-1 weight stages, noise tile
