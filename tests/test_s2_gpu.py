@@ -1,7 +1,7 @@
 """GPU parity of the StyleGAN2 HIP path (through the C ABI) against the golden vectors of the
 reference and against the oracle.  Tolerances: f32 path 2e-4 of the tensor's max magnitude
-(exact-f32 MFMA, differences are summation order only); bf16 path 6e-2 at the image / 3e-2 per
-layer (bf16 storage of activations and weights, f32 accumulation)."""
+(exact-f32 MFMA, differences are summation order only); bf16 path (bf16 storage of activations and weights, f32
+accumulation): every bound is 2x the error measured on MI355X (three runs, round 2; the measured value is in the comment)."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +12,7 @@ from tests.helpers import s2_shapes, modconv_shapes
 from oracle import ref_torch as O
 
 pytestmark = pytest.mark.gpu
-TOL = {"f32": 2e-4, "bf16": 3e-2}
+TOL = {"f32": 2e-4, "bf16": 9e-3}      # bf16 measured: blocks 1.6e-3 .. 4.3e-3, ragged convs 3.0e-3 .. 4.3e-3
 
 
 def relerr(a, b):
@@ -50,6 +50,7 @@ def test_modconv_blocks_vs_reference_golden(cd):
         assert relerr(s, g[f"c{ci}_style"]) < 1e-5
         y = y.cpu() if torgb else from_nhwc(y)
         e = relerr(y, g[f"c{ci}_y"])
+        print(f"MEAS blocks {cd} case{ci} {e:.3e}")
         assert e < TOL[cd], f"case {ci} ({cin}->{cout} res {res} up {up} k {k}) {cd}: {e:.3e}"
 
 
@@ -67,14 +68,17 @@ def test_synthesis_vs_reference_golden(cd):
     assert relerr(r["style00"], g["syn_style00"]) < 1e-5
     assert relerr(r["output_style4"], g["syn_output_style4"]) < 1e-5
     e = relerr(r["image"], g["syn_image"])
-    assert e < (2e-4 if cd == "f32" else 6e-2), e
+    print(f"MEAS syn_image {cd} {e:.3e}")
+    assert e < (2e-4 if cd == "f32" else 1.8e-2), e          # bf16 measured 8.9e-3 (12 layers deep)
     # full forward in eval mode: mapping + truncation + synthesis
     z = R.randn("s2.z", (2, 512), 5).cuda()
     with torch.no_grad():
         r = G(z, trunc_psi=0.7, trunc_layers=8, randomize_noise=False)
     assert relerr(r["w"], g["eval_w"]) < 1e-5
     assert relerr(r["wp"], g["eval_wp"]) < 1e-5
-    assert relerr(r["image"], g["eval_image"]) < (2e-4 if cd == "f32" else 6e-2)
+    e = relerr(r["image"], g["eval_image"])
+    print(f"MEAS eval_image {cd} {e:.3e}")
+    assert e < (2e-4 if cd == "f32" else 1.3e-2), e          # bf16 measured 6.3e-3
 
 
 def test_train_mode_quirk_q1_matches_reference():
@@ -118,9 +122,10 @@ def test_conv_vs_oracle_random_shapes(cd):
                        in_scale=isc.cuda(), in_shift=ish.cuda(), bias=bias.cuda(), noise=noise.view(B, H, W).cuda(),
                        noise_w=nw.cuda(), act=ops.ACT_LRELU, stats=stats)
         e = relerr(from_nhwc(y), ref)
+        print(f"MEAS conv {cd} {(B, cin, cout, H, W, k)} {e:.3e} stats {relerr(stats, torch.stack([ref.sum(dim=(2, 3)), (ref * ref).sum(dim=(2, 3))], dim=2)):.3e}")
         assert e < TOL[cd], ((B, cin, cout, H, W, k), e)
         s_ref = torch.stack([ref.sum(dim=(2, 3)), (ref * ref).sum(dim=(2, 3))], dim=2)
-        assert relerr(stats, s_ref) < (1e-4 if cd == "f32" else 3e-2)
+        assert relerr(stats, s_ref) < (1e-4 if cd == "f32" else 4e-3)      # bf16 measured 0.8e-3 .. 1.8e-3
 
 
 @pytest.mark.parametrize("cd", ["f32", "bf16"])
@@ -133,8 +138,9 @@ def test_synthesis_grad_wp_vs_reference_golden(cd):
     G.load_state_dict(P)
     wp = R.randn("s2.wp", (2, 10, 512), 5).cuda().requires_grad_(True)
     img = G.synthesis(wp)["image"]
-    assert relerr(img, g["syn_image"]) < (2e-4 if cd == "f32" else 6e-2)
+    assert relerr(img, g["syn_image"]) < (2e-4 if cd == "f32" else 1.8e-2)
     gimg = R.randn("s2.gimg", tuple(img.shape), 5, 1.0 / img.numel() ** 0.5).cuda()
     (img * gimg).sum().backward()
     e = relerr(wp.grad, g["grad_wp"])
-    assert e < (1e-3 if cd == "f32" else 8e-2), e
+    print(f"MEAS grad_wp {cd} {e:.3e}")
+    assert e < (1e-3 if cd == "f32" else 8e-2), e                # bf16 measured 3.8e-2
