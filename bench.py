@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-2 and eval-mode-G entries")
+    ap.add_argument("--extra-graph", action="store_true", help="also replay the batch-2 step from a hipGraph inside this process (capturing after eager "
+                    "steps of the same models crashed the runtime once: opt-in; `--graph --batch 2` is the robust way)")
     ap.add_argument("--no-synthesis", action="store_true", help="skip the synthesis-only timing (used by tools/pmc_traffic.sh so that "
                     "the profiled conv launches are exactly those of the training steps)")
     ap.add_argument("--cpu-size", type=int, default=1024, help="image size of the bounded CPU-oracle sample")
@@ -209,6 +211,18 @@ def main():
             d2, s2 = timed_steps(lambda i: st2.step(i), 3, 10, sync)
             extras["batch2"] = {"value": 2 * 10 / d2, "unit": "images/sec", "ms_per_step": d2 / 10 * 1e3, "step_ms_median": s2["median"],
                                 "note": "reference default batch (E_align_s2.py:308), eager"}
+            # the same batch replayed from a captured hipGraph: at this batch the eager step is bound by the host's launch rate
+            try:
+                if not a.extra_graph:
+                    raise RuntimeError("skipped (opt-in: --extra-graph; `python bench.py --graph --batch 2` measures the same in its own process)")
+                st2.capture()
+                for i in range(2):
+                    st2.replay()
+                dg, sg = timed_steps(lambda i: st2.replay(), 0, 10, sync)
+                extras["batch2_graph"] = {"value": 2 * 10 / dg, "unit": "images/sec", "ms_per_step": dg / 10 * 1e3, "step_ms_median": sg["median"],
+                                          "note": "batch 2, hipGraph replay of the captured iteration (EAlignStep.capture / replay)"}
+            except Exception as ex:
+                extras["batch2_graph"] = {"value": None, "note": f"not measured: {ex}"}
             del st2
         G.eval()
         for i in range(2):
@@ -266,14 +280,15 @@ def main():
         # HBM bytes per launch from the PMC counters: collected offline by tools/pmc_traffic.sh (separate rocprofv3 --pmc
         # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
         traffic, tsrc = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")
+        tname = "r02_conv_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_conv_traffic.json")) else "r01_conv_traffic.json"
+        tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and a.mtype == 2 and a.img_size == 1024 and a.batch == 8 and a.dtype == "bf16":
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic, tsrc = tj["traffic_bytes_per_launch"], "profiles/r01_conv_traffic.json"
+            traffic, tsrc = tj["traffic_bytes_per_launch"], "profiles/" + tname
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "conv_igemm_kernel<*> + upconv_fir_kernel (all implicit-GEMM conv launches of a step)",
+                           "kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + upconv_fir_kernel (all conv launches of a step: dge_conv2d)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,
                            "algorithmic_bytes_per_launch": ab / max(nlaunch, 1),
