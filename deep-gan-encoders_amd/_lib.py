@@ -30,6 +30,8 @@ SIGNATURES = {
     "dge_sum_slots_planar": [_P, _P, _I, _I, _I, _P],
     "dge_packed_n": [_I],
     "dge_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "dge_pack_conv_weights_multi": [_P, _P, _I, _I, _P],
+    "dge_pack_desc_bytes": [],
     "dge_weight_sumsq": [_P, _P, _I, _I, _I, _F, _P],
     "dge_linear": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _I, _F, _I, _P],
     "dge_pixelnorm": [_P, _P, _I, _I, _F, _P],

@@ -6,16 +6,29 @@ from . import ops
 from .stylegan2_generator import _dt
 
 
+def _ver(w):
+    return (w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
+
+
 def _packed(cache, conv, dtype, mode):
-    """Packed copy of a conv weight, rebuilt when the parameter was updated in place."""
+    """Packed copy of a conv weight, rebuilt when the parameter was updated in place.  An optimizer step makes EVERY copy of
+    the module stale at once: the first stale hit refreshes all of them in one launch (ops.pack_conv_weights_multi) - in
+    place, the consumers of the old values are earlier on the same stream."""
     w = conv.weight
     key = (id(w), mode, dtype)
-    ver = (w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
+    ver = _ver(w)
     hit = cache.get(key)
-    if hit is None or hit[0] != ver:
-        hit = (ver, ops.pack_conv_weight(w, mode, dtype, 1.0))
-        cache[key] = hit
-    return hit[1]
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    if hit is None:
+        cache[key] = [ver, ops.pack_conv_weight(w, mode, dtype, 1.0), w]
+        return cache[key][1]
+    stale = [(k, e) for k, e in cache.items() if isinstance(k, tuple) and len(k) == 3 and isinstance(e, list) and _ver(e[2]) != e[0]]
+    cache["_pack_scratch"] = ops.pack_conv_weights_multi([(e[2].detach(), k[1], k[2], 1.0, e[1]) for k, e in stale],
+                                                         cache.get("_pack_scratch"))
+    for k, e in stale:
+        e[0] = _ver(e[2])
+    return cache[key][1]
 
 
 def draw_noises(E, B, R, device):

@@ -3,6 +3,8 @@
 // (mapping MLP / style affine), toRGB + skip-branch upsample, layout conversion.
 // Reference math: model/stylegan2_generator.py (lines cited per kernel).
 #include "common.h"
+#include <vector>
+#include <string.h>
 #include "conv_params.h"
 
 // ------------------------------------------------------------------ weight packing
@@ -73,6 +75,40 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             if (n < Cin) v = upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap);
         }
         Elem<T>::st(out + idx, v * scale);
+    }
+}
+
+// Every packed weight copy of a module in ONE launch (the encoder re-packs ~35 weights after each optimizer step: 71 launches
+// of 3-9 us per training step).  One thread owns a (packed row n, k) pair and loops over the taps: for the forward layout the
+// k*k source values are one contiguous 36-byte run, and the writes of a wave are contiguous per tap.
+struct DgePackDesc {
+    const float* w; void* out;
+    int cout, cin, ks, ntot, mode, dtype, kdim;
+    float scale;
+    long long pair_start;                 // first (n, k) pair of this tensor in the launch's pair space
+};
+__device__ __forceinline__ float pack_gather(const float* __restrict__ w, int mode, int Cout, int Cin, int ntap, int n, int k, int tap) {
+    if (mode == 0) return n < Cout ? w[((size_t)n * Cin + k) * ntap + tap] : 0.f;
+    if (mode == 2) return n < Cin ? w[((size_t)k * Cin + n) * ntap + (ntap - 1 - tap)] : 0.f;
+    if (mode == 1) return n < 4 * Cout ? upfold_weight(w, n % Cout, k, Cin, n / Cout, tap) : 0.f;
+    if (mode == 4) return n < 4 * Cout ? sg1_up_weight(w, k, n % Cout, Cout, n / Cout, tap) : 0.f;
+    if (mode == 5) return n < Cin ? sg1_up_weight(w, n, k % Cout, Cout, k / Cout, 8 - tap) : 0.f;
+    return n < Cin ? upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap) : 0.f;
+}
+__global__ void pack_multi_kernel(const DgePackDesc* __restrict__ descs, int nd, long long total_pairs) {
+    for (long long pidx = (long long)blockIdx.x * blockDim.x + threadIdx.x; pidx < total_pairs; pidx += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nd - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].pair_start <= pidx) lo = mid; else hi = mid - 1; }
+        const DgePackDesc e = descs[lo];
+        const long long local = pidx - e.pair_start;
+        const int k = (int)(local % e.kdim), n = (int)(local / e.kdim);
+        const int ntap = e.ks * e.ks;
+        for (int tap = 0; tap < ntap; tap++) {
+            const float v = pack_gather(e.w, e.mode, e.cout, e.cin, ntap, n, k, tap) * e.scale;
+            const size_t o = ((size_t)tap * e.ntot + n) * e.kdim + k;
+            if (e.dtype == DGE_BF16) ((bf16_t*)e.out)[o] = f2bf(v);
+            else ((float*)e.out)[o] = v;
+        }
     }
 }
 
@@ -295,6 +331,44 @@ extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, in
     DGE_LAUNCH_CHECK("pack_conv_weight");
     return 0;
 }
+
+// `table`: device array of `n` rows of 8 x int64: {w, out, cout | cin << 32, ksize | mode << 32, dtype, scale (float bits), -, -};
+// the rows are validated on the host by the caller's wrapper (this entry cannot read device memory).  `descs`: device scratch of
+// n * sizeof(DgePackDesc) bytes the call fills from `table_host` when `upload` is set.
+extern "C" int dge_pack_conv_weights_multi(const long long* table_host, void* descs_dev, int n, int upload, hipStream_t s) {
+    DGE_CHECK(n > 0 && n <= 4096, "pack_multi: bad entry count %d", n);
+    static thread_local std::vector<DgePackDesc> host;
+    host.resize(n);
+    long long pairs = 0;
+    for (int i = 0; i < n; i++) {
+        const long long* r = table_host + (size_t)i * 8;
+        DgePackDesc& d = host[i];
+        d.w = (const float*)r[0]; d.out = (void*)r[1];
+        d.cout = (int)(r[2] & 0xffffffffLL); d.cin = (int)(r[2] >> 32);
+        d.ks = (int)(r[3] & 0xffffffffLL); d.mode = (int)(r[3] >> 32);
+        d.dtype = (int)r[4];
+        const unsigned bits = (unsigned)r[5]; memcpy(&d.scale, &bits, 4);
+        DGE_CHECK(d.mode >= 0 && d.mode <= 5, "pack_multi: bad mode %d", d.mode);
+        DGE_CHECK((d.mode != 1 && d.mode < 3) || d.ks == 3, "pack_multi: up fold needs a 3x3 kernel");
+        const int nvalid = (d.mode == 1 || d.mode == 4) ? 4 * d.cout : (d.mode >= 2 ? d.cin : d.cout);
+        d.ntot = dge_packed_n(nvalid);
+        d.kdim = d.mode == 2 ? d.cout : ((d.mode == 3 || d.mode == 5) ? 4 * d.cout : d.cin);
+        d.pair_start = pairs;
+        pairs += (long long)d.ntot * d.kdim;
+    }
+    // upload = 0: descs_dev still holds the descriptors of an earlier call with the same table (the steady state of a
+    // training loop: a pageable host -> device copy waits for the stream to drain, so it is paid once, not per step)
+    if (upload) {
+        hipError_t e = hipMemcpyAsync(descs_dev, host.data(), (size_t)n * sizeof(DgePackDesc), hipMemcpyHostToDevice, s);
+        DGE_CHECK(e == hipSuccess, "pack_multi: descriptor upload failed: %s", hipGetErrorString(e));
+    }
+    long long blocks = (pairs + 255) / 256;
+    const int grid = (int)(blocks > 8192 ? 8192 : blocks);
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(grid), dim3(256), 0, s, (const DgePackDesc*)descs_dev, n, pairs);
+    DGE_LAUNCH_CHECK("pack_conv_weights_multi");
+    return 0;
+}
+extern "C" int dge_pack_desc_bytes(void) { return (int)sizeof(DgePackDesc); }
 
 extern "C" int dge_packed_n(int nvalid) {
     const int t = dge_conv_ntile(nvalid);

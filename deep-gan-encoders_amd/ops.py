@@ -195,6 +195,33 @@ def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
     return out
 
 
+def pack_conv_weights_multi(entries, scratch=None):
+    """entries: [(w [Cout,Cin,k,k] f32, mode, dtype, scale, out)] with `out` the tensors pack_conv_weight returned for the same
+    arguments: refreshes all of them in ONE launch.  Returns the device scratch (pass it back to reuse it)."""
+    import struct
+    n = len(entries)
+    if n == 0:
+        return scratch
+    rows = []
+    for (w, mode, dtype, scale, out) in entries:
+        cout, cin, k, _ = w.shape
+        if mode in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):
+            cin, cout = cout, cin
+        if not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32):
+            raise DgeError("pack_conv_weights_multi: weights must be contiguous f32 device tensors")
+        rows += [w.data_ptr(), out.data_ptr(), cout | (cin << 32), k | (mode << 32), dtype,
+                 struct.unpack("<I", struct.pack("<f", float(scale)))[0], 0, 0]
+    tab = (C.c_longlong * (8 * n))(*rows)
+    need = n * lib().dge_pack_desc_bytes()
+    key = tuple(rows)
+    if scratch is None or scratch[0].numel() < need:
+        scratch = [torch.empty(max(need, 4096), dtype=torch.uint8, device=entries[0][0].device), None]
+    upload = 0 if scratch[1] == key else 1          # same table as the last call: the descriptors are already on the device
+    check(lib().dge_pack_conv_weights_multi(tab, _p(scratch[0]), n, upload, _stream()), "dge_pack_conv_weights_multi")
+    scratch[1] = key
+    return scratch
+
+
 def weight_sumsq(w, scale=1.0):
     cout, cin, k, _ = w.shape
     out = torch.empty((cout, cin), dtype=torch.float32, device=w.device)

@@ -102,6 +102,13 @@ int dge_demod_rows(const float* s_all, const float* wsq_cat, const int* row_woff
 int dge_packed_n(int n_valid);
 int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
                          float scale, dge_stream_t stream);
+/* All packed copies of a module's conv weights in one launch (the encoder's ~35 weights change at every optimizer step,
+ * model/utils/custom_adam.py:88-102, and each is needed in forward and data-gradient layout).  table_host: n rows of
+ * 8 x int64 on the HOST {w_oihw, out, cout | cin << 32, ksize | mode << 32, dtype, float bits of scale, 0, 0}; descs_dev:
+ * device scratch of n * dge_pack_desc_bytes() bytes, written when upload != 0 (upload = 0: it still holds the descriptors
+ * of an earlier call with the same table). */
+int dge_pack_conv_weights_multi(const long long* table_host, void* descs_dev, int n, int upload, dge_stream_t stream);
+int dge_pack_desc_bytes(void);
 /* wsq[o][i] = scale^2 * sum_taps W^2 : the demodulation norm of :867-870 for the shared-weight form */
 int dge_weight_sumsq(const float* w_oihw, float* wsq, int cout, int cin, int ksize, float scale, dge_stream_t stream);
 

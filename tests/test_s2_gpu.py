@@ -144,3 +144,28 @@ def test_synthesis_grad_wp_vs_reference_golden(cd):
     e = relerr(wp.grad, g["grad_wp"])
     print(f"MEAS grad_wp {cd} {e:.3e}")
     assert e < (1e-3 if cd == "f32" else 8e-2), e                # bf16 measured 3.8e-2
+
+
+def test_grouped_weight_pack_equals_the_single_tensor_pack():
+    """ops.pack_conv_weights_multi (one launch for all packed copies of a module) writes bit-identical bytes to
+    ops.pack_conv_weight for every layout (forward, data gradient, folded up layer and its adjoint, StyleGAN1 up / adjoint),
+    both storage types, 1x1 and 3x3, and refreshes in place when the source weights change."""
+    from dge_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    cases = [(24, 16, 3, ops.PACK_FWD, ops.BF16), (16, 24, 3, ops.PACK_DGRAD, ops.BF16), (64, 32, 1, ops.PACK_FWD, ops.BF16),
+             (32, 64, 1, ops.PACK_DGRAD, ops.F32), (16, 32, 3, ops.PACK_UPFOLD, ops.BF16), (16, 32, 3, ops.PACK_UPFOLD_DGRAD, ops.BF16),
+             (32, 16, 3, ops.PACK_SG1_UP, ops.BF16), (32, 16, 3, ops.PACK_SG1_UP_DGRAD, ops.F32), (512, 512, 3, ops.PACK_FWD, ops.BF16)]
+    ws = [torch.randn(co, ci, k, k, device="cuda", generator=g) for (co, ci, k, _, _) in cases]
+    singles = [ops.pack_conv_weight(w, m, dt, 0.7) for w, (_, _, _, m, dt) in zip(ws, cases)]
+    outs = [torch.full_like(s, float("nan")) if s.dtype == torch.float32 else torch.zeros_like(s) for s in singles]
+    entries = [(w, m, dt, 0.7, o) for w, (_, _, _, m, dt), o in zip(ws, cases, outs)]
+    scratch = ops.pack_conv_weights_multi(entries)
+    for a, b, c in zip(outs, singles, cases):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8)), c
+    # in-place refresh after an update of the sources (same table: the descriptors are not uploaded again)
+    for w in ws:
+        w.mul_(1.5)
+    scratch2 = ops.pack_conv_weights_multi(entries, scratch)
+    assert scratch2 is scratch
+    for w, a, (_, _, _, m, dt) in zip(ws, outs, cases):
+        assert torch.equal(a.view(torch.uint8), ops.pack_conv_weight(w, m, dt, 0.7).view(torch.uint8))
