@@ -654,6 +654,15 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64) || !(p.Cout == 16 || p.Cout == 32 || p.Cout == 64)) return false;
     if (p.W % 4 != 0 || p.W < 64 || p.H < 32) return false;
     if ((long)p.H * p.W < 128L * 128) return false;
+    {   // enough rows per wave to amortise the weight fold (and the shift table of the encoder flavours): measured break-even
+        // against conv_igemm (profiles/r02_conv_stream_*): data gradient always, generator >= 2^18 pixels, encoder >= 2^20
+        const long px = (long)p.B * p.H * p.W;
+        const bool enc = p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0);
+        if (!getenv("DGE_FORCE_STREAM")) {           // (tests run the kernel on small ragged shapes)
+            if (!p.dot_src && px < (enc ? (1L << 20) : (1L << 18))) return false;
+            if (p.dot_src && px < (1L << 16)) return false;
+        }
+    }
     if ((long)p.W * p.Cin * 2 >= (1L << 31) || (long)p.H * p.W * 64 * 2 >= (1L << 40)) return false;
     if (p.dot_src && !p.stats) return false;
     if (p.Cin == 64 && !p.dot_src && (p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0))) return false;
