@@ -52,6 +52,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst_unifor
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
+// the same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_saddr_u(unsigned voff, unsigned long long sbase, unsigned lds_dst_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst_uniform) : "memory");
+}
+
 struct UpParams {
     const void* x; const void* w; void* y;
     const float* in_scale; const float* out_scale; const float* noise; const float* noise_w; const float* bias;
@@ -156,13 +161,23 @@ __global__ __launch_bounds__(256, (UpCfg<T>::MINW)) void upconv_fir_kernel(UpPar
     // weight chunk kc of all 9 units -> LDS buffer `buf`: 18 pieces of 1 KiB (16 rows x 64 B), piece pc by wave pc % 4;
     // lane -> (row r = 16 pc + lane/4, source chunk c = lane%4 ^ swizzle(r)), destination lane-linear
     const unsigned ldsB_off = (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)ldsB;
+    // the per-lane part of the source address does not depend on the chunk: one 32-bit byte offset per piece, computed once;
+    // a chunk adds a scalar base, so a piece is one M0 write + one instruction (as in conv_igemm)
+    unsigned boffu[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int pc = wave + 4 * k;
+        const int r = pc * 16 + (lane >> 2);                     // q*32 + n
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        boffu[k] = (unsigned)((((size_t)(r >> 5) * p.Cout + bn0 + (r & 31)) * p.Cin + c * EP16) * sizeof(T));
+    }
     auto dma_b = [&](int kc, int buf) {
-        for (int pc = wave; pc < 18; pc += 4) {
-            const int r = pc * 16 + (lane >> 2);                 // q*32 + n
-            const int c = (lane & 3) ^ ((r >> 2) & 3);
-            const T* src = Wp + ((size_t)((r >> 5) * p.Cout + bn0 + (r & 31)) * p.Cin + kc * C::KC + c * EP16);
-            glds16(src, __builtin_amdgcn_readfirstlane(ldsB_off + buf * C::B_BYTES + pc * 1024));
-        }
+        const unsigned long long sb = (unsigned long long)Wp + (size_t)kc * C::KC * sizeof(T);
+        SFor<5>::run([&](auto kcst) {
+            constexpr int k = decltype(kcst)::value;
+            const int pc = wave + 4 * k;
+            if (pc < 18) glds16_saddr_u(boffu[k], sb, __builtin_amdgcn_readfirstlane(ldsB_off + buf * C::B_BYTES + pc * 1024));
+        });
     };
     const unsigned char* __restrict__ Xbc = (const unsigned char*)Xb;
 

@@ -1,3 +1,2 @@
-timeout 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -x 2>&1 | tail -3
-python tools/bench_embed.py 2>&1 | tail -1
-python bench.py --no-cpu-baseline --no-roofline --no-synthesis 2>&1 | tail -1 | cut -c1-900
+python tools/perf_s2.py 2>&1 | grep -E "synthesis|up=1"
+timeout 600 python -m pytest tests/test_upconv_gpu.py tests/test_s2_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x -k "up or synthesis" 2>&1 | tail -3
