@@ -2,6 +2,7 @@
 // conv weight gradient (MFMA, split over pixel tiles, f32 atomics), instance-norm / statistics
 // backward, activation backward with bias / noise-weight reductions, FromRGB and dense-layer
 // weight gradients.  The conv data gradients reuse conv_igemm (DGE_PACK_DGRAD).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/dge_hip.h"
 
@@ -649,7 +650,9 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     const int tx = (W + 15) / 16, ty = tall ? (H + 15) / 16 : (H + 7) / 8;
     const int ntiles = tx * ty * B;
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
-    int groups = 512 / noi; if (groups < 1) groups = 1; if (groups > ntiles) groups = ntiles;   // few, long-running workgroups: one atomic flush each
+    int groups = 512 / noi; if (groups < 1) groups = 1;
+    { const char* e = getenv("DGE_WGRAD_GROUPS"); if (e) groups = atoi(e); }                  // tuning override
+    if (groups > ntiles) groups = ntiles;   // few, long-running workgroups: one atomic flush each
     dim3 grid(noi, groups);
     if (dtype == DGE_BF16) dge_note_kernel("conv_wgrad_tr<%d,%d>", ksize, tall ? 16 : 8);
     else dge_note_kernel("conv_wgrad<f32,%d>", ksize);
