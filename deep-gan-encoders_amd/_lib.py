@@ -28,6 +28,8 @@ SIGNATURES = {
     "dge_conv2d": [C.POINTER(ConvDesc), _P],
     "dge_sum_slots": [_P, _P, _I, _I, _I, _P],
     "dge_sum_slots_planar": [_P, _P, _I, _I, _I, _P],
+    "dge_set_deterministic": [_I],
+    "dge_get_deterministic": [],
     "dge_packed_n": [_I],
     "dge_pack_conv_weight": [_P, _P, _I, _I, _I, _I, _I, _F, _P],
     "dge_pack_conv_weights_multi": [_P, _P, _I, _I, _P],

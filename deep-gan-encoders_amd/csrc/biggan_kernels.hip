@@ -284,6 +284,20 @@ __global__ __launch_bounds__(256) void sn_wtu_kernel(const SnEntry* __restrict__
     const SnEntry e = E[blockIdx.z];
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int o0 = blockIdx.y * 64;
+    if (det_on()) {
+        // deterministic mode: domain = (entry, k block), slot = row slab; every workgroup of the grid arrives (slabs beyond the
+        // entry's rows contribute zeros), the last one adds the ordered sum
+        const int dom = blockIdx.x + gridDim.x * blockIdx.z, nslots = gridDim.y;
+        float a = 0.f;
+        if (k < e.K && o0 < e.O) {
+            const int o1 = min(o0 + 64, e.O);
+            for (int o = o0; o < o1; o++) a += e.W[(size_t)o * e.K + k] * e.u[o];
+        }
+        float* slot = det_slot(dom, gridDim.x * gridDim.z, blockIdx.y, nslots, 256);
+        slot[threadIdx.x] = a;
+        if (det_arrive_wg(dom, nslots) && k < e.K) e.t[k] += det_sum(dom, nslots, 256, threadIdx.x);
+        return;
+    }
     if (k >= e.K || o0 >= e.O) return;
     const int o1 = min(o0 + 64, e.O);
     float a = 0.f;

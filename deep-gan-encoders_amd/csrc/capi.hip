@@ -17,6 +17,29 @@ void dge_note_kernel(const char* fmt, ...) {
 extern "C" const char* dge_last_kernel(void) { return g_kernel; }
 extern "C" int dge_version(void) { return 100; }
 
+// ---- deterministic mode: the per-translation-unit copies of the device-side state are updated through their registered setters
+#include <vector>
+static std::vector<void (*)(const DgeDet*)>& det_setters() { static std::vector<void (*)(const DgeDet*)> v; return v; }
+void dge_det_register(void (*setter)(const DgeDet*)) { det_setters().push_back(setter); }
+static DgeDet g_det_host = {0, nullptr, nullptr, 0, 0};
+extern "C" int dge_set_deterministic(int on) {
+    if (on && !g_det_host.ws) {
+        const long long nf = 32LL << 20;                 // 32 Mi floats = 128 MiB (largest need measured: 4.7 Mi, the weight-gradient slabs)
+        const int nc = 1 << 16;
+        float* ws = nullptr; unsigned* ct = nullptr;
+        DGE_CHECK(hipMalloc((void**)&ws, (size_t)nf * 4) == hipSuccess, "set_deterministic: workspace allocation failed");
+        DGE_CHECK(hipMalloc((void**)&ct, (size_t)nc * 4) == hipSuccess, "set_deterministic: counter allocation failed");
+        DGE_CHECK(hipMemset(ct, 0, (size_t)nc * 4) == hipSuccess, "set_deterministic: counter reset failed");
+        g_det_host.ws = ws; g_det_host.counters = ct; g_det_host.ws_floats = nf; g_det_host.ncounters = nc;
+    }
+    g_det_host.enabled = on ? 1 : 0;
+    DGE_CHECK(hipDeviceSynchronize() == hipSuccess, "set_deterministic: device synchronisation failed");   // no launch straddles the switch
+    for (auto f : det_setters()) f(&g_det_host);
+    DGE_CHECK(hipDeviceSynchronize() == hipSuccess, "set_deterministic: state upload failed");
+    return 0;
+}
+extern "C" int dge_get_deterministic(void) { return g_det_host.enabled; }
+
 extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(d && d->x && d->w_packed && d->y, "conv2d: null tensor");
     DGE_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: bad shape");

@@ -78,6 +78,86 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// ------------------------------------------------------------------ deterministic mode (dge_set_deterministic)
+// Reductions that end in same-address f32 atomics are order dependent run to run (the reference pins
+// torch.backends.cudnn.deterministic = True, training_utils.py:51).  In deterministic mode every such reduction goes through a
+// library-owned workspace instead: each contributor stores its partial vector in ITS slot (plain stores), takes a ticket, and
+// the LAST contributor of the domain sums the slots in slot order and hands the totals on.  No contributor ever waits for
+// another one (no assumption on dispatch order); cross-CU visibility follows the release -> ticket -> acquire recipe.
+// One copy of the state per translation unit (no relocatable device code); capi.hip updates all of them.
+struct DgeDet {
+    int enabled;
+    float* ws;                 // [domain][slot][L] partial vectors of the running launch
+    unsigned* counters;        // one arrival counter per domain, zero between launches (reset by the last arriver)
+    long long ws_floats;
+    int ncounters;
+};
+static __device__ DgeDet g_det = {0, nullptr, nullptr, 0, 0};
+void dge_det_register(void (*setter)(const DgeDet*));
+static void dge_det_set_this_tu(const DgeDet* v) {
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_det), v, sizeof(DgeDet), 0, hipMemcpyHostToDevice);
+}
+namespace { struct DgeDetReg { DgeDetReg() { dge_det_register(&dge_det_set_this_tu); } }; static DgeDetReg dge_det_reg_instance; }
+
+__device__ __forceinline__ bool det_on() { return g_det.enabled != 0; }
+__device__ __forceinline__ float* det_slot(int domain, int ndomains, int slot, int nslots, int L) {
+    if ((long long)ndomains * nslots * L > g_det.ws_floats || ndomains > g_det.ncounters) __builtin_trap();   // loud: the launch aborts
+    return g_det.ws + ((size_t)domain * nslots + slot) * L;
+}
+// Workgroup-level close of a domain: call after EVERY thread of the workgroup has stored its part of the slot.  Returns true
+// (to all threads) in the last workgroup to arrive, after which it may read all `nslots` slots of the domain.
+// `arrivals` = number of det_arrive_wg calls per domain.
+__device__ __forceinline__ bool det_arrive_wg(int domain, int arrivals) {
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = atomicAdd(&g_det.counters[domain], 1u);
+        const int last = (t == (unsigned)(arrivals - 1));
+        if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); g_det.counters[domain] = 0u; }
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+// the same for a single wave (no workgroup barrier: the wave's own stores precede its fence in program order)
+__device__ __forceinline__ bool det_arrive_wave(int domain, int arrivals) {
+    int last = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned t = atomicAdd(&g_det.counters[domain], 1u);
+        last = (t == (unsigned)(arrivals - 1));
+        if (last) g_det.counters[domain] = 0u;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last != 0;
+}
+// ordered sum of element idx over the slots of a domain
+__device__ __forceinline__ float det_sum(int domain, int nslots, int L, int idx) {
+    const float* base = g_det.ws + (size_t)domain * nslots * L + idx;
+    float s = 0.f;
+    for (int k = 0; k < nslots; k++) s += base[(size_t)k * L];
+    return s;
+}
+
+// block-parallel ordered total of element idx over the slots of a domain (fixed combination order: thread-strided partial
+// sums, xor butterfly inside a wave, waves in index order): every thread of the workgroup calls; `red` holds >= 16 floats
+__device__ __forceinline__ float det_total_wg(int domain, int nslots, int L, int idx, float* red) {
+    const float* base = g_det.ws + (size_t)domain * nslots * L + idx;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nslots; k += blockDim.x) s += base[(size_t)k * L];
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += red[w];
+    return t;
+}
+
 // Per-channel block reduction for NHWC streaming kernels.  Thread t owns channel chunk (t % cpt)
 // (EP channels) of pixel slot (t / cpt); each thread holds NS partial sums per channel.  The
 // sums of all pixel slots are combined in LDS and added atomically to out[c*NS + k].
@@ -91,6 +171,26 @@ __device__ __forceinline__ void block_chan_flush(float (&s)[NS][EP], int cpt, in
 #pragma unroll
         for (int e = 0; e < EP; e++) red[tid * NS * EP + k * EP + e] = s[k][e];
     __syncthreads();
+    if (det_on()) {
+        // domain = the workgroups that share out_b (same blockIdx.y / z), slot = blockIdx.x
+        const int L = cpt * NS * EP, nslots = gridDim.x, ndom = gridDim.y * gridDim.z, dom = blockIdx.y + gridDim.y * blockIdx.z;
+        float* slot = det_slot(dom, ndom, blockIdx.x, nslots, L);
+        for (int item = tid; item < L; item += 256) {
+            const int ch = item / (NS * EP), r = item % (NS * EP);
+            float a = 0.f;
+            for (int j = 0; j < ppi; j++) a += red[(j * cpt + ch) * NS * EP + r];
+            slot[item] = a;
+        }
+        if (det_arrive_wg(dom, nslots)) {
+            for (int item = tid; item < L; item += 256) {
+                const int ch = item / (NS * EP), r = item % (NS * EP);
+                const int c = ch * EP + (r % EP);
+                if (c < C) out_b[(size_t)c * NS + (r / EP)] += det_sum(dom, nslots, L, item);      // single writer
+            }
+        }
+        __syncthreads();
+        return;
+    }
     for (int item = tid; item < cpt * NS * EP; item += 256) {
         const int ch = item / (NS * EP), r = item % (NS * EP);
         float a = 0.f;

@@ -377,6 +377,11 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     // In DOT mode (data gradients) the per-channel scale is applied post, on the staged raw value.
     const bool post_stats = p.stats && (DOT || ADD);
     float* __restrict__ STATS = p.stats ? p.stats + (size_t)(vbid % p.stats_slots) * p.B * p.Cout * 2 : nullptr;
+    // deterministic mode: domain = (sample, N tile), slot = (pixel tile, wave row wm), vector = (sum, sum2) per channel of the N tile;
+    // the last workgroup of the domain sums the slots in order into copy 0 of the statistics buffer (the other copies stay zero)
+    const bool det = p.stats && !p.up && det_on();
+    const int det_ntn = (p.Ntot + BN - 1) / BN, det_dom = b * det_ntn + ntile, det_nslots = p.tiles_x * p.tiles_y * WM;
+    float* det_vec = det ? det_slot(det_dom, p.B * det_ntn, (ty_i * p.tiles_x + tx_i) * WM + wm, det_nslots, BN * 2) : nullptr;
     // activation as max(v, slope*v) (slope in [0,1]); the gain (> 0, checked by the launcher) is folded
     // into scale / noise weight / bias because every supported activation is positively homogeneous
     const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
@@ -489,8 +494,13 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
             ssum += __shfl_xor(ssum, 32, 64);
             ssq += __shfl_xor(ssq, 32, 64);
             if (lane < 32 && ovalid) {
-                atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2, ssum);
-                atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
+                if (det) {                 // this wave's slot of the (sample, N tile) domain: one entry pair per channel of the tile
+                    const int e = (wn * C::WTN + j * 32 + l31) * 2;
+                    det_vec[e] = ssum; det_vec[e + 1] = ssq;
+                } else {
+                    atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2, ssum);
+                    atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
+                }
             }
         }
         if (post_stats) {          // lanes with equal chq hold partial sums of the same channels
@@ -499,12 +509,25 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
 #pragma unroll
                 for (int msk = CPR; msk < 64; msk <<= 1) { ps0[e] += __shfl_xor(ps0[e], msk, 64); ps1[e] += __shfl_xor(ps1[e], msk, 64); }
                 if (lane < CPR && cvalid) {
-                    atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2, ps0[e]);
-                    atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2 + 1, ps1[e]);
+                    if (det) {
+                        const int ee = (wn * C::WTN + j * 32 + chq * EP16 + e) * 2;
+                        det_vec[ee] = ps0[e]; det_vec[ee + 1] = ps1[e];
+                    } else {
+                        atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2, ps0[e]);
+                        atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2 + 1, ps1[e]);
+                    }
                 }
             }
         }
     });
+    if (det) {
+        if (det_arrive_wg(det_dom, p.tiles_x * p.tiles_y)) {
+            for (int idx = tid; idx < BN * 2; idx += 256) {
+                const int o = bn0 + (idx >> 1);
+                if (o < p.Cout) p.stats[((size_t)b * p.Cout + o) * 2 + (idx & 1)] = det_sum(det_dom, det_nslots, BN * 2, idx);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------- dispatch

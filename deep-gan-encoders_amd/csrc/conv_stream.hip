@@ -581,6 +581,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 #pragma unroll
                 for (int r = 0; r < 16; r++) { if (!pv) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; } }
             float* __restrict__ ST = p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2;
+            // deterministic mode: domain = sample, slot = (segment, strip), the team's waves fill disjoint channel ranges of it
+            const bool det = det_on();
+            float* dvec = det ? det_slot(b, p.B, seg * nstrips + strip, nseg * nstrips, COUT * 2) : nullptr;
 #pragma unroll
             for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
@@ -590,10 +593,15 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                     for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m, 64); c += __shfl_xor(c, m, 64); }
                     if (n31 == 0) {
                         const int ch = wave * C::MTW * 32 + chan_of_reg(mt, r);
-                        atomicAdd(ST + ch * 2, a);
-                        atomicAdd(ST + ch * 2 + 1, c);
+                        if (det) { dvec[ch * 2] = a; dvec[ch * 2 + 1] = c; }
+                        else { atomicAdd(ST + ch * 2, a); atomicAdd(ST + ch * 2 + 1, c); }
                     }
                 }
+            if (det && det_arrive_wave(b, nseg * nstrips * C::TEAM)) {
+                // last wave of the sample: ordered sum of all slots into copy 0 of the statistics buffer
+                for (int idx = lane; idx < COUT * 2; idx += 64)
+                    p.stats[(size_t)b * COUT * 2 + idx] = det_sum(b, nseg * nstrips, COUT * 2, idx);
+            }
         }
     }
 }

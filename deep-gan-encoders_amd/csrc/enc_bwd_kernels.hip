@@ -41,6 +41,20 @@ __device__ __forceinline__ void wgrad_flush(const f32x16_t (&acc)[NTAP], float* 
     }
     __syncthreads();
     const int ni = (Ci - i0 < 32 ? Ci - i0 : 32) * NTAP;  // valid floats of one o row of this tile (contiguous in dW)
+    if (det_on()) {
+        // deterministic mode: domain = the (o, i) tile (blockIdx.x), slot = the pixel-tile group (blockIdx.y); the last group to
+        // arrive adds the ordered sum of all groups to dW (single writer: dW may already hold the other phase's gradient)
+        const int L = 1024 * NTAP, nslots = gridDim.y;
+        float* slot = det_slot(blockIdx.x, gridDim.x, blockIdx.y, nslots, L);
+        for (int idx = tid; idx < L; idx += 256) slot[idx] = stage[idx];
+        if (det_arrive_wg(blockIdx.x, nslots)) {
+            for (int idx = tid; idx < L; idx += 256) {
+                const int ol = idx / (32 * NTAP), j = idx - ol * (32 * NTAP);
+                if (o0 + ol < Co && j < ni) dW[((size_t)(o0 + ol) * Ci + i0) * NTAP + j] += det_sum(blockIdx.x, nslots, L, idx);
+            }
+        }
+        return;
+    }
     for (int idx = tid; idx < 1024 * NTAP; idx += 256) {
         const int ol = idx / (32 * NTAP), j = idx - ol * (32 * NTAP);
         if (o0 + ol < Co && j < ni) atomicAdd(dW + ((size_t)(o0 + ol) * Ci + i0) * NTAP + j, stage[idx]);

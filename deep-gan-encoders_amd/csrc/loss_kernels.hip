@@ -15,6 +15,19 @@ __device__ __forceinline__ void block_atomic_sums(float* vals, int n, float* out
         if (lane == 0) red[i * 4 + wave] = s;
     }
     __syncthreads();
+    if (det_on()) {            // deterministic mode: one slot of 8 sums per workgroup, ordered total into copy 0 by the last arriver
+        const int nslots = gridDim.x;
+        float* slot = det_slot(0, 1, blockIdx.x, nslots, 8);
+        if (threadIdx.x < n) slot[threadIdx.x] = red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3];
+        if (det_arrive_wg(0, nslots)) {
+            __shared__ float dred[16];
+            for (int i = 0; i < n; i++) {
+                const float t = det_total_wg(0, nslots, 8, i, dred);
+                if (threadIdx.x == 0) out[i] += t;
+            }
+        }
+        return;
+    }
     // 16 slot copies of the 8 sums: thousands of workgroups end here and same-address f32 atomics serialise (~40 ns each)
     if (threadIdx.x < n) atomicAdd(out + (blockIdx.x & 15) * 8 + threadIdx.x, red[threadIdx.x * 4] + red[threadIdx.x * 4 + 1] + red[threadIdx.x * 4 + 2] + red[threadIdx.x * 4 + 3]);
 }
@@ -106,6 +119,18 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
     S = wave_sum(S);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = S;
     __syncthreads();
+    if (det_on()) {            // deterministic mode: one slot per workgroup, ordered total into copy 0
+        const int nslots = gridDim.x * gridDim.y * gridDim.z;
+        const int sl = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        float* slot = det_slot(0, 1, sl, nslots, 1);
+        if (threadIdx.x == 0) slot[0] = red[0] + red[1] + red[2] + red[3];
+        if (det_arrive_wg(0, nslots)) {
+            __shared__ float dred[16];
+            const float t = det_total_wg(0, nslots, 1, 0, dred);
+            if (threadIdx.x == 0) ssim_sum[0] += t;
+        }
+        return;
+    }
     // 32 slot copies (same-address f32 atomics serialise; thousands of workgroups end here), summed by the finaliser
     if (threadIdx.x == 0) atomicAdd(ssim_sum + ((blockIdx.x + blockIdx.y * 7 + blockIdx.z * 13) & 31), red[0] + red[1] + red[2] + red[3]);
 }
@@ -253,6 +278,17 @@ __global__ __launch_bounds__(256) void ssim_box7_kernel(const float* __restrict_
     S = wave_sum(S);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = S;
     __syncthreads();
+    if (det_on()) {            // deterministic mode: domain = plane bc, one slot per tile
+        const int nslots = gridDim.x * gridDim.y, sl = blockIdx.x + gridDim.x * blockIdx.y;
+        float* slot = det_slot(bc, gridDim.z, sl, nslots, 1);
+        if (threadIdx.x == 0) slot[0] = red[0] + red[1] + red[2] + red[3];
+        if (det_arrive_wg(bc, nslots)) {
+            __shared__ float dred[16];
+            const float t = det_total_wg(bc, nslots, 1, 0, dred);
+            if (threadIdx.x == 0) sums[bc] += t;
+        }
+        return;
+    }
     if (threadIdx.x == 0) atomicAdd(sums + bc, red[0] + red[1] + red[2] + red[3]);
 }
 

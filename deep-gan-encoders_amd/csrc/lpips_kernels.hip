@@ -163,6 +163,17 @@ __global__ __launch_bounds__(256) void lpips_head_kernel(const T* __restrict__ f
     __shared__ float wred[4];                             // one atomic per workgroup (same-address atomics serialise)
     if (lane == 0) wred[threadIdx.x >> 6] = dacc;
     __syncthreads();
+    if (det_on()) {            // deterministic mode: domain = sample, one slot per workgroup
+        const int nslots = gridDim.x;
+        float* slot = det_slot(b, gridDim.y, blockIdx.x, nslots, 1);
+        if (threadIdx.x == 0) slot[0] = ((wred[0] + wred[1]) + (wred[2] + wred[3])) * inv_hw;
+        if (det_arrive_wg(b, nslots)) {
+            __shared__ float dred[16];
+            const float t = det_total_wg(b, nslots, 1, 0, dred);
+            if (threadIdx.x == 0) val[b] += t;
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         const float t = (wred[0] + wred[1]) + (wred[2] + wred[3]);
         if (t != 0.f) atomicAdd(val + b, t * inv_hw);

@@ -510,6 +510,9 @@ def add_model_args(parser):
 
 def train(tensor_writer=None, args=None):
     """Reference E_align_s2.train() (flags: E_align_s2.py:304-318)."""
+    if getattr(args, "deterministic", False):
+        from . import ops
+        ops.set_deterministic(True)
     G, Gm, E, LP = load_models(args)
     load_lpips_weights(LP, getattr(args, "vgg_weights", None), getattr(args, "lpips_weights", None),
                        allow_standin=getattr(args, "allow_standin_lpips", False))
@@ -537,6 +540,7 @@ def main(argv=None):
     parser.add_argument("--stage", type=int, default=2, help="2: E_align_s2.py; 1: E_align_cropping_s1.py (latent phase only trains E)")
     parser.add_argument("--vgg_weights", default=None, help="torchvision vgg16 checkpoint (features.*) or an lpips.LPIPS state_dict")
     parser.add_argument("--lpips_weights", default=None, help="the lpips package's weights/v0.1/vgg.pth (lin{k}.model.1.weight)")
+    parser.add_argument("--deterministic", action="store_true", help="bit-reproducible reductions (training_utils.py:51 cudnn.deterministic): ops.set_deterministic")
     parser.add_argument("--allow_standin_lpips", action="store_true", help="train on seeded stand-in LPIPS weights (NOT the reference objective)")
     return train(None, parser.parse_args(argv))
 

@@ -195,6 +195,18 @@ def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
     return out
 
 
+def set_deterministic(on=True):
+    """Deterministic mode of the library (the reference pins torch.backends.cudnn.deterministic = True, training_utils.py:51):
+    every reduction that ends in same-address f32 atomics - conv statistics, weight-gradient flush, the per-channel sums of
+    the streaming backward kernels, loss sums - goes through per-contributor slots and an ordered sum by the last contributor
+    instead (csrc/common.h).  Run to run the results are then bit-identical.  Synchronises the device."""
+    check(lib().dge_set_deterministic(1 if on else 0), "dge_set_deterministic")
+
+
+def is_deterministic():
+    return bool(lib().dge_get_deterministic())
+
+
 def pack_conv_weights_multi(entries, scratch=None):
     """entries: [(w [Cout,Cin,k,k] f32, mode, dtype, scale, out)] with `out` the tensors pack_conv_weight returned for the same
     arguments: refreshes all of them in ONE launch.  Returns the device scratch (pass it back to reuse it)."""

@@ -99,6 +99,11 @@ int dge_linear_rows(const float* x, int ldx_b, const int* row_xoff, const float*
  * row wsq_cat[row_woff[r] ..) of dge_weight_sumsq values. */
 int dge_demod_rows(const float* s_all, const float* wsq_cat, const int* row_woff, const int* row_sbase, const int* row_cin,
                    float* d_all, const int* row_dbase, const int* row_dbstride, int B, int R, float eps, dge_stream_t stream);
+/* Deterministic mode (the reference pins torch.backends.cudnn.deterministic = True, training_utils.py:51): every reduction that
+ * ends in same-address f32 atomics (conv statistics, weight-gradient flush, per-channel sums of the streaming backward kernels,
+ * loss sums) goes through per-contributor slots and an ordered sum by the last contributor instead.  Synchronises the device. */
+int dge_set_deterministic(int on);
+int dge_get_deterministic(void);
 int dge_packed_n(int n_valid);
 int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
                          float scale, dge_stream_t stream);

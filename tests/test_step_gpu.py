@@ -421,3 +421,51 @@ def test_two_phase_step_biggan_matches_reference_run():
                         assert ((du - du_ref).norm() / du_ref.norm()).item() < 0.08, (it, k)
         cs = R.checksum({k: v.cpu() for k, v in sd_e.items() if v.dtype.is_floating_point})
         assert abs(cs - float(g[f"it{it}_param_checksum"])) < 1e-5 * float(g[f"it{it}_param_checksum"])
+
+
+def _fresh_step(cd):
+    import dge_amd
+    from dge_amd.encoder import BE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.e_align import EAlignStep
+    G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype=cd).cuda()
+    G.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+    G.train()
+    for p in G.parameters():
+        p.requires_grad_(False)
+    E = BE(startf=16, maxf=64, layer_count=5, compute_dtype=cd).cuda()
+    E.load_state_dict(R.fill_encoder(enc_shapes(16, 64, 5), seed=31))
+    LP = LPIPS(compute_dtype=cd).cuda()
+    LP.load_state_dict(LR.seeded_params(0))
+    return EAlignStep(G, E, LP, lr=0.0015, batch_size=4), E
+
+
+@pytest.mark.parametrize("cd", ["bf16", "f32"])
+def test_deterministic_mode_makes_the_step_bit_reproducible(cd):
+    """ops.set_deterministic(True) (the reference pins cudnn.deterministic, training_utils.py:51): two runs of three complete
+    two-phase iterations from the same state end in BIT-IDENTICAL encoder parameters and losses; the default (atomic) mode
+    agrees with them to the usual summation-order bound."""
+    from dge_amd import ops
+
+    def run():
+        st, E = _fresh_step(cd)
+        out = []
+        for it in range(3):
+            r = st.step(it)
+            out.append((float(r["loss_tsa"]), float(r["loss_w"])))
+        torch.cuda.synchronize()
+        return out, {k: v.detach().clone() for k, v in E.state_dict().items()}
+
+    ops.set_deterministic(True)
+    try:
+        assert ops.is_deterministic()
+        l1, p1 = run()
+        l2, p2 = run()
+    finally:
+        ops.set_deterministic(False)
+    assert l1 == l2, (l1, l2)
+    for k in p1:
+        assert torch.equal(p1[k], p2[k]), k
+    l3, p3 = run()                                   # default mode: same numbers up to the order of f32 atomics
+    for a, b in zip(l1, l3):
+        assert abs(a[0] - b[0]) < (1e-4 if cd == "f32" else 2e-2) * abs(a[0]) and abs(a[1] - b[1]) < (1e-4 if cd == "f32" else 2e-2) * abs(a[1])
