@@ -1,1 +1,2 @@
-for cfg in "8 128 128 128 3" "8 256 256 64 3" "8 256 512 64 3" "8 512 512 32 3" "8 512 512 16 3" "8 512 512 8 3"; do for gr in 0 1 2 4 16; do if [ $gr = 0 ]; then unset DGE_WGRAD_GROUPS; else export DGE_WGRAD_GROUPS=$gr; fi; echo -n "groups=$gr "; python tools/perf_wgrad.py $cfg 2>&1 | grep wgrad; done; done
+for v in "" ep2; do echo "== ${v:-base}"; if [ -n "$v" ]; then export DGE_LIB_PATH=deep-gan-encoders_amd/variants/libdge_$v.so; else unset DGE_LIB_PATH; fi
+for cfg in "8 128 128 256 3" "8 256 256 128 3" "8 512 512 64 3" "8 512 512 32 3"; do python tools/perf_conv.py $cfg 2>&1 | grep DBG; done; done
