@@ -11,11 +11,11 @@ torch.manual_seed(0)
 G = dge_amd.StyleGAN2Generator(1024, compute_dtype=cd).cuda().eval()
 wp = torch.randn(B, 18, 512, device="cuda")
 with torch.no_grad():
-    for _ in range(3):
+    for _ in range(int(os.environ.get("WARM", "3"))):
         G.synthesis(wp)
     torch.cuda.synchronize()
     t0 = time.time()
-    N = 10
+    N = int(os.environ.get("NIT", "10"))
     for _ in range(N):
         G.synthesis(wp)
     torch.cuda.synchronize()
