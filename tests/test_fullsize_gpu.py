@@ -380,6 +380,19 @@ RAGGED = [
     (2, 100, 172, 32, 32, "enc_stats"),
     (1, 257, 68, 32, 16, "dot"),
     (2, 64, 256, 16, 16, "g"),
+    # every channel pair the kernel is built for, in the flavour(s) that reach it, on shapes that end inside strips / ring periods
+    (1, 137, 132, 16, 64, "g"),           # 2-wave team (Cout = 64), H not a multiple of the ring period, 4 px in the last strip
+    (2, 149, 132, 32, 64, "enc"),
+    (1, 133, 132, 64, 64, "g"),           # Cin = 64: five DMA pieces per row, split over the team
+    (2, 141, 128, 64, 32, "relu"),
+    (1, 135, 160, 64, 16, "g"),
+    (2, 167, 136, 64, 64, "dot"),
+    (1, 131, 128, 64, 32, "dot"),
+    (2, 145, 164, 16, 16, "dot"),
+    (1, 139, 132, 32, 32, "dot"),
+    (2, 152, 144, 16, 16, "enc_stats"),
+    (1, 128, 128, 32, 16, "relu"),        # smallest eligible image
+    (3, 161, 200, 16, 32, "enc_stats"),
 ]
 
 
