@@ -132,6 +132,11 @@ def lib():
         for name in ("dge_last_error", "dge_last_kernel"):
             getattr(_lib, name).restype = C.c_char_p
             getattr(_lib, name).argtypes = []
+        # DGE_DETERMINISTIC=1: deterministic mode from the first launch on (same as ops.set_deterministic(True); needs a device)
+        if os.environ.get("DGE_DETERMINISTIC") == "1":
+            import torch
+            if torch.cuda.is_available() and _lib.dge_set_deterministic(1) != 0:
+                raise DgeError("DGE_DETERMINISTIC=1: " + _lib.dge_last_error().decode())
     return _lib
 
 
