@@ -2,6 +2,7 @@
 // transposed-conv + FIR up layer), sum-of-squares for demodulation, small dense layers
 // (mapping MLP / style affine), toRGB + skip-branch upsample, layout conversion.
 // Reference math: model/stylegan2_generator.py (lines cited per kernel).
+#include <stdlib.h>
 #include "common.h"
 #include <vector>
 #include <string.h>
@@ -256,6 +257,62 @@ __global__ void torgb_kernel(const T* __restrict__ x, const float* __restrict__ 
     }
 }
 
+// The same layer for the low resolutions (4^2 .. 64^2, Cin = 512): one WAVE per pixel - the lanes split the channels (one
+// 16-byte load each per 64*EP16 channels), three wave reductions - instead of one thread walking all 512 channels of its pixel
+// (a 4^2 image gave 16 busy threads per sample and ~30 us of pure latency per launch; six such launches per synthesis pass).
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void torgb_wave_kernel(const T* __restrict__ x, const float* __restrict__ wrgb, const float* __restrict__ s,
+                                                         const float* __restrict__ bias, const float* __restrict__ prev, float* __restrict__ img,
+                                                         int B, int H, int W, int Cin, float wscale) {
+    constexpr int EP16 = Elem<T>::PER16;
+    const int lane = threadIdx.x & 63;
+    const int HW = H * W;
+    const long gp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // global pixel = b * HW + pix (wave-uniform)
+    if (gp >= (long)B * HW) return;
+    const int b = (int)(gp / HW), pix = (int)(gp - (long)b * HW);
+    const T* xp = x + (size_t)gp * Cin;
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = 0.f;
+    for (int i = lane * EP16; i < Cin; i += 64 * EP16) {
+        float f[EP16], sv[EP16];
+        unpack16(*(const uint4*)(xp + i), f, (T*)nullptr);
+#pragma unroll
+        for (int e4 = 0; e4 < EP16 / 4; e4++) *(float4*)&sv[e4 * 4] = *(const float4*)(s + (size_t)b * Cin + i + e4 * 4);
+#pragma unroll
+        for (int e = 0; e < EP16; e++) f[e] *= sv[e];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            float wv[EP16];
+#pragma unroll
+            for (int e4 = 0; e4 < EP16 / 4; e4++) *(float4*)&wv[e4 * 4] = *(const float4*)(wrgb + (size_t)c * Cin + i + e4 * 4);
+#pragma unroll
+            for (int e = 0; e < EP16; e++) acc[c] = fmaf(f[e], wv[e], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = wave_sum(acc[c]) * wscale;
+    if (lane < NC) {
+        const int c = lane;
+        float v = bias[c];
+#pragma unroll
+        for (int k = 0; k < NC; k++) v += (k == c) ? acc[k] : 0.f;
+        if (prev) {
+            const int y = pix / W, xx = pix % W;
+            const int h2 = H >> 1, w2 = W >> 1;
+            const float* pp = prev + ((size_t)b * NC + c) * h2 * w2;
+            const int my = y >> 1, mx = xx >> 1;
+            const int ya = (y & 1) ? my : my - 1, yb = (y & 1) ? my + 1 : my;
+            const int xa = (xx & 1) ? mx : mx - 1, xb = (xx & 1) ? mx + 1 : mx;
+            const float wya = (y & 1) ? 0.75f : 0.25f, wyb = 1.f - wya;
+            const float wxa = (xx & 1) ? 0.75f : 0.25f, wxb = 1.f - wxa;
+            auto at = [&](int yy, int xq) { return (yy >= 0 && yy < h2 && xq >= 0 && xq < w2) ? pp[yy * w2 + xq] : 0.f; };
+            v += wya * (wxa * at(ya, xa) + wxb * at(ya, xb)) + wyb * (wxa * at(yb, xa) + wxb * at(yb, xb));
+        }
+        img[((size_t)b * NC + c) * HW + pix] = v;
+    }
+}
+
 // ------------------------------------------------------------------ layout conversion
 // NCHW f32 (batch-broadcast when src_B == 1) -> NHWC T
 template <typename T>
@@ -413,6 +470,16 @@ extern "C" int dge_torgb(const void* x, const float* wrgb, const float* style, c
     const int esz = dtype == DGE_BF16 ? 2 : 4;
     DGE_CHECK(cin % (16 / esz) == 0, "torgb: Cin=%d not a multiple of %d", cin, 16 / esz);
     const int hw = H * W;
+    if (cin >= 256 && cin % (64 * (16 / esz)) == 0 && (long)B * hw <= (1L << 16) && !getenv("DGE_TORGB_THREAD")) {
+        // low resolutions: one wave per pixel (the channels are the only parallelism a 4^2 .. 64^2 image offers)
+        const unsigned nblk = (unsigned)(((long)B * hw + 3) / 4);
+        if (dtype == DGE_BF16)
+            hipLaunchKernelGGL((torgb_wave_kernel<bf16_t, 3>), dim3(nblk), dim3(256), 0, s, (const bf16_t*)x, wrgb, style, bias, prev, img, B, H, W, cin, wscale);
+        else
+            hipLaunchKernelGGL((torgb_wave_kernel<float, 3>), dim3(nblk), dim3(256), 0, s, (const float*)x, wrgb, style, bias, prev, img, B, H, W, cin, wscale);
+        DGE_LAUNCH_CHECK("torgb");
+        return 0;
+    }
     int gx = (hw + 255) / 256; if (gx > 2048) gx = 2048;
     const size_t shm = (size_t)3 * cin * sizeof(float);
     if (dtype == DGE_BF16)
