@@ -18,7 +18,7 @@ class ConvDesc(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
         ("ksize", C.c_int), ("up", C.c_int), ("in_s2d", C.c_int), ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int),
         ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float), ("add_scale", C.c_float),
-        ("dtype", C.c_int), ("in_up2", C.c_int), ("in_relu", C.c_int), ("stats_slots", C.c_int),
+        ("dtype", C.c_int), ("in_up2", C.c_int), ("in_relu", C.c_int), ("stats_slots", C.c_int), ("w_layout", C.c_int),
     ]
 
 
@@ -26,6 +26,7 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes; every symbol declared in include/dge_hip.h must be listed here
 SIGNATURES = {
     "dge_conv2d": [C.POINTER(ConvDesc), _P],
+    "dge_conv_small_supported": [_I, _I, _I, _I, _I, _I, _I, _I],
     "dge_sum_slots": [_P, _P, _I, _I, _I, _P],
     "dge_sum_slots_planar": [_P, _P, _I, _I, _I, _P],
     "dge_set_deterministic": [_I],

@@ -10,11 +10,14 @@ def _ver(w):
     return (w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
 
 
-def _packed(cache, conv, dtype, mode):
+def _packed(cache, conv, dtype, mode, hw=None):
     """Packed copy of a conv weight, rebuilt when the parameter was updated in place.  An optimizer step makes EVERY copy of
     the module stale at once: the first stale hit refreshes all of them in one launch (ops.pack_conv_weights_multi) - in
-    place, the consumers of the old values are earlier on the same stream."""
+    place, the consumers of the old values are earlier on the same stream.  `hw`: resolution the conv runs at (the
+    low-resolution blocks keep their copies in fragment order for csrc/conv_small.hip)."""
     w = conv.weight
+    if hw is not None:
+        mode = ops.pack_mode_for(w, mode, hw, hw, dtype)
     key = (id(w), mode, dtype)
     ver = _ver(w)
     hit = cache.get(key)
@@ -110,7 +113,7 @@ def encoder_forward(E, img, noises=None, save=False):
         w1 = ops.linear(musig1, blk.inver_mod1.weight.detach(), blk.inver_mod1.bias.detach())
         n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
         st1 = zeros(Cc)
-        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
+        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD, H), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
                         noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
                         act=ops.ACT_LRELU, stats=st1)
         musig2, sc2, sh2 = ops.stats_finalize(st1, H * H, musig_out=ms_slot(2 * j + 1))
@@ -120,7 +123,7 @@ def encoder_forward(E, img, noises=None, save=False):
         nstats = zeros(C2) if not last else None
         if not last:
             n2 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
-            a2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=sc2, in_shift=sh2, noise=n2,
+            a2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H), C2, 3, in_scale=sc2, in_shift=sh2, noise=n2,
                             noise_w=blk.noise_weight_2.detach().reshape(-1), bias=blk.bias_2.detach().reshape(-1),
                             act=ops.ACT_LRELU)
             if has3:

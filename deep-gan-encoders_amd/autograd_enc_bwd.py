@@ -86,7 +86,7 @@ def encoder_backward(E, saved, g_w):
             ops.conv_wgrad(g_pre2, x1, gW2, rec["sc2"], rec["sh2"])
             grads[pre + "conv_2.weight"] = gW2
             dots2 = ops.SlotStats(B, Cc, dev)                 # slot copies are added by in_bwd_coef
-            g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots2, dot_src=x1)
+            g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
             if has3:
                 grads[pre + "conv_3.bias"] = red2[2] * 0.889
                 gW3 = ops.zeros(tuple(blk.conv_3.weight.shape), dev)
@@ -109,7 +109,7 @@ def encoder_backward(E, saved, g_w):
         ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
         grads[pre + "conv_1.weight"] = gW1
         dots1 = ops.SlotStats(B, Cc, dev)
-        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD), Cc, 3, stats=dots1, dot_src=x)
+        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
         coef1 = ops.in_bwd_coef(dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
         g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
         if j == L // 2:

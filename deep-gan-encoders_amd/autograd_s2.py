@@ -111,6 +111,8 @@ def synthesis_run(mod, wp, randomize_noise=False, save=False):
 
 def _dgrad_weight(L, dtype):
     mode = ops.PACK_UPFOLD_DGRAD if L.up else ops.PACK_DGRAD
+    hg = L.res // 2 if L.up else L.res          # grid the data-gradient conv runs on (space-to-depth grid for the up layers)
+    mode = ops.pack_mode_for(L.weight, mode, hg, hg, dtype)
     key = ("dg", dtype, L.weight._version, L.weight.data_ptr(), getattr(L.weight, "_dge_gen", 0))
     c = L._cache.get("dg")
     if c is None or c[0] != key:

@@ -66,6 +66,8 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.noise_w_stride = d->noise_w_per_channel ? 1 : 0;
     p.act = d->act; p.bias_scale = d->bias_scale; p.gain = d->gain; p.add_scale = d->add_scale;
     p.tiles_x = p.tiles_y = 0;
+    p.w_frag = d->w_layout == 1 ? 1 : 0;
+    DGE_CHECK(d->w_layout == 0 || d->w_layout == 1, "conv2d: bad w_layout %d", d->w_layout);
     p.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
     return dge_conv_launch(p, d->dtype, d->ksize, s);
 }

@@ -109,6 +109,9 @@ __device__ __forceinline__ float* det_slot(int domain, int ndomains, int slot, i
 // `arrivals` = number of det_arrive_wg calls per domain.
 __device__ __forceinline__ bool det_arrive_wg(int domain, int arrivals) {
     __shared__ int s_last;
+    // every wave drains ITS slot stores to L2 before the barrier; thread 0's agent-scope release (buffer_wbl2) then writes the
+    // XCD's dirty lines back, so the ticket cannot overtake another wave's stores (the fence alone waits only for wave 0's)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

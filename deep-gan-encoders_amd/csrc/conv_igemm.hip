@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "conv_params.h"
+#include "conv_epilogue.h"
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -356,178 +357,9 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
         for (int kc = 0; kc + 1 < nchunks; kc++) chunk(kc, std::false_type{});
         chunk(nchunks - 1, std::true_type{});
     }
-    // LDS is re-used as the epilogue transpose buffer from here (all reads done: barrier above)
-
-    // ---------------------------------------------------------------- epilogue
-    // NOTE: every accumulator index below is a compile-time constant (StaticFor): a run-time index
-    // into acc[][] would push the whole accumulator file to scratch on every main-loop iteration.
-    unsigned char* est = lds + wave * (32 * C::ESTR);     // (the noise tile at the end of `lds` stays valid)
-    const int OH = p.up ? 2 * p.H : p.H, OW = p.up ? 2 * p.W : p.W;
-    T* __restrict__ Y = (T*)p.y;
-    const T* __restrict__ ADD = (const T*)p.addend;
-    const T* __restrict__ DOT = (const T*)p.dot_src;
-    constexpr int CPR = 32 / EP16;              // 16-byte chunks per 32-channel row
-    constexpr int PPP = 64 / CPR;               // pixels per read-back pass
-    // Two kinds of epilogue work:
-    //   "pre"  (per accumulator element, this lane owns ONE channel): demodulation scale, noise,
-    //          bias, activation, gain, plain statistics;
-    //   "post" (after the LDS transpose, this lane owns 8/4 consecutive channels of one pixel, so
-    //          every global access is a 16-byte vector): residual addend, the data-gradient dot
-    //          products with dot_src, statistics of results that include the addend.
-    // In DOT mode (data gradients) the per-channel scale is applied post, on the staged raw value.
-    const bool post_stats = p.stats && (DOT || ADD);
-    float* __restrict__ STATS = p.stats ? p.stats + (size_t)(vbid % p.stats_slots) * p.B * p.Cout * 2 : nullptr;
-    // deterministic mode: domain = (sample, N tile), slot = (pixel tile, wave row wm), vector = (sum, sum2) per channel of the N tile;
-    // the last workgroup of the domain sums the slots in order into copy 0 of the statistics buffer (the other copies stay zero)
-    const bool det = p.stats && !p.up && det_on();
-    const int det_ntn = (p.Ntot + BN - 1) / BN, det_dom = b * det_ntn + ntile, det_nslots = p.tiles_x * p.tiles_y * WM;
-    float* det_vec = det ? det_slot(det_dom, p.B * det_ntn, (ty_i * p.tiles_x + tx_i) * WM + wm, det_nslots, BN * 2) : nullptr;
-    // activation as max(v, slope*v) (slope in [0,1]); the gain (> 0, checked by the launcher) is folded
-    // into scale / noise weight / bias because every supported activation is positively homogeneous
-    const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
-    const bool tile_full = (y0 + TH <= p.H) && (x0 + TW <= p.W);
-    const int lh = lane >> 5, l31 = lane & 31;
-    T* __restrict__ Yb = Y + (size_t)b * OH * OW * p.Cout;           // in-image offsets fit 32 bits
-    const T* __restrict__ ADDb = ADD ? ADD + (size_t)b * OH * OW * p.Cout : nullptr;
-    const T* __restrict__ DOTb = DOT ? DOT + (size_t)b * OH * OW * p.Cout : nullptr;
-    if (!(p.dbg & 4))
-    StaticFor<C::NT>::run([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const int n0 = bn0 + wn * C::WTN + j * 32;          // first N of this 32-wide tile
-        if (n0 >= p.Ntot_valid) return;                     // wave-uniform
-        // up mode: N = (phase, channel).  A 32-wide tile lies inside one phase when Cout % 32 == 0 (tile-uniform
-        // phase); with Cout == 16 (StyleGAN1 FFHQ-1024 top block) it spans two, so phase/channel are per lane.
-        const bool split = p.up && (p.Cout & 31);
-        int phase = p.up ? n0 / p.Cout : 0;                 // "pre" side: this lane's channel n0 + l31
-        int o = (p.up ? n0 % p.Cout : n0) + l31;
-        const int chq = lane % CPR;
-        int phase_c = phase;                                // "post" side: this lane's chunk n0 + chq*EP16 ..
-        int oc = (p.up ? n0 % p.Cout : n0) + chq * EP16;
-        bool ovalid = o < p.Cout, cvalid = oc < p.Cout;
-        if (split) {
-            const int n = n0 + l31, nc = n0 + chq * EP16;
-            phase = n / p.Cout; o = n - phase * p.Cout; ovalid = n < p.Ntot_valid;
-            phase_c = nc / p.Cout; oc = nc - phase_c * p.Cout; cvalid = nc < p.Ntot_valid;
-            if (!ovalid) phase = 0;
-        }
-        const int py = phase_c >> 1, px = phase_c & 1;
-        const float osc = ((p.out_scale && ovalid && !DOT) ? p.out_scale[b * p.Cout + o] : 1.f) * p.gain;
-        const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale * p.gain : 0.f;
-        const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] * p.gain : 0.f;
-        float ssum = 0.f, ssq = 0.f;
-        float posc[EP16], ps0[EP16], ps1[EP16];
-#pragma unroll
-        for (int e = 0; e < EP16; e++) {
-            posc[e] = (DOT && p.out_scale && cvalid) ? p.out_scale[b * p.Cout + oc + e] : 1.f;
-            ps0[e] = 0.f; ps1[e] = 0.f;
-        }
-        float* estw = (float*)(est + 4 * lh * C::ESTR) + l31;                     // + ((r&3) + 8(r>>2)) rows
-        const float* nzb = ldsN + phase * C::BM + wm * C::WTM + 4 * lh;          // + i*32 + 8(r>>2) + (r&3)
-        StaticFor<C::MT>::run([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            const f32x16_t a = acc[i][j];
-            float nz[16], val[16];
-            if (p.noise) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) *(float4*)&nz[q * 4] = *(const float4*)(nzb + i * 32 + q * 8);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; r++) nz[r] = 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float v = fmaf(a[r], osc, fmaf(nw, nz[r], bia));
-                val[r] = fmaxf(v, v * slope);
-            }
-            if (p.stats && !post_stats) {
-                if (tile_full) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) { ssum += val[r]; ssq += val[r] * val[r]; }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int m = wm * C::WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        const bool pv = (y0 + m / TW < p.H) & (x0 + m % TW < p.W);
-                        ssum += pv ? val[r] : 0.f; ssq += pv ? val[r] * val[r] : 0.f;
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) estw[((r & 3) + 8 * (r >> 2)) * (C::ESTR / 4)] = val[r];
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int q = 0; q < 32 / PPP; q++) {
-                const int ml = q * PPP + lane / CPR;
-                const int m = wm * C::WTM + i * 32 + ml;
-                const int gy = y0 + m / TW, gx = x0 + m % TW;
-                const int oy = p.up ? 2 * gy + py : gy, ox = p.up ? 2 * gx + px : gx;
-                if ((gy < p.H) & (gx < p.W) & cvalid) {
-                    float f[EP16];
-#pragma unroll
-                    for (int e4 = 0; e4 < EP16 / 4; e4++)
-                        *(uint4*)&f[e4 * 4] = *(const uint4*)(est + ml * C::ESTR + chq * EP16 * 4 + e4 * 16);
-                    const int off = (oy * OW + ox) * p.Cout + oc;
-                    if (DOT || ADD) {
-                        if (DOT) {
-                            float d[EP16];
-                            unpack16(*(const uint4*)(DOTb + off), d, (T*)nullptr);
-#pragma unroll
-                            for (int e = 0; e < EP16; e++) { ps0[e] += f[e] * d[e]; ps1[e] += f[e]; f[e] *= posc[e]; }
-                        }
-                        if (ADD) {
-                            float ad[EP16];
-                            unpack16(*(const uint4*)(ADDb + off), ad, (T*)nullptr);
-#pragma unroll
-                            for (int e = 0; e < EP16; e++) f[e] += p.add_scale * ad[e];
-                        }
-                        if (post_stats && !DOT) {
-#pragma unroll
-                            for (int e = 0; e < EP16; e++) { ps0[e] += f[e]; ps1[e] += f[e] * f[e]; }
-                        }
-                    }
-                    *(uint4*)(Yb + off) = pack16(f, (T*)nullptr);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        });
-        if (p.stats && !post_stats) {
-            ssum += __shfl_xor(ssum, 32, 64);
-            ssq += __shfl_xor(ssq, 32, 64);
-            if (lane < 32 && ovalid) {
-                if (det) {                 // this wave's slot of the (sample, N tile) domain: one entry pair per channel of the tile
-                    const int e = (wn * C::WTN + j * 32 + l31) * 2;
-                    det_vec[e] = ssum; det_vec[e + 1] = ssq;
-                } else {
-                    atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2, ssum);
-                    atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
-                }
-            }
-        }
-        if (post_stats) {          // lanes with equal chq hold partial sums of the same channels
-#pragma unroll
-            for (int e = 0; e < EP16; e++) {
-#pragma unroll
-                for (int msk = CPR; msk < 64; msk <<= 1) { ps0[e] += __shfl_xor(ps0[e], msk, 64); ps1[e] += __shfl_xor(ps1[e], msk, 64); }
-                if (lane < CPR && cvalid) {
-                    if (det) {
-                        const int ee = (wn * C::WTN + j * 32 + chq * EP16 + e) * 2;
-                        det_vec[ee] = ps0[e]; det_vec[ee + 1] = ps1[e];
-                    } else {
-                        atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2, ps0[e]);
-                        atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2 + 1, ps1[e]);
-                    }
-                }
-            }
-        }
-    });
-    if (det) {
-        if (det_arrive_wg(det_dom, p.tiles_x * p.tiles_y)) {
-            for (int idx = tid; idx < BN * 2; idx += 256) {
-                const int o = bn0 + (idx >> 1);
-                if (o < p.Cout) p.stats[((size_t)b * p.Cout + o) * 2 + (idx & 1)] = det_sum(det_dom, det_nslots, BN * 2, idx);
-            }
-        }
-    }
+    // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
+    // LDS is re-used as the transpose buffer from here (all reads done: barrier above); the noise tile at its end stays valid
+    conv_epilogue<T, C, TH, TW, BN, WM, WN, 256>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
 }
 
 // ------------------------------------------------------------------------- dispatch
@@ -586,6 +418,12 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
 }
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s) {
+    if (p.w_frag) {                  // fragment-ordered weights: the low-resolution kernel (conv_small.hip) is the only reader
+        DGE_CHECK(dge_conv_small_shape_ok(p.H, p.W, p.Cin, p.Ntot, ksize, p.in_s2d, p.in_up2, dtype),
+                  "conv: w_layout = 1 (DGE_PACK_FRAG) but the launch %dx%d Cin=%d N=%d is not one dge_conv_small_supported() accepts",
+                  p.H, p.W, p.Cin, p.Ntot);
+        return dge_conv_small_launch(p, s);
+    }
     if (dge_conv_stream_eligible(p, dtype, ksize)) return dge_conv_stream_launch(p, s);     // HBM-bound layers: conv_stream.hip
     const int esize = dtype == DGE_BF16 ? 2 : 4;
     DGE_CHECK(ksize == 1 || ksize == 3, "conv: ksize %d unsupported", ksize);

@@ -29,6 +29,7 @@ struct ConvParams {
     float bias_scale, gain, add_scale;
     int tiles_x, tiles_y;     // filled by the launcher
     int dbg;                  // ablation switches for tuning (DGE_CONV_DBG), 0 in production
+    int w_frag;               // 1: `w` is in MFMA-fragment order (DGE_PACK_FRAG): the launch must go to conv_small.hip
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);
@@ -37,3 +38,6 @@ extern "C" int dge_conv_ntile(int ntot);
 // conv_stream.hip: the streaming kernel for the HBM-bound small-channel 3x3 layers
 bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize);
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s);
+// conv_small.hip: the low-resolution 3x3 layers (whole-Cin halo tile resident in LDS, weights streamed straight into registers)
+bool dge_conv_small_shape_ok(int H, int W, int cin, int ntot, int ksize, int in_s2d, int in_up2, int dtype);
+int dge_conv_small_launch(const ConvParams& p, hipStream_t s);

@@ -51,9 +51,21 @@ __device__ __forceinline__ float upfold_weight(const float* __restrict__ w, int 
     return v;
 }
 
+// DGE_PACK_FRAG (mode bit 0x100): the same [tap][n][k] values stored in MFMA-fragment order for csrc/conv_small.hip, which loads
+// its weight operand straight from global memory: the 32 rows x 16 k block (tap, n/32, k/16) is one contiguous 1 KiB run in
+// lane order - lane = (n % 32) + 32 * ((k % 16) / 8) holds the 8 consecutive k of its v_mfma_f32_32x32x16_bf16 B operand - so a
+// wave's operand load is `base + lane * 16`, fully coalesced.
+__device__ __forceinline__ size_t pack_out_index(int frag, int tap, int n, int k, int Ntot, int Kdim) {
+    if (!frag) return ((size_t)tap * Ntot + n) * Kdim + k;
+    const size_t blk = ((size_t)tap * (Ntot >> 5) + (n >> 5)) * (Kdim >> 4) + (k >> 4);
+    return blk * 512 + (size_t)(((n & 31) + 32 * ((k & 15) >> 3)) * 8 + (k & 7));
+}
+
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KS,
                                    int Ntot, int mode, float scale) {
+    const int frag = mode & 0x100;
+    mode &= 0xff;
     const int ntap = KS * KS;
     const int Kdim = (mode == 2) ? Cout : ((mode == 3 || mode == 5) ? 4 * Cout : Cin);
     const int total = ntap * Ntot * Kdim;            // < 2^31 (checked by the launcher): 32-bit index math
@@ -75,7 +87,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
         } else {
             if (n < Cin) v = upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap);
         }
-        Elem<T>::st(out + idx, v * scale);
+        Elem<T>::st(out + pack_out_index(frag, tap, n, k, Ntot, Kdim), v * scale);
     }
 }
 
@@ -105,8 +117,8 @@ __global__ void pack_multi_kernel(const DgePackDesc* __restrict__ descs, int nd,
         const int k = (int)(local % e.kdim), n = (int)(local / e.kdim);
         const int ntap = e.ks * e.ks;
         for (int tap = 0; tap < ntap; tap++) {
-            const float v = pack_gather(e.w, e.mode, e.cout, e.cin, ntap, n, k, tap) * e.scale;
-            const size_t o = ((size_t)tap * e.ntot + n) * e.kdim + k;
+            const float v = pack_gather(e.w, e.mode & 0xff, e.cout, e.cin, ntap, n, k, tap) * e.scale;
+            const size_t o = pack_out_index(e.mode & 0x100, tap, n, k, e.ntot, e.kdim);
             if (e.dtype == DGE_BF16) ((bf16_t*)e.out)[o] = f2bf(v);
             else ((float*)e.out)[o] = v;
         }
@@ -373,11 +385,16 @@ extern "C" int dge_demod_rows(const float* s_all, const float* wsq_cat, const in
 
 extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, int cin, int ksize, int mode, int dtype,
                                     float scale, hipStream_t s) {
-    DGE_CHECK(mode >= 0 && mode <= 5, "pack: bad mode %d", mode);
+    const int frag = mode & 0x100;
+    const int mode_full = mode;
+    mode &= 0xff;
+    DGE_CHECK(mode >= 0 && mode <= 5 && (mode_full & ~0x1ff) == 0, "pack: bad mode %d", mode_full);
     DGE_CHECK((mode != 1 && mode < 3) || ksize == 3, "pack: up fold needs a 3x3 kernel");
     const int nvalid = (mode == 1 || mode == 4) ? 4 * cout : (mode >= 2 ? cin : cout);
     const int ntot = dge_packed_n(nvalid);
     const int kdim = mode == 2 ? cout : ((mode == 3 || mode == 5) ? 4 * cout : cin);
+    DGE_CHECK(!frag || (dtype == DGE_BF16 && ntot % 32 == 0 && kdim % 16 == 0), "pack: fragment order needs bf16, N %% 32 == 0, K %% 16 == 0");
+    mode = mode_full;
     const long total = (long)ksize * ksize * ntot * kdim;
     DGE_CHECK(total < (1L << 31) - (4096L * 256), "pack: weight too large (%ld elements)", total);
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
@@ -405,11 +422,14 @@ extern "C" int dge_pack_conv_weights_multi(const long long* table_host, void* de
         d.ks = (int)(r[3] & 0xffffffffLL); d.mode = (int)(r[3] >> 32);
         d.dtype = (int)r[4];
         const unsigned bits = (unsigned)r[5]; memcpy(&d.scale, &bits, 4);
-        DGE_CHECK(d.mode >= 0 && d.mode <= 5, "pack_multi: bad mode %d", d.mode);
-        DGE_CHECK((d.mode != 1 && d.mode < 3) || d.ks == 3, "pack_multi: up fold needs a 3x3 kernel");
-        const int nvalid = (d.mode == 1 || d.mode == 4) ? 4 * d.cout : (d.mode >= 2 ? d.cin : d.cout);
+        const int bm = d.mode & 0xff;
+        DGE_CHECK(bm >= 0 && bm <= 5 && (d.mode & ~0x1ff) == 0, "pack_multi: bad mode %d", d.mode);
+        DGE_CHECK((bm != 1 && bm < 3) || d.ks == 3, "pack_multi: up fold needs a 3x3 kernel");
+        const int nvalid = (bm == 1 || bm == 4) ? 4 * d.cout : (bm >= 2 ? d.cin : d.cout);
         d.ntot = dge_packed_n(nvalid);
-        d.kdim = d.mode == 2 ? d.cout : ((d.mode == 3 || d.mode == 5) ? 4 * d.cout : d.cin);
+        d.kdim = bm == 2 ? d.cout : ((bm == 3 || bm == 5) ? 4 * d.cout : d.cin);
+        DGE_CHECK(!(d.mode & 0x100) || (d.dtype == DGE_BF16 && d.ntot % 32 == 0 && d.kdim % 16 == 0),
+                  "pack_multi: fragment order needs bf16, N %% 32 == 0, K %% 16 == 0");
         d.pair_start = pairs;
         pairs += (long long)d.ntot * d.kdim;
     }

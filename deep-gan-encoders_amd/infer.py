@@ -20,8 +20,9 @@ from .ops import _f32, _p, _stream
 
 
 @torch.no_grad()
-def reconstruct(step, z=None, iteration=4):
-    """One inversion round trip with the models of an `EAlignStep` (any --mtype): returns dict(imgs1, w1, const2, w2, imgs2)."""
+def reconstruct(step, z=None, iteration=4, noises=None):
+    """One inversion round trip with the models of an `EAlignStep` (any --mtype): returns dict(imgs1, w1, const2, w2, imgs2).
+    `noises`: optional encoder noise tensors (the reference draws them on the CPU, model/E/E.py:60,73 - parity runs inject them)."""
     from .e_align import set_seed, _BigGANAdapter
     gen, E, B = step.gen, step.E, step.batch_size
     big = isinstance(gen, _BigGANAdapter)
@@ -30,7 +31,7 @@ def reconstruct(step, z=None, iteration=4):
         z = gen.draw(iteration, B, step.dev) if big else torch.randn(B, step.z_dim)
     z = z.to(step.dev)
     imgs1, w1 = gen.sample(z)
-    const2, w2 = E(imgs1, gen.const1) if big else E(imgs1)
+    const2, w2 = E(imgs1, gen.const1, noises=noises) if big else E(imgs1, noises=noises)
     return dict(imgs1=imgs1, w1=w1, const2=const2, w2=w2, imgs2=gen.synth(w2))
 
 

@@ -106,8 +106,10 @@ class LPIPS(nn.Module):
         self.pretrained = True
         return self
 
-    def _packed(self, ci, dt, mode):
+    def _packed(self, ci, dt, mode, hw=None):
         conv = self.convs[ci]
+        if hw is not None and ci > 0:       # conv5_x on the cropped images run on the low-resolution kernel: fragment-ordered copy
+            mode = ops.pack_mode_for(conv.weight, mode, hw[0], hw[1], dt)
         key = (ci, dt, mode)
         ver = (conv.weight._version, conv.weight.data_ptr(), getattr(conv.weight, "_dge_gen", 0))
         hit = self._cache.get(key)
@@ -163,7 +165,7 @@ class LPIPS(nn.Module):
                 cur = y
                 continue
             conv = self.convs[ci]
-            cur = ops.conv2d(cur, self._packed(ci, dt, ops.PACK_FWD), item[1], 3, bias=conv.bias.detach(), act=ops.ACT_RELU)
+            cur = ops.conv2d(cur, self._packed(ci, dt, ops.PACK_FWD, cur.shape[1:3]), item[1], 3, bias=conv.bias.detach(), act=ops.ACT_RELU)
             acts.append(cur)
             ci += 1
         val = torch.zeros(B, dtype=torch.float32, device=dev)
@@ -191,7 +193,7 @@ class LPIPS(nn.Module):
             g_pre = ops.act_bwd(g, f_b, slope=0.0)
             cin = _CPAD if ci == 0 else _VGG_CIN[ci]
             # input of conv ci and whether it came through a max pool
-            g_in = ops.conv2d(g_pre, self._packed(ci, dt, ops.PACK_DGRAD), cin, 3,
+            g_in = ops.conv2d(g_pre, self._packed(ci, dt, ops.PACK_DGRAD, g_pre.shape[1:3]), cin, 3,
                               addend=(heads[_TAP_AFTER.index(ci - 1)] if (ci - 1 in _TAP_AFTER and ci not in pools) else None))
             if ci == 0:
                 g = g_in

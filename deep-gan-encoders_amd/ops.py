@@ -10,6 +10,7 @@ from ._lib import lib, check, ConvDesc, DgeError
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
 PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP, PACK_SG1_UP_DGRAD = 0, 1, 2, 3, 4, 5
+PACK_FRAG = 0x100     # OR-ed into a pack mode: MFMA-fragment order for the low-resolution kernel (csrc/conv_small.hip)
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag, algorithmic_bytes) per conv launch
 
 
@@ -182,16 +183,46 @@ def packed_n(n):
     return lib().dge_packed_n(int(n))
 
 
+def small_conv(H, W, kdim, nvalid, ksize=3, in_s2d=False, in_up2=False, dtype=BF16):
+    """True when dge_conv2d runs a launch of this shape (input grid H x W, packed K = kdim, N = nvalid before padding) on the
+    low-resolution kernel: its weights must then be packed with `mode | PACK_FRAG`."""
+    return bool(lib().dge_conv_small_supported(int(H), int(W), int(kdim), packed_n(nvalid), int(ksize), int(bool(in_s2d)),
+                                               int(bool(in_up2)), int(dtype)))
+
+
+def pack_dims(w, mode):
+    """(nvalid, kdim) of the packed copy of w [Cout,Cin,k,k] in pack mode `mode`"""
+    cout, cin = w.shape[0], w.shape[1]
+    mode &= 0xff
+    if mode in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):
+        cin, cout = cout, cin
+    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cout)
+    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cin)
+    return nvalid, kdim
+
+
+def pack_mode_for(w, mode, H, W, dtype):
+    """`mode`, with PACK_FRAG added when the conv that reads this copy at input resolution H x W runs on the low-resolution kernel"""
+    nvalid, kdim = pack_dims(w, mode)
+    in_s2d = (mode & 0xff) in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD)
+    return mode | PACK_FRAG if small_conv(H, W, kdim, nvalid, w.shape[-1], in_s2d, False, dtype) else mode
+
+
 def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
-    """w: [Cout,Cin,k,k] f32 (reference layout) -> packed [k*k, Npad, K] tensor of `dtype`."""
+    """w: [Cout,Cin,k,k] f32 (reference layout) -> packed [k*k, Npad, K] tensor of `dtype`; with `mode | PACK_FRAG` the same values in
+    MFMA-fragment order (the tensor carries `_dge_frag = True`, which conv2d hands on as dge_conv_desc.w_layout)."""
+    frag = bool(mode & PACK_FRAG)
+    mode_full, mode = mode, mode & 0xff
     cout, cin, k, _ = w.shape
     if mode in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):          # ConvTranspose2d parameter layout [Cin, Cout, k, k]
         cin, cout = cout, cin
     nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cout)
     kdim = cout if mode == PACK_DGRAD else (4 * cout if mode in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cin)
     out = torch.empty((k * k, packed_n(nvalid), kdim), dtype=tdtype(dtype), device=w.device)
-    check(lib().dge_pack_conv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, k, mode, dtype, float(scale),
+    check(lib().dge_pack_conv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, k, mode_full, dtype, float(scale),
                                      _stream()), "dge_pack_conv_weight")
+    if frag:
+        out._dge_frag = True
     return out
 
 
@@ -217,7 +248,7 @@ def pack_conv_weights_multi(entries, scratch=None):
     rows = []
     for (w, mode, dtype, scale, out) in entries:
         cout, cin, k, _ = w.shape
-        if mode in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):
+        if (mode & 0xff) in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):
             cin, cout = cout, cin
         if not (w.is_cuda and w.is_contiguous() and w.dtype == torch.float32):
             raise DgeError("pack_conv_weights_multi: weights must be contiguous f32 device tensors")
@@ -304,6 +335,7 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
     d.ksize, d.up, d.in_s2d, d.in_up2 = ksize, 1 if up else 0, 1 if in_s2d else 0, 1 if in_up2 else 0
     d.in_relu = 1 if in_relu else 0
+    d.w_layout = 1 if getattr(w_packed, "_dge_frag", False) else 0
     d.noise_batch = 1 if noise is None else noise.shape[0]
     d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
     d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt

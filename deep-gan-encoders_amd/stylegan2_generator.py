@@ -152,7 +152,9 @@ class ModulateConvBlock(nn.Module):
         c = self._cache.get("w")
         if c is None or c[0] != key:
             mode = ops.PACK_UPFOLD if self.up else ops.PACK_FWD
-            packed = ops.pack_conv_weight(self.weight, mode, dtype, self.wscale) if self.ksize == 3 else None
+            hin = self.res // 2 if self.up else self.res         # the low-resolution layers get fragment-ordered weights (conv_small)
+            packed = ops.pack_conv_weight(self.weight, ops.pack_mode_for(self.weight, mode, hin, hin, dtype), dtype, self.wscale) \
+                if self.ksize == 3 else None
             wsq = ops.weight_sumsq(self.weight, self.wscale) if self.demodulate else None
             c = (key, packed, wsq)
             self._cache["w"] = c

@@ -74,8 +74,15 @@ typedef struct dge_conv_desc {
     int in_up2;               /* 1: x is [B,H/2,W/2,Cin] read through a nearest x2 upsample (upscale2d, model/stylegan1/net.py:37-43) */
     int in_relu;              /* 1: ReLU after the prologue affine (BigGAN BN -> ReLU -> conv, model/biggan_generator.py:178-196) */
     int stats_slots;          /* >=1: workgroups spread their statistics atomics over this many copies (combine with dge_sum_slots) */
+    int w_layout;             /* 0: [tap][N][K] rows; 1: MFMA-fragment order (pack mode | DGE_PACK_FRAG) - only where
+                                 dge_conv_small_supported() says so: the low-resolution layers (4^2 .. 16^2 at 512 channels:
+                                 stylegan2_generator.py:488-490 layers 0-4, E.py blocks at <= 16^2, LPIPS conv5_x) */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
+/* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
+ * weights packed with DGE_PACK_FRAG; H, W = the conv's input grid, cin / ntot = packed K and N (4*Cout in up mode). */
+int dge_conv_small_supported(int H, int W, int cin, int ntot, int ksize, int in_s2d, int in_up2, int dtype);
+#define DGE_PACK_FRAG 0x100   /* OR-ed into the pack mode: fragment-ordered output for dge_conv_desc.w_layout = 1 */
 /* Test / tuning hook: the kernel instantiation the calling thread's last dge_conv2d / dge_upconv_fir / dge_conv_wgrad call
  * selected, e.g. "conv_igemm<bf16,16,16,128,32,3,2,2>" (pixel tile TH x TW, N tile, K chunk, kernel size, wave grid),
  * "upconv_fir<bf16>", "conv_wgrad_tr<3,16>".  The parity tests assert by name that the configurations which carry the

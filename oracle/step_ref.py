@@ -9,9 +9,10 @@ from . import ref_torch as O
 from . import lpips_ref as LR
 
 
-def e_align_step(PG, PE, PL, z, noises, lr=0.0015, state=None):
+def e_align_step(PG, PE, PL, z, noises, lr=0.0015, state=None, record=None):
     """PE: dict of leaf tensors with requires_grad=True (updated in place through .data, like
-    LREQAdam).  Returns dict with losses.  `state`: optimiser state dict (exp_avg_sq, step)."""
+    LREQAdam).  Returns dict with losses.  `state`: optimiser state dict (exp_avg_sq, step); `record`: optional dict that
+    receives the encoder gradients of both phases ("grad1", "grad2") for the full-size gradient parity test."""
     state = {} if state is None else state
     with torch.no_grad():
         w, wp, imgs1 = O.s2_generator_eval(PG, z)
@@ -37,10 +38,15 @@ def e_align_step(PG, PE, PL, z, noises, lr=0.0015, state=None):
     for p in PE.values():
         p.grad = None
     tot.backward(retain_graph=True)
+    if record is not None:          # encoder gradients of the image phase (before the optimiser touches the weights)
+        record["grad1"] = {k: p.grad.clone() for k, p in PE.items() if p.grad is not None}
     adam(state.get("_coef", {}))
     lw, _ = O.space_loss(wp, w2, image_space=False)
     for p in PE.values():
         p.grad = None
     (lw * 0.01).backward()
+    if record is not None:          # latent phase: weights already updated once, activations from before (quirk Q3)
+        record["grad2"] = {k: p.grad.clone() for k, p in PE.items() if p.grad is not None}
+        record["wp"] = wp
     adam(state.get("_coef", {}))
     return dict(loss_tsa=float(tot), loss_w=float(lw), imgs1=imgs1, imgs2=imgs2.detach(), w2=w2.detach())

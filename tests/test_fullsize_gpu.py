@@ -64,6 +64,14 @@ def _kernel():
     return last_kernel()
 
 
+def _pack(w, mode, H, W, scale=1.0, model_dispatch=True):
+    """packed copy of w the way the models make it: fragment order where the launch goes to the low-resolution kernel
+    (ops.pack_mode_for); model_dispatch=False keeps the row layout (the general kernel's small-tile configuration)"""
+    from dge_amd import ops
+    m = ops.pack_mode_for(w, mode, H, W, ops.BF16) if model_dispatch else mode
+    return ops.pack_conv_weight(w, m, ops.BF16, scale)
+
+
 SAMPLES = lambda B: sorted({0, B - 1})
 
 # (Cin, Cout, R, B) of the generator's stride-1 layers and the instantiation launch_t must select for them
@@ -74,8 +82,10 @@ G_LAYERS = [
     (256, 256, 128, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),     # layer10
     (512, 512, 64, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),      # layer8
     (512, 512, 32, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>"),       # layer6
-    (512, 512, 16, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),        # layer4: small-tile configuration, 256-byte K chunks
-    (512, 512, 4, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),         # layer0
+    (512, 512, 16, 8, "conv_small<bf16,8,8,64,512>"),              # layer4: the low-resolution kernel (csrc/conv_small.hip)
+    (512, 512, 8, 8, "conv_small<bf16,8,8,64,512>"),               # layer2
+    (512, 512, 4, 8, "conv_small<bf16,8,8,64,512>"),               # layer0 (one 8x8 tile per sample, a quarter of it image)
+    (512, 512, 16, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),        # the general kernel's small-tile configuration (row-ordered weights)
     (32, 32, 1024, 1, "conv_stream<bf16,32,32,gen>"),       # batch 1
 ]
 
@@ -94,8 +104,8 @@ def test_generator_stride1_layer_fullsize(cin, cout, R, B, kernel):
     noise = torch.randn(1, R, R, device=DEV, generator=g)
     ns = torch.tensor([0.37], device=DEV)
     bias = 0.2 * torch.randn(cout, device=DEV, generator=g)
-    y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, wscale), cout, 3, in_scale=s, out_scale=d, bias=bias,
-                   bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=math.sqrt(2.0))
+    y = ops.conv2d(x, _pack(w, ops.PACK_FWD, R, R, wscale, model_dispatch=not kernel.startswith("conv_igemm<bf16,8,8")), cout, 3,
+                   in_scale=s, out_scale=d, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=math.sqrt(2.0))
     assert _kernel() == kernel
     # the packed weight is w*wscale rounded to bf16: hand the oracle the same values
     wq = CR.bf16_round(w.cpu() * wscale)
@@ -115,8 +125,8 @@ UP_LAYERS = [
     (128, 64, 256, 8, "upconv_fir<bf16>"),                         # layer13
     (512, 512, 32, 8, "upconv_fir<bf16>"),                         # layer7
     (512, 512, 16, 8, "upconv_fir<bf16>"),                         # layer5 (-> 32^2: smallest phase-form layer)
-    (512, 512, 4, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),         # layer1: folded 3x3-per-phase form (N = 4*Cout)
-    (512, 512, 8, 8, "conv_igemm<bf16,8,8,64,128,3,2,2>"),         # layer3
+    (512, 512, 4, 8, "conv_small<bf16,8,8,64,512>"),               # layer1: folded 3x3-per-phase form (N = 4*Cout), depth-to-space store
+    (512, 512, 8, 8, "conv_small<bf16,8,8,64,512>"),               # layer3
 ]
 
 
@@ -139,7 +149,7 @@ def test_generator_up_layer_fullsize(cin, cout, Rin, B, kernel):
         assert ops.upconv_supported(cin, cout, ops.BF16) and 2 * Rin >= 32
         y = ops.upconv_fir(x, ops.pack_upconv_weight(w, ops.BF16, wscale), cout, **args)
     else:
-        y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_UPFOLD, ops.BF16, wscale), cout, 3, up=True, **args)
+        y = ops.conv2d(x, _pack(w, ops.PACK_UPFOLD, Rin, Rin, wscale), cout, 3, up=True, **args)
     assert _kernel() == kernel
     # phase form: the packed units are w*wscale in bf16; folded form: K (x) W summed in f32, then rounded - both within the bound
     wq = CR.bf16_round(w.cpu() * wscale)
@@ -162,7 +172,8 @@ ENC_CONVS = [
     (32, 64, 512, 8, False, "conv_stream<bf16,32,64,enc>"),     # block 1 conv_2
     (64, 64, 256, 8, True, "conv_igemm<bf16,16,16,64,32,3,4,1>"),      # block 2 conv_1 (encoder flavours stop at Cin = 32: registers)
     (64, 128, 256, 8, False, "conv_igemm<bf16,16,16,128,32,3,2,2>"),   # block 2 conv_2: back on the implicit-GEMM kernel
-    (512, 512, 8, 8, True, "conv_igemm<bf16,8,8,64,128,3,2,2>"),       # block 7 conv_1
+    (512, 512, 8, 8, True, "conv_small<bf16,8,8,64,512>"),             # block 7 conv_1
+    (512, 512, 16, 8, True, "conv_small<bf16,8,8,64,512>"),            # block 6 conv_1 (four tiles per sample)
 ]
 
 
@@ -181,7 +192,7 @@ def test_encoder_conv_fullsize(cin, cout, R, B, stats, kernel):
     nw = 0.1 * torch.randn(cout, device=DEV, generator=g)
     bias = 0.1 * torch.randn(cout, device=DEV, generator=g)
     st = ops.SlotStats(B, cout, DEV) if stats else None
-    y = ops.conv2d(x, ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, 1.0), cout, 3, in_scale=sc, in_shift=sh, noise=noise,
+    y = ops.conv2d(x, _pack(w, ops.PACK_FWD, R, R), cout, 3, in_scale=sc, in_shift=sh, noise=noise,
                    noise_w=nw, bias=bias, act=ops.ACT_LRELU, stats=st)
     assert _kernel() == kernel
     if stats:
@@ -243,6 +254,9 @@ DGRADS = [
     (64, 32, 512, 8, 3, False, "conv_stream<bf16,64,32,dot>"),        # encoder block 1 conv_2
     (128, 128, 256, 8, 3, True, "conv_igemm<bf16,16,16,128,32,3,2,2>"),    # generator layer12
     (64, 32, 256, 8, 1, False, "conv_igemm<bf16,16,16,32,32,1,4,1>"),      # encoder block 1 conv_3 (1x1)
+    (512, 512, 16, 8, 3, True, "conv_small<bf16,8,8,64,512>"),             # generator layer4 (low-resolution kernel, dot statistics)
+    (512, 512, 8, 8, 3, False, "conv_small<bf16,8,8,64,512>"),             # encoder block 7
+    (512, 512, 4, 8, 3, True, "conv_small<bf16,8,8,64,512>"),              # generator layer0
 ]
 
 
@@ -258,7 +272,7 @@ def test_data_gradient_fullsize(cof, cif, R, B, k, oscale, kernel):
     w = (_wgt(cof, cif, k, g) / math.sqrt(k * k * cif)).to(torch.bfloat16).float()
     s = (1.0 + 0.3 * torch.randn(B, cif, device=DEV, generator=g)) if oscale else None
     dots = ops.SlotStats(B, cif, DEV) if k == 3 else None
-    gx = ops.conv2d(gy, ops.pack_conv_weight(w, ops.PACK_DGRAD, ops.BF16, 1.0), cif, k, stats=dots, dot_src=xin if k == 3 else None,
+    gx = ops.conv2d(gy, _pack(w, ops.PACK_DGRAD, R, R), cif, k, stats=dots, dot_src=xin if k == 3 else None,
                     out_scale=s, gain=1.0 if k == 3 else 0.889)
     assert _kernel() == kernel
     tot = dots.buf.sum(0).cpu() if dots is not None else None
@@ -446,3 +460,28 @@ def test_conv_stream_ragged_shapes(B, H, W, cin, cout, flavour, monkeypatch):
         assert _stat_close(tot[:, :, 1], rd.sum((2, 3)), rd.abs().sum((2, 3))) < 1e-5
     assert _kernel().startswith("conv_stream<bf16,%d,%d," % (cin, cout)), _kernel()
     assert _one_rounding(nchw(y), ref) <= 0
+
+
+@pytest.mark.parametrize("H,W,B", [(22, 22, 16), (16, 12, 16), (11, 11, 16), (16, 16, 2)])
+def test_low_resolution_kernel_ragged_shapes(H, W, B):
+    """csrc/conv_small.hip on the shapes LPIPS' conv4_x / conv5_x see on the cropped images (176^2 -> 22^2 / 11^2, 256x192 -> 16x12:
+    tiles that hang over the image, both axes) at 512 channels: forward with bias + ReLU (VGG16 conv, lpips.LPIPS net='vgg') and
+    the data gradient with a residual addend (the tap gradient joining the chain)."""
+    from dge_amd import ops
+    import torch.nn.functional as F
+    g = _gen(9000 + H * 31 + W)
+    C = 512
+    x = _act(B, H, W, C, g)
+    w = (_wgt(C, C, 3, g) / math.sqrt(9 * C)).to(torch.bfloat16).float()
+    bias = 0.1 * torch.randn(C, device=DEV, generator=g)
+    y = ops.conv2d(x, _pack(w, ops.PACK_FWD, H, W), C, 3, bias=bias, act=ops.ACT_RELU)
+    assert _kernel() == "conv_small<bf16,8,8,64,512>"
+    gy = _act(B, H, W, C, g)
+    add = _act(B, H, W, C, g)
+    gx = ops.conv2d(gy, _pack(w, ops.PACK_DGRAD, H, W), C, 3, addend=add)
+    assert _kernel() == "conv_small<bf16,8,8,64,512>"
+    for b in SAMPLES(B):
+        ref = F.relu(F.conv2d(_nchw(x, b), w.cpu(), bias.cpu(), padding=1))
+        assert _one_rounding(_nchw(y, b), ref) <= 0, b
+        refg = CR.conv_dgrad(_nchw(gy, b), w.cpu()) + _nchw(add, b)
+        assert _one_rounding(_nchw(gx, b), refg) <= 0, b

@@ -126,6 +126,40 @@ def test_reconstruct_round_trip_runs_for_stylegan2():
     assert w2.shape == (2, 10, 512) and imgs2.shape == (2, 3, 64, 64) and torch.isfinite(imgs2).all()
 
 
+@pytest.mark.gpu
+def test_reconstruct_matches_the_oracle_round_trip():
+    """inferE.py:101-141 (G -> E -> G once) through `reconstruct()` against the CPU oracle on the same weights, z and injected
+    encoder noise: imgs1, w2, imgs2 (f32 path: tight; bf16: the storage bounds of the step test)."""
+    import dge_amd
+    from dge_amd.encoder import BE
+    from dge_amd.e_align import EAlignStep
+    from dge_amd.infer import reconstruct
+    from tests.golden import recipe as R
+    from tests.helpers import s2_shapes, enc_shapes
+    from oracle import ref_torch as O
+    PG = R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11)
+    PE = R.fill_encoder(enc_shapes(16, 64, 5), seed=31)
+    z = R.randn("rec.z", (2, 512), 3)
+    noises = [R.randn(f"rec.n{i}", s, 3) for i, s in enumerate(O.enc_noise_shapes(5, 2, 64))]
+    with torch.no_grad():
+        _, wp, imgs1 = O.s2_generator_eval(PG, z)
+        _, w2 = O.enc_forward(PE, imgs1, noises)
+        imgs2 = O.s2_synthesis(PG, w2)
+    rel = lambda a, b: ((a.detach().float().cpu() - b).abs().max() / b.abs().max()).item()
+    for cd, tol in (("f32", (5e-4, 2e-3, 2e-3)), ("bf16", (1.5e-2, 1.2e-2, 2.2e-2))):
+        G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype=cd).cuda()
+        G.load_state_dict(PG)
+        G.eval()
+        E = BE(startf=16, maxf=64, layer_count=5, compute_dtype=cd).cuda()
+        E.load_state_dict(PE)
+        with torch.no_grad():
+            r = reconstruct(EAlignStep(G, E, None, batch_size=2), z=z, noises=[n.cuda() for n in noises])
+        e = (rel(r["imgs1"], imgs1), rel(r["w2"], w2), rel(r["imgs2"], imgs2))
+        print(f"reconstruct {cd}: imgs1 {e[0]:.2e} w2 {e[1]:.2e} imgs2 {e[2]:.2e}")
+        assert e[0] < tol[0] and e[1] < tol[1] and e[2] < tol[2], (cd, e)
+        assert rel(r["w1"], wp) < 1e-5
+
+
 def _args(**kw):
     import argparse
     from dge_amd.e_align import add_model_args

@@ -1,6 +1,7 @@
 """Pins the oracle (oracle/ref_torch.py) against the golden vectors produced by the
 reference itself (tools/gen_golden.py).  CPU only."""
 import json
+import math
 import os
 
 import numpy as np
@@ -285,3 +286,85 @@ def test_conv_ref_folded_forms_equal_the_unfused_ones():
     b = CR.enc_conv(x, w, sc, sh, nzb, nw, bias)
     for u, v in zip(a, b):
         close(u, v, rtol=2e-5)
+
+
+def test_elem_ref_encoder_block_backward_equals_autograd_of_the_reference_restatement():
+    """oracle/elem_ref.py's stage-wise backward (what tests/test_fullsize_elem_gpu.py holds the HIP kernels to), composed the way
+    dge_amd/autograd_enc_bwd.py composes the kernels, against torch.autograd through oracle/ref_torch.enc_block - itself pinned
+    on the reference's BEBlock outputs above (model/E/E.py:50-85)."""
+    from oracle import elem_ref as ER, conv_ref as CR
+    torch.manual_seed(3)
+    C, C2, H = 8, 16, 12
+    pre = "decode_block.0."
+    P = {pre + "inver_mod1.weight": torch.randn(32, 2 * C) * 0.2, pre + "inver_mod1.bias": torch.randn(32) * 0.1,
+         pre + "inver_mod2.weight": torch.randn(32, 2 * C) * 0.2, pre + "inver_mod2.bias": torch.randn(32) * 0.1,
+         pre + "conv_1.weight": torch.randn(C, C, 3, 3) * 0.2, pre + "conv_2.weight": torch.randn(C2, C, 3, 3) * 0.2,
+         pre + "conv_3.weight": torch.randn(C2, C, 1, 1) * 0.3, pre + "conv_3.bias": torch.randn(C2) * 0.1,
+         pre + "noise_weight_1": torch.randn(1, C, 1, 1) * 0.3, pre + "bias_1": torch.randn(1, C, 1, 1) * 0.2,
+         pre + "noise_weight_2": torch.randn(1, C2, 1, 1) * 0.3, pre + "bias_2": torch.randn(1, C2, 1, 1) * 0.2}
+    P = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    x = torch.randn(1, C, H, H, dtype=torch.float64, requires_grad=True)
+    n1, n2 = torch.randn(1, 1, H, H, dtype=torch.float64), torch.randn(1, 1, H, H, dtype=torch.float64)
+    out, w1, w2 = O.enc_block(P, pre, x, n1, n2, last=False)
+    g_out, g_w1, g_w2 = torch.randn_like(out), torch.randn_like(w1), torch.randn_like(w2)
+    names = [pre + "bias_1", pre + "noise_weight_1", pre + "bias_2", pre + "noise_weight_2"]
+    ref = torch.autograd.grad((out * g_out).sum() + (w1 * g_w1).sum() + (w2 * g_w2).sum(), [x] + [P[n] for n in names])
+    # ---- the stage-wise composition (stored activations only, as the HIP path has them)
+    with torch.no_grad():
+        m1, v1 = O.enc_stats(x)
+        x1 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(O.inorm(x, m1, v1), P[pre + "conv_1.weight"], padding=1)
+                                            + P[pre + "noise_weight_1"] * n1 + P[pre + "bias_1"], 0.2)
+        m2, v2 = O.enc_stats(x1)
+        a2 = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(O.inorm(x1, m2, v2), P[pre + "conv_2.weight"], padding=1)
+                                            + P[pre + "noise_weight_2"] * n2 + P[pre + "bias_2"], 0.2)
+    gp2, gb2, gn2 = ER.enc_act_pool_bwd(a2, g_out, n2[0, 0], 0.111 * 0.25)
+    g_yn2 = CR.conv_dgrad(gp2, P[pre + "conv_2.weight"].detach())
+    gms2 = (g_w2 @ P[pre + "inver_mod2.weight"].detach())[0]
+    g_pre1, gb1, gn1 = ER.enc_in_bwd(x1, g_yn2, gms2[:C], gms2[C:], noise=n1[0, 0], act=True)
+    g_yn1 = CR.conv_dgrad(g_pre1, P[pre + "conv_1.weight"].detach())
+    extra = CR.conv_dgrad(g_out, P[pre + "conv_3.weight"].detach()) * 0.889
+    gms1 = (g_w1 @ P[pre + "inver_mod1.weight"].detach())[0]
+    g_x, _, _ = ER.enc_in_bwd(x.detach(), g_yn1, gms1[:C], gms1[C:], extra=extra, extra_scale=0.25)
+    got = [g_x, gb1, gn1, gb2, gn2]
+    for a, b, nm in zip(got, ref, ["x"] + names):
+        assert torch.allclose(a.reshape(-1), b.reshape(-1), rtol=1e-9, atol=1e-10), nm
+
+
+def test_elem_ref_generator_tails_equal_autograd_of_the_reference_restatement():
+    """modconv tail / toRGB stages of oracle/elem_ref.py against autograd through oracle/ref_torch.s2_modconv (pinned on the
+    reference's ModulateConvBlock outputs above; model/stylegan2_generator.py:855-922, :515-522)."""
+    from oracle import elem_ref as ER, conv_ref as CR
+    torch.manual_seed(4)
+    Ci, Co, H = 8, 8, 10
+    P = {"L.weight": torch.randn(Co, Ci, 3, 3), "L.bias": torch.randn(Co) * 0.3, "L.noise_strength": torch.tensor(0.4),
+         "L.noise": torch.randn(1, 1, H, H), "L.style.weight": torch.randn(Ci, 512) * 0.5, "L.style.bias": torch.randn(Ci) * 0.2,
+         "T.weight": torch.randn(3, Co, 1, 1), "T.bias": torch.randn(3) * 0.1, "T.style.weight": torch.randn(Co, 512) * 0.5,
+         "T.style.bias": torch.randn(Co) * 0.2}
+    x = torch.randn(1, Ci, H, H, requires_grad=True)
+    wl = torch.randn(1, 512)
+    y, s = O.s2_modconv(P, "L", x, wl)
+    prev = torch.randn(1, 3, H // 2, H // 2)
+    rgb, srgb = O.s2_modconv(P, "T", y, wl, demodulate=False, add_noise=False, act="linear")
+    img = rgb + O.s2_upsample_skip(prev)
+    gimg = torch.randn_like(img)
+    (gx_ref,) = torch.autograd.grad((img * gimg).sum(), x)
+    # stage-wise
+    wscale_t = 1.0 / math.sqrt(Co)
+    img2 = ER.torgb(y.detach(), P["T.weight"].reshape(3, Co), srgb[0].detach(), P["T.bias"], wscale_t, prev)
+    assert torch.allclose(img2, img.detach(), rtol=1e-5, atol=1e-5)
+    gy, gs = ER.torgb_bwd(y.detach(), P["T.weight"].reshape(3, Co), srgb[0].detach(), wscale_t, gimg)
+    wscale = 1.0 / math.sqrt(9 * Ci)
+    Wm = P["L.weight"] * wscale
+    d = torch.rsqrt(((Wm[None] * s.detach()[:, None, :, None, None]) ** 2).sum(dim=(2, 3, 4)) + 1e-8)[0]
+    g_yraw, R = ER.modconv_tail_bwd(y.detach(), gy, d, P["L.noise"][0, 0], math.sqrt(2.0))
+    gx = CR.conv_dgrad(g_yraw.float(), Wm) * s.detach()[:, :, None, None]
+    assert torch.allclose(gx, gx_ref, rtol=2e-4, atol=2e-5)
+    # the noise-strength gradient is R[:,1] summed over channels; bias gradient R[:,2] (bscale 1)
+    ns = P["L.noise_strength"].clone().requires_grad_(True)
+    b = P["L.bias"].clone().requires_grad_(True)
+    P2 = dict(P); P2["L.noise_strength"] = ns; P2["L.bias"] = b
+    y2, _ = O.s2_modconv(P2, "L", x.detach(), wl)
+    rgb2, _ = O.s2_modconv(P2, "T", y2, wl, demodulate=False, add_noise=False, act="linear")
+    gns, gb = torch.autograd.grad((rgb2 * gimg).sum(), (ns, b))
+    assert abs(float(R[:, 1].sum()) - float(gns)) < 2e-4 * abs(float(gns)) + 1e-5
+    assert torch.allclose(R[:, 2].float(), gb, rtol=2e-4, atol=2e-5)
