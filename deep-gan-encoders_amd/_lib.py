@@ -19,6 +19,8 @@ class ConvDesc(C.Structure):
         ("ksize", C.c_int), ("up", C.c_int), ("in_s2d", C.c_int), ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int),
         ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float), ("add_scale", C.c_float),
         ("dtype", C.c_int), ("in_up2", C.c_int), ("in_relu", C.c_int), ("stats_slots", C.c_int), ("w_layout", C.c_int),
+        ("prep", C.c_int), ("prep_gain", C.c_float), ("prep_noise", C.c_void_p), ("prep_ns", C.c_void_p), ("prep_noise_batch", C.c_int),
+        ("prep_stats", C.c_void_p),
     ]
 
 
@@ -27,6 +29,8 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "dge_conv2d": [C.POINTER(ConvDesc), _P],
     "dge_conv_small_supported": [_I, _I, _I, _I, _I, _I, _I, _I],
+    "dge_torgb_bwd_prep": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P],
+    "dge_demod_bwd_prep": [_P, _I, _P, _P, _P, _I, _I, _F, _P],
     "dge_sum_slots": [_P, _P, _I, _I, _I, _P],
     "dge_sum_slots_planar": [_P, _P, _I, _I, _I, _P],
     "dge_set_deterministic": [_I],

@@ -122,7 +122,13 @@ def _dgrad_weight(L, dtype):
 
 
 def synthesis_backward(mod, wp, saved, g_image):
-    """d(image)/d(wp) contracted with g_image [B,3,R,R] -> g_wp [B,num_layers,512]."""
+    """d(image)/d(wp) contracted with g_image [B,3,R,R] -> g_wp [B,num_layers,512].
+
+    The gradient travels down the chain as g_z (w.r.t. the pre-activation z = yraw*d + noise*ns + bias of each layer,
+    stylegan2_generator.py:908-921): the data-gradient conv of layer i+1 differentiates layer i's noise / bias / lrelu tail in its own
+    epilogue (it streams layer i's stored output as `dot_src` anyway) and also leaves the two per-(b,c) sums of the demodulation
+    gradient there; the demodulation factor d multiplies g_z in the NEXT conv's prologue.  `fused=False` (deterministic mode) runs
+    the same math with the tail backward as a pass of its own (dge_modconv_bwd_prep)."""
     B = wp.shape[0]
     dev = wp.device
     nl = mod.num_layers
@@ -130,10 +136,16 @@ def synthesis_backward(mod, wp, saved, g_image):
     layers = saved["layers"]
     dt = ops.dtype_of(saved["const"])
     g_img = g_image.float().contiguous()
+    fused = not ops.is_deterministic()
     # top layer: its output only feeds the last toRGB (image_k = rgb_k + up(image_{k-1}), :515-522)
     top = nl - 2
-    Ot = getattr(mod, f"output{top // 2}")
-    g_x, g_srgb = ops.torgb_bwd(g_img, layers[top]["y"], Ot.weight.detach().reshape(3, -1), saved["rgb"][top // 2]["s"], Ot.wscale)
+    Lt, Ot = getattr(mod, f"layer{top}"), getattr(mod, f"output{top // 2}")
+    P = None
+    if fused:
+        g_x, g_srgb, P = ops.torgb_bwd_prep(g_img, layers[top]["y"], Ot.weight.detach().reshape(3, -1), saved["rgb"][top // 2]["s"], Ot.wscale,
+                                            layers[top]["noise"], Lt.noise_strength.detach().reshape(1), Lt.gain)
+    else:
+        g_x, g_srgb = ops.torgb_bwd(g_img, layers[top]["y"], Ot.weight.detach().reshape(3, -1), saved["rgb"][top // 2]["s"], Ot.wscale)
     ops.linear_t(g_srgb, Ot.style.weight.detach(), g_wp[:, top + 1], scale=Ot.style.wscale, accumulate=True)
     if top // 2 > 0:
         g_img = ops.up2_bwd(g_img)
@@ -141,8 +153,11 @@ def synthesis_backward(mod, wp, saved, g_image):
         L = getattr(mod, f"layer{i}")
         rec = layers[i]
         # ---- backward through noise/bias/act/demod of layer i
-        R = ops.zeros((B, L.out_c, 3), dev)
-        g_y = ops.modconv_bwd_prep(g_x, rec["y"], rec["d"], rec["noise"], L.gain, R)
+        if P is not None:
+            g_y, d_in = g_x, rec["d"]                  # g_x is g_z already (with its sums in P); d joins in the conv prologue
+        else:
+            R = ops.zeros((B, L.out_c, 3), dev)
+            g_y, d_in = ops.modconv_bwd_prep(g_x, rec["y"], rec["d"], rec["noise"], L.gain, R), None
         x_in = saved["const"] if i == 0 else layers[i - 1]["y"]
         # toRGB gradient of the previous (even) layer joins through the epilogue addend
         addend = None
@@ -155,16 +170,26 @@ def synthesis_backward(mod, wp, saved, g_image):
             if kp > 0:
                 g_img = ops.up2_bwd(g_img)
         st = ops.zeros((B, L.in_c, 2), dev)
-        g_xprev = ops.conv2d(g_y, _dgrad_weight(L, dt), L.in_c, 3, in_s2d=L.up, out_scale=rec["s"], addend=addend,
-                             add_scale=1.0, stats=st, dot_src=x_in)
+        prep, P_next = None, None
+        # (the space-to-depth data gradient of a narrow up layer - layer 15: 64 -> 32 channels - loses more in its 64-wide tile
+        #  than the separate pass costs: measured 890 vs 747 us; tools/perf_prep.py)
+        if fused and i >= 1 and not (L.up and L.in_c < 128):
+            Lp = getattr(mod, f"layer{i - 1}")
+            P_next = ops.SlotStats(B, L.in_c, dev)
+            prep = dict(gain=Lp.gain, noise=layers[i - 1]["noise"], ns=Lp.noise_strength.detach().reshape(1), stats=P_next)
+        g_xprev = ops.conv2d(g_y, _dgrad_weight(L, dt), L.in_c, 3, in_s2d=L.up, in_scale=d_in, out_scale=rec["s"], addend=addend,
+                             add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
         # ---- style / demodulation gradients -> g_wp[:, i]
-        t = ops.demod_bwd(R, rec["d"], L.bias.detach(), L.noise_strength.detach().reshape(1), L.bscale)
+        if P is not None:
+            t = ops.demod_bwd_prep(P, rec["d"], L.bias.detach(), L.bscale)
+        else:
+            t = ops.demod_bwd(R, rec["d"], L.bias.detach(), L.noise_strength.detach().reshape(1), L.bscale)
         _, wsq = L._prepared(dt)
         gs_view = st.view(B, -1)      # [B, 2*Cin]: element (b, 2*i) = g_s[b,i]
         ops.linear_t(t, wsq, gs_view, mul=rec["s"], accumulate=True, incy=2, ldy=2 * L.in_c)
         ops.linear_t(gs_view, L.style.weight.detach(), g_wp[:, i], scale=L.style.wscale, accumulate=True, incx=2,
                      ldx=2 * L.in_c, O=L.in_c)
-        g_x = g_xprev
+        g_x, P = g_xprev, P_next
     return g_wp
 
 

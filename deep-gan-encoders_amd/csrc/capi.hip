@@ -67,6 +67,11 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.act = d->act; p.bias_scale = d->bias_scale; p.gain = d->gain; p.add_scale = d->add_scale;
     p.tiles_x = p.tiles_y = 0;
     p.w_frag = d->w_layout == 1 ? 1 : 0;
+    p.prep = d->prep ? 1 : 0;
+    p.prep_gain = d->prep_gain; p.prep_noise = d->prep_noise; p.prep_ns = d->prep_ns; p.prep_stats = d->prep_stats;
+    p.prep_noise_bstride = d->prep_noise_batch > 1 ? OH * OW : 0;
+    DGE_CHECK(!d->prep || (d->dot_src && d->prep_stats && d->prep_gain > 0.f && !d->up), "conv2d: prep needs dot_src, prep_stats, a positive prep_gain and no up mode");
+    DGE_CHECK(!d->prep || !dge_get_deterministic(), "conv2d: the fused tail backward (prep) is not offered in deterministic mode; run dge_modconv_bwd_prep");
     DGE_CHECK(d->w_layout == 0 || d->w_layout == 1, "conv2d: bad w_layout %d", d->w_layout);
     p.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
     return dge_conv_launch(p, d->dtype, d->ksize, s);

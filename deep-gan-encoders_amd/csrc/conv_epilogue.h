@@ -12,7 +12,9 @@
 // `lds`: base of the workgroup's LDS (staging area of wave w at lds + w*32*C::ESTR; all main-loop reads are done);
 // `ldsN`: the noise tile staged by the prologue.  Only waves 0 .. WM*WN-1 carry tiles (`carrier`); in deterministic mode
 // every thread of the workgroup must call.
-template <typename T, class C, int TH, int TW, int BN, int WM, int WN, int NTHREADS>
+// PREP (compile time): the fused tail backward of ConvParams::prep - its 16 extra per-lane sums cost the instantiations that
+// never use it a wave of occupancy, so they are built without it.
+template <typename T, class C, int TH, int TW, int BN, int WM, int WN, int NTHREADS, bool PREP = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&acc)[C::MT][C::NT], unsigned char* lds, const float* ldsN,
                                               int b, int x0, int y0, int bn0, int ntile, int vbid, int tx_i, int ty_i,
                                               int wave, int lane, int tid, bool carrier) {
@@ -74,12 +76,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
         const float bia = (p.bias && ovalid) ? p.bias[o] * p.bias_scale * p.gain : 0.f;
         const float nw = (p.noise && ovalid) ? p.noise_w[o * p.noise_w_stride] * p.gain : 0.f;
         float ssum = 0.f, ssq = 0.f;
-        float posc[EP16], ps0[EP16], ps1[EP16];
+        float posc[EP16], ps0[EP16], ps1[EP16], pt0[PREP ? EP16 : 1], pt1[PREP ? EP16 : 1];
 #pragma unroll
         for (int e = 0; e < EP16; e++) {
             posc[e] = (DOT && p.out_scale && cvalid) ? p.out_scale[b * p.Cout + oc + e] : 1.f;
             ps0[e] = 0.f; ps1[e] = 0.f;
+            if constexpr (PREP) { pt0[e] = 0.f; pt1[e] = 0.f; }
         }
+        // fused tail backward of the layer below (ConvParams::prep): g -> g_z and the two sums of its demodulation gradient
+        const bool prep = PREP && p.prep && DOT;
+        const float pg_pos = p.prep_gain, pg_neg = 0.2f * p.prep_gain, pz_pos = 1.f / p.prep_gain, pz_neg = 1.f / (0.2f * p.prep_gain);
+        const float pns = (prep && p.prep_noise && p.prep_ns) ? p.prep_ns[0] : 0.f;
+        const bool pnz = prep && p.prep_noise;                       // its plane sits in the noise tile (staged by the kernel's prologue)
         float* estw = (float*)(est + 4 * lh * C::ESTR) + l31;                     // + ((r&3) + 8(r>>2)) rows
         const float* nzb = ldsN + phase * C::BM + wm * C::WTM + 4 * lh;          // + i*32 + 8(r>>2) + (r&3)
         StaticFor<C::MT>::run([&](auto ic) {
@@ -127,8 +135,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
                         *(uint4*)&f[e4 * 4] = *(const uint4*)(est + ml * C::ESTR + chq * EP16 * 4 + e4 * 16);
                     const int off = (oy * OW + ox) * p.Cout + oc;
                     if (DOT || ADD) {
+                        float d[EP16];
                         if (DOT) {
-                            float d[EP16];
                             unpack16(*(const uint4*)(DOTb + off), d, (T*)nullptr);
 #pragma unroll
                             for (int e = 0; e < EP16; e++) { ps0[e] += f[e] * d[e]; ps1[e] += f[e]; f[e] *= posc[e]; }
@@ -138,6 +146,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
                             unpack16(*(const uint4*)(ADDb + off), ad, (T*)nullptr);
 #pragma unroll
                             for (int e = 0; e < EP16; e++) f[e] += p.add_scale * ad[e];
+                        }
+                        if constexpr (PREP) if (prep) {
+                            const float nzs = pnz ? pns * ldsN[m] : 0.f;
+#pragma unroll
+                            for (int e = 0; e < EP16; e++) {
+                                const bool pos = d[e] > 0.f;
+                                const float gz = f[e] * (pos ? pg_pos : pg_neg);
+                                const float zt = d[e] * (pos ? pz_pos : pz_neg) - nzs;
+                                pt0[e] = fmaf(gz, zt, pt0[e]); pt1[e] += gz;
+                                f[e] = gz;
+                            }
                         }
                         if (post_stats && !DOT) {
 #pragma unroll
@@ -159,6 +178,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
                 } else {
                     atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2, ssum);
                     atomicAdd(STATS + ((size_t)b * p.Cout + o) * 2 + 1, ssq);
+                }
+            }
+        }
+        if constexpr (PREP) if (prep && p.prep_stats) {
+            float* __restrict__ PST = p.prep_stats + (size_t)(vbid % p.stats_slots) * p.B * p.Cout * 2;
+#pragma unroll
+            for (int e = 0; e < EP16; e++) {
+#pragma unroll
+                for (int msk = CPR; msk < 64; msk <<= 1) { pt0[e] += __shfl_xor(pt0[e], msk, 64); pt1[e] += __shfl_xor(pt1[e], msk, 64); }
+                if (lane < CPR && cvalid) {
+                    atomicAdd(PST + ((size_t)b * p.Cout + oc + e) * 2, pt0[e]);
+                    atomicAdd(PST + ((size_t)b * p.Cout + oc + e) * 2 + 1, pt1[e]);
                 }
             }
         }

@@ -112,7 +112,7 @@ struct ConvCfg {
     static constexpr int MINW = (LDS_BYTES <= 53 * 1024 && MT * NT < 8) ? 3 : (LDS_BYTES <= 80 * 1024 ? 2 : 1);
 };
 
-template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN, bool PREP>
 __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)) void conv_igemm_kernel(ConvParams p) {
     using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>;
     constexpr int EP16 = Elem<T>::PER16;
@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
         const int ay = ph >> 1, ax = ph & 1;
         const int coff = cb + achunk * EP16;
         if (affine) {
-            const int ci = b * p.Cin + cbase + achunk * EP16;
+            // (space-to-depth reads: the affine is per physical channel, [B, Cin/4] - the four phases of a channel share it)
+            const int ci = b * cphys + cb + achunk * EP16;
             if (p.in_scale) {
 #pragma unroll
                 for (int e4 = 0; e4 < EP16 / 4; e4++) *(float4*)&asc[e4 * 4] = *(const float4*)(p.in_scale + ci + e4 * 4);
@@ -281,14 +282,17 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     for (int q = 0; q < C::NBUF - 1; q++)
         if (q < nstages) dma_b(q / KS, q % KS, q);
     load_a(0);
-    if (p.noise) {
+    // noise tile of the epilogue: this layer's plane (forward), or - fused tail backward, ConvParams::prep - the plane of the layer below
+    const float* __restrict__ nz_src = p.prep ? p.prep_noise : p.noise;
+    if (nz_src) {
+        const int nz_bs = p.prep ? p.prep_noise_bstride : p.noise_bstride;
         const int OHn = p.up ? 2 * p.H : p.H, OWn = p.up ? 2 * p.W : p.W;
         const int nph = p.up ? 4 : 1;
         for (int idx = tid; idx < nph * C::BM; idx += 256) {
             const int m = idx % C::BM, ph = idx / C::BM;
             const int gy = y0 + m / TW, gx = x0 + m % TW;
             const int oy = p.up ? 2 * gy + (ph >> 1) : gy, ox = p.up ? 2 * gx + (ph & 1) : gx;
-            ldsN[idx] = (gy < p.H && gx < p.W) ? p.noise[(size_t)b * p.noise_bstride + (size_t)oy * OWn + ox] : 0.f;
+            ldsN[idx] = (gy < p.H && gx < p.W) ? nz_src[(size_t)b * nz_bs + (size_t)oy * OWn + ox] : 0.f;
         }
     }
     store_a();
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     }
     // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
     // LDS is re-used as the transpose buffer from here (all reads done: barrier above); the noise tile at its end stays valid
-    conv_epilogue<T, C, TH, TW, BN, WM, WN, 256>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
+    conv_epilogue<T, C, TH, TW, BN, WM, WN, 256, PREP>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
 }
 
 // ------------------------------------------------------------------------- dispatch
@@ -371,8 +375,14 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     p.tiles_y = (p.H + TH - 1) / TH;
     const int ntiles = (p.Ntot + BN - 1) / BN;
     const long grid = (long)p.tiles_x * p.tiles_y * p.B * ntiles;
-    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN, p.prep ? "+prep" : "");
+    if constexpr (KS == 3) {         // the fused tail backward exists for the 3x3 data gradients only
+        if (p.prep) hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN, true>), dim3((unsigned)grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    } else {
+        DGE_CHECK(!p.prep, "conv: prep is offered for 3x3 launches only");
+        hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN, false>), dim3((unsigned)grid), dim3(256), 0, s, p);
+    }
     DGE_LAUNCH_CHECK("conv_igemm");
     return 0;
 }

@@ -30,6 +30,17 @@ struct ConvParams {
     int tiles_x, tiles_y;     // filled by the launcher
     int dbg;                  // ablation switches for tuning (DGE_CONV_DBG), 0 in production
     int w_frag;               // 1: `w` is in MFMA-fragment order (DGE_PACK_FRAG): the launch must go to conv_small.hip
+    // Fused backward of the PRODUCING layer's tail (data gradients of the StyleGAN2 synthesis chain, needs dot_src): dot_src is the
+    // stored activation x = lrelu(z)*prep_gain of the layer below, z = yraw*d + noise*ns + bias (stylegan2_generator.py:908-921).
+    // The conv result g = acc*out_scale + addend is the gradient w.r.t. x; with prep the kernel stores g_z = g * prep_gain * lrelu'(x)
+    // instead and adds per (b, c): prep_stats[.., 0] += sum g_z * (z - ns*noise), prep_stats[.., 1] += sum g_z  (the two sums the
+    // demodulation / bias gradient of that layer needs; dge_modconv_bwd_prep computes them in a pass of its own).
+    int prep;
+    float prep_gain;
+    const float* prep_noise;  // [nB,OH,OW] noise plane of the layer below, or null
+    const float* prep_ns;     // its noise strength (device scalar), or null
+    int prep_noise_bstride;   // 0 (shared plane) or OH*OW
+    float* prep_stats;        // [slots][B,Cout,2], pre-zeroed (same slot count as `stats`)
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);

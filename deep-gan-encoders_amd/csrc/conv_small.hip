@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x16_t mma(const uint4& a, const uint4& b, f32x16_t
 }
 
 // KQ = K steps (16 channels) per wave and tap = Cin / 64
-template <int KQ>
+template <int KQ, bool PREP>
 __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
     constexpr int CIN = KQ * 64, CH = CIN / 8;                 // CH = 16-byte chunks per pixel
     constexpr int PSTR = pstr_of(CIN), RPITCH = rpitch_of(CIN);
@@ -73,8 +73,9 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
     // ---- weight stream: fragment blocks ((tap * N/32 + n32) * KST + kstep) of 1 KiB, lane-linear
     const unsigned char* wbase = (const unsigned char*)p.w + ((size_t)(bn0 / 32 + nt) * KST + kq * KQ) * 1024 + lane * 16;
     const size_t tap_stride = (size_t)(p.Ntot / 32) * KST * 1024;
-    // PF taps (PF * KQ KiB per wave) are requested ahead of the MFMAs: 8 waves x 16 KB cover the loaded L2 latency at ~100 GB/s per CU
-    constexpr int PF = 2;
+    // PF taps (PF * KQ KiB per wave) are requested ahead of the MFMAs.  In a training step the weights of a layer are L2-cold (they
+    // come from HBM at ~2.5 us): 8 waves x 24 KB in flight per CU; measured in-step 25 us with PF = 2 against 14 us on hot weights
+    constexpr int PF = KQ >= 8 ? 3 : 4;
     uint4 bw[PF + 1][KQ];
 #pragma unroll
     for (int t = 0; t < PF; t++)
@@ -105,14 +106,16 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
             if (inside) v[i] = *(const uint4*)(Xb + (gy * p.W + gx) * CIN + chunk * 8);
             inmask |= (inside ? 1u : 0u) << i;
         }
-        if (p.noise) {
+        const float* __restrict__ nz_src = p.prep ? p.prep_noise : p.noise;      // (prep: the plane of the layer below)
+        if (nz_src) {
+            const int nz_bs = p.prep ? p.prep_noise_bstride : p.noise_bstride;
             const int OWn = p.up ? 2 * p.W : p.W;
             const int nph = p.up ? 4 : 1;
             for (int idx = tid; idx < nph * SmallCfg::BM; idx += 512) {
                 const int m = idx % SmallCfg::BM, ph = idx / SmallCfg::BM;
                 const int gy = y0 + m / TW, gx = x0 + m % TW;
                 const int oy = p.up ? 2 * gy + (ph >> 1) : gy, ox = p.up ? 2 * gx + (ph & 1) : gx;
-                ldsN[idx] = (gy < p.H && gx < p.W) ? p.noise[(size_t)b * p.noise_bstride + (size_t)oy * OWn + ox] : 0.f;
+                ldsN[idx] = (gy < p.H && gx < p.W) ? nz_src[(size_t)b * nz_bs + (size_t)oy * OWn + ox] : 0.f;
             }
         }
 #pragma unroll
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
             tile[0][0][r] = s;
         }
     }
-    conv_epilogue<bf16_t, SmallCfg, TH, TW, BN, 2, 2, 512>(p, tile, lds + RED_BYTES, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i,
+    conv_epilogue<bf16_t, SmallCfg, TH, TW, BN, 2, 2, 512, PREP>(p, tile, lds + RED_BYTES, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i,
                                                             wave, lane, tid, carrier);
 }
 
@@ -215,9 +218,14 @@ int dge_conv_small_launch(const ConvParams& p0, hipStream_t s) {
     p.tiles_y = (p.H + TH - 1) / TH;
     const long grid = (long)p.tiles_x * p.tiles_y * p.B * (p.Ntot / BN);
     DGE_CHECK(grid > 0 && grid < (1L << 31), "conv_small: bad grid");
-    dge_note_kernel("conv_small<bf16,8,8,64,%d>", p.Cin);
-    if (p.Cin == 512) hipLaunchKernelGGL(conv_small_kernel<8>, dim3((unsigned)grid), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL(conv_small_kernel<4>, dim3((unsigned)grid), dim3(512), 0, s, p);
+    dge_note_kernel("conv_small<bf16,8,8,64,%d>%s", p.Cin, p.prep ? "+prep" : "");
+    if (p.Cin == 512) {
+        if (p.prep) hipLaunchKernelGGL((conv_small_kernel<8, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_small_kernel<8, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    } else {
+        if (p.prep) hipLaunchKernelGGL((conv_small_kernel<4, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_small_kernel<4, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    }
     DGE_LAUNCH_CHECK("conv_small");
     return 0;
 }

@@ -107,11 +107,13 @@ template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigne
                      "buffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds" : : "v"(voff), "s"(m0v), "s"(rs), "v"(voff1) : "memory");
 }
 
-enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3 };
+enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4 };
 // FL_GEN:       uniform noise weight (or none), no input shift, no statistics            (generator forward, LPIPS convs)
 // FL_ENC:       per-channel noise weight, folded instance-norm shift with border terms    (encoder forward) - superset of GEN
 // FL_ENC_STATS: + (sum, sum of squares) of the output per (sample, channel)
 // FL_DOT:       data-gradient mode: y = acc * out_scale, statistics (sum acc * dot_src, sum acc); no bias / noise / activation
+// FL_DOT_PREP:  FL_DOT + the tail backward of the layer that produced dot_src (ConvParams::prep): y = g_z, statistics
+//               (sum acc * dot_src, -) and prep_stats (sum g_z * (z - ns*noise), sum g_z); the noise ring carries that layer's plane
 
 template <int CIN, int COUT, int FL>
 struct SC {
@@ -125,8 +127,9 @@ struct SC {
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
-    static constexpr bool DOT = FL == FL_DOT, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS;
-    static constexpr bool NOISE = !DOT;
+    static constexpr bool PREP = FL == FL_DOT_PREP;
+    static constexpr bool DOT = FL == FL_DOT || PREP, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS;
+    static constexpr bool NOISE = !DOT || PREP;
 #ifndef DGE_SC_NR
 #define DGE_SC_NR 6
 #define DGE_SC_D 2
@@ -158,8 +161,9 @@ struct SC {
     static constexpr int TBYTES = 32 * MTW * 16 * 4;
     static constexpr int DUMMY_OFF = T_OFF + TEAM * TBYTES;
     static constexpr int LDS_BYTES = DUMMY_OFF + (TEAM == 2 ? 1024 : 0);
-    static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + 36;
-    static constexpr int WPE = NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2);
+    static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + (PREP ? 16 : 0) + 36;
+    // (the 64-channel prep flavour holds 144 weight + 48 sum registers: at two waves per SIMD it spilled 360 B per lane)
+    static constexpr int WPE = (PREP && CIN == 64) ? 1 : (NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2));
     static_assert(D <= NR - 3, "the slot of the row being fetched must be dead");
     static_assert((D - 1) * LPR + 1 < 64, "vmcnt range");
 };
@@ -206,8 +210,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     const unsigned xrow_bytes = (unsigned)p.W * C::PXB, yrow_bytes = (unsigned)p.W * C::CPB;
     const unsigned long long Xb = (unsigned long long)p.x + (unsigned long long)b * p.H * xrow_bytes;
     unsigned char* __restrict__ Yb = (unsigned char*)p.y + (size_t)b * p.H * yrow_bytes;
-    const unsigned long long NZb = p.noise ? (unsigned long long)(p.noise + (size_t)b * p.noise_bstride) : Xb;
-    const unsigned nzrow_bytes = p.noise ? (unsigned)p.W * 4 : 0;
+    const float* __restrict__ nzsrc = C::PREP ? p.prep_noise : p.noise;      // (prep: the plane of the layer whose tail is differentiated)
+    const unsigned long long NZb = nzsrc ? (unsigned long long)(nzsrc + (size_t)b * (C::PREP ? p.prep_noise_bstride : p.noise_bstride)) : Xb;
+    const unsigned nzrow_bytes = nzsrc ? (unsigned)p.W * 4 : 0;
     const unsigned long long DOTb = C::DOT ? (unsigned long long)p.dot_src + (unsigned long long)b * p.H * yrow_bytes : Xb;
 
     // ---- DMA lane offsets.  x row: 16-byte unit u = lane (+ 64 per piece) = (halo pixel, chunk); source chunk swizzled
@@ -256,7 +261,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     // noise rows q .. q+7 of the segment (one piece; NR of them are used) into buffer `buf_off` (0 / 1024)
     auto issue_noise = [&](int q, unsigned buf_off) {
         const int gy = r0 + q;
-        const bool v = p.noise != nullptr && gy < p.H && q < rows;
+        const bool v = nzsrc != nullptr && gy < p.H && q < rows;
         const rsrc_t rn = make_rsrc(NZb + (unsigned long long)(v ? gy : 0) * nzrow_bytes, v ? (unsigned)(p.H - gy) * nzrow_bytes : 0u);
         dma_piece(nvoff, rn, lds0 + C::N_OFF + wave * C::NRING + buf_off);
     };
@@ -374,13 +379,20 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     // output byte offset of this lane inside an image row: pixel, this wave's channels, this lane's first run of 8
     const unsigned yoff = (unsigned)gx * C::CPB + (unsigned)(wave * C::MTW * 32 * 2) + kh * 16;
 
-    float s0[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s1[C::MTW][(C::STATS || C::DOT) ? 16 : 1];
+    float s0[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s1[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s2[C::PREP ? 16 : 1];
     if constexpr (C::STATS || C::DOT) {
 #pragma unroll
         for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; }
     }
+    if constexpr (C::PREP) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) s2[r] = 0.f;
+    }
+    // prep: x = lrelu(z)*gain of the layer below -> g_z = g * gain * lrelu'(x), z = x / (gain * lrelu'(x))
+    const float pg_pos = p.prep_gain, pg_neg = 0.2f * p.prep_gain, pz_pos = 1.f / p.prep_gain, pz_neg = 1.f / (0.2f * p.prep_gain);
+    const float pns = (C::PREP && p.prep_noise && p.prep_ns) ? p.prep_ns[0] : 0.f;
 
     // ---- one output row.  I = position in the ring period (compile time): halo rows in slots I, I+1, I+2 (mod NR)
 #ifdef DGE_SC_TIMING
@@ -497,15 +509,27 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 uint4 dd[2];
                 dd[0] = lds_u4(doff[0] + (I % C::DR) * C::DROWB);
                 if constexpr (NREG == 16) dd[1] = lds_u4(doff[1] + (I % C::DR) * C::DROWB);
+                const float nzs = C::PREP ? pns * nz : 0.f;
 #pragma unroll
                 for (int q = 0; q < NREG / 8; q++) {
                     float d[8];
                     unpack16(dd[q], d, (bf16_t*)nullptr);
 #pragma unroll
-                    for (int e = 0; e < 8; e++) { s0[mt][8 * q + e] = fmaf(v[8 * q + e], d[e], s0[mt][8 * q + e]); s1[mt][8 * q + e] += v[8 * q + e]; }
+                    for (int e = 0; e < 8; e++) {
+                        const int r = 8 * q + e;
+                        s0[mt][r] = fmaf(v[r], d[e], s0[mt][r]);
+                        if constexpr (C::PREP) {
+                            const bool pos = d[e] > 0.f;
+                            const float gz = v[r] * oscv[r] * (pos ? pg_pos : pg_neg);
+                            const float zt = d[e] * (pos ? pz_pos : pz_neg) - nzs;
+                            s2[r] = fmaf(gz, zt, s2[r]); s1[mt][r] += gz;
+                            v[r] = gz;
+                        } else {
+                            s1[mt][r] += v[r];
+                            v[r] *= oscv[r];
+                        }
+                    }
                 }
-#pragma unroll
-                for (int r = 0; r < NREG; r++) v[r] *= oscv[r];
             } else {
 #pragma unroll
                 for (int r = 0; r < NREG; r++) {
@@ -579,8 +603,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 #pragma unroll
             for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) { if (!pv) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; } }
+                for (int r = 0; r < 16; r++) { if (!pv) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; if constexpr (C::PREP) s2[r] = 0.f; } }
             float* __restrict__ ST = p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2;
+            float* __restrict__ PST = (C::PREP && p.prep_stats) ? p.prep_stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2 : nullptr;
             // deterministic mode: domain = sample, slot = (segment, strip), the team's waves fill disjoint channel ranges of it
             const bool det = det_on();
             float* dvec = det ? det_slot(b, p.B, seg * nstrips + strip, nseg * nstrips, COUT * 2) : nullptr;
@@ -588,16 +613,22 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
                 for (int r = 0; r < NREG; r++) {
-                    float a = s0[mt][r], c = s1[mt][r];
+                    float a = s0[mt][r], c = s1[mt][r], t2 = C::PREP ? s2[r] : 0.f;
 #pragma unroll
-                    for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m, 64); c += __shfl_xor(c, m, 64); }
+                    for (int m = 1; m < 32; m <<= 1) {
+                        a += __shfl_xor(a, m, 64); c += __shfl_xor(c, m, 64);
+                        if constexpr (C::PREP) t2 += __shfl_xor(t2, m, 64);
+                    }
                     if (n31 == 0) {
                         const int ch = wave * C::MTW * 32 + chan_of_reg(mt, r);
-                        if (det) { dvec[ch * 2] = a; dvec[ch * 2 + 1] = c; }
+                        if constexpr (C::PREP) {        // (the launcher refuses prep in deterministic mode)
+                            atomicAdd(ST + ch * 2, a);
+                            if (PST) { atomicAdd(PST + ch * 2, t2); atomicAdd(PST + ch * 2 + 1, c); }
+                        } else if (det) { dvec[ch * 2] = a; dvec[ch * 2 + 1] = c; }
                         else { atomicAdd(ST + ch * 2, a); atomicAdd(ST + ch * 2 + 1, c); }
                     }
                 }
-            if (det && det_arrive_wave(b, nseg * nstrips * C::TEAM)) {
+            if (!C::PREP && det && det_arrive_wave(b, nseg * nstrips * C::TEAM)) {
                 // last wave of the sample: ordered sum of all slots into copy 0 of the statistics buffer
                 for (int idx = lane; idx < COUT * 2; idx += 64)
                     p.stats[(size_t)b * COUT * 2 + idx] = det_sum(b, nseg * nstrips, COUT * 2, idx);
@@ -632,7 +663,7 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     const int njobs = p.B * nstrips * nseg;
     const int nwg = (njobs + C::TPW - 1) / C::TPW;
     const int jobs_per_xcd = (nwg + 7) / 8;                        // workgroups per XCD
-    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : "dot"));
+    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : "dot_prep")));
     dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
     hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM * C::TPW), C::LDS_BYTES * C::TPW, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
@@ -642,6 +673,10 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
 template <int CIN, int COUT>
 int launch_flavour(const ConvParams& p, hipStream_t s) {
     if (p.dot_src) {
+        if constexpr (CIN == COUT && CIN >= 32) {        // the generator's stride-1 layers at 512^2 / 1024^2 (64 / 32 channels)
+            if (p.prep) return launch_stream<CIN, COUT, FL_DOT_PREP>(p, s);
+        }
+        if (p.prep) { dge_set_error("conv_stream: the fused tail backward is built for 32->32 and 64->64 only"); return -1; }
         return launch_stream<CIN, COUT, FL_DOT>(p, s);
     }
     const bool enc = p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0);
@@ -673,6 +708,7 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     }
     if ((long)p.W * p.Cin * 2 >= (1L << 31) || (long)p.H * p.W * 64 * 2 >= (1L << 40)) return false;
     if (p.dot_src && !p.stats) return false;
+    if (p.prep && !(p.Cin == p.Cout && p.Cin >= 32)) return false;
     if (p.Cin == 64 && !p.dot_src && (p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0))) return false;
     if (p.dot_src && (p.bias || p.noise || p.in_shift || p.act != DGE_ACT_NONE)) return false;
     if (p.noise && p.noise_w == nullptr) return false;

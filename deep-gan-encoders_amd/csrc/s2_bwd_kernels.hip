@@ -53,6 +53,67 @@ __global__ void demod_bwd_kernel(const float* __restrict__ R, const float* __res
     t[idx] = -(R[(size_t)idx * 3] - (ns ? ns[0] : 0.f) * R[(size_t)idx * 3 + 1] - bias[o] * bscale * R[(size_t)idx * 3 + 2]) * dv * dv;
 }
 
+// The same from the sums of the FUSED tail backward (ConvParams::prep, dge_torgb_bwd_prep): P[slot][b,o,:] = (sum g_z*(z - ns*noise),
+// sum g_z), i.e. R0 - ns*R1 and R2 of the line above;  t[b,o] = -(P0 - bias[o]*bscale*P1) * d[b,o]^2.  Slot copies are added here.
+__global__ void demod_bwd_prep_kernel(const float* __restrict__ P, int nslot, const float* __restrict__ d, const float* __restrict__ bias,
+                                      float* __restrict__ t, int B, int C, float bscale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * C) return;
+    const float2 pp = sum_slot_pairs(P + (size_t)idx * 2, (size_t)B * C * 2, nslot);
+    const float dv = d[idx];
+    t[idx] = -(pp.x - bias[idx % C] * bscale * pp.y) * dv * dv;
+}
+
+// Top of the synthesis backward in one pass: the last layer's output x feeds only the last toRGB (image = rgb + up(prev),
+// stylegan2_generator.py:515-522), so its gradient is the toRGB adjoint, t_i = wscale * sum_c g[b,c,p] Wrgb[c,i], g = t_i * s[b,i],
+// gs[b,i] += sum_p t_i x[b,p,i] - immediately followed by the layer's own tail backward (:908-921): g_z = g * gain * lrelu'(x),
+// P[b,i,:] += (sum g_z*(z - ns*noise), sum g_z).  (dge_torgb_bwd + dge_modconv_bwd_prep without the gradient round trip.)
+template <typename T>
+__global__ __launch_bounds__(256) void torgb_bwd_prep_kernel(const float* __restrict__ gimg, const T* __restrict__ x,
+                                                              const float* __restrict__ wrgb, const float* __restrict__ sty,
+                                                              const float* __restrict__ noise, const float* __restrict__ nsp,
+                                                              T* __restrict__ gz_out, float* __restrict__ gs, float* __restrict__ P,
+                                                              int HW, int C, float wscale, float gain, int noise_bstride) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * 2 * EP];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    float w0[EP], w1[EP], w2[EP], sv[EP], sg[1][EP], sp[2][EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) {
+        const int i = chunk * EP + e;
+        w0[e] = wrgb[i] * wscale; w1[e] = wrgb[C + i] * wscale; w2[e] = wrgb[2 * C + i] * wscale;
+        sv[e] = sty[(size_t)b * C + i]; sg[0][e] = 0.f; sp[0][e] = 0.f; sp[1][e] = 0.f;
+    }
+    const float ns = (noise && nsp) ? nsp[0] : 0.f;
+    const float gpos = gain, gneg = 0.2f * gain, zpos = 1.f / gain, zneg = 1.f / (0.2f * gain);
+    const float* gb = gimg + (size_t)b * 3 * HW;
+    for (int p0 = blockIdx.x * ppi; p0 < HW; p0 += gridDim.x * ppi) {
+        const int p = p0 + slot;
+        if (slot < ppi && p < HW) {
+            const float g0 = gb[p], g1 = gb[HW + p], g2 = gb[2 * HW + p];
+            const float nzs = noise ? ns * noise[(size_t)b * noise_bstride + p] : 0.f;
+            const size_t o = ((size_t)b * HW + p) * C + chunk * EP;
+            float xv[EP], out[EP];
+            unpack16(*(const uint4*)(x + o), xv, (T*)nullptr);
+#pragma unroll
+            for (int e = 0; e < EP; e++) {
+                const float t = g0 * w0[e] + g1 * w1[e] + g2 * w2[e];
+                sg[0][e] += t * xv[e];
+                const bool pos = xv[e] > 0.f;
+                const float gz = t * sv[e] * (pos ? gpos : gneg);
+                const float zt = xv[e] * (pos ? zpos : zneg) - nzs;
+                sp[0][e] = fmaf(gz, zt, sp[0][e]); sp[1][e] += gz;
+                out[e] = gz;
+            }
+            *(uint4*)(gz_out + o) = pack16(out, (T*)nullptr);
+        }
+    }
+    block_chan_flush<EP, 1>(sg, cpt, ppi, gs + (size_t)b * C, C, red);
+    block_chan_flush<EP, 2>(sp, cpt, ppi, P + (size_t)b * C * 2, C, red);
+}
+
 // y[b*ldy + k*incy] (+)= scale * mul[b,k] * sum_o x[b*ldx + o*incx] * W[o,k]
 // block = 16 waves: lanes own 64 consecutive k (coalesced W rows), waves split the o range, LDS combine.
 __global__ __launch_bounds__(1024) void linear_t_kernel(const float* __restrict__ x, int ldx, int incx, const float* __restrict__ W,
@@ -169,6 +230,33 @@ extern "C" int dge_demod_bwd(const float* R, const float* d, const float* bias, 
                              int C, float bscale, hipStream_t s) {
     hipLaunchKernelGGL(demod_bwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, R, d, bias, noise_strength, t, B, C, bscale);
     DGE_LAUNCH_CHECK("demod_bwd");
+    return 0;
+}
+
+extern "C" int dge_demod_bwd_prep(const float* P, int nslot, const float* d, const float* bias, float* t, int B, int C, float bscale,
+                                  hipStream_t s) {
+    DGE_CHECK(nslot >= 1, "demod_bwd_prep: bad slot count");
+    hipLaunchKernelGGL(demod_bwd_prep_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, P, nslot, d, bias, t, B, C, bscale);
+    DGE_LAUNCH_CHECK("demod_bwd_prep");
+    return 0;
+}
+
+extern "C" int dge_torgb_bwd_prep(const float* gimg, const void* x, const float* wrgb, const float* style, const float* noise,
+                                  const float* noise_strength, int noise_batch, void* gz, float* gs, float* P, int B, int HW, int C,
+                                  float wscale, float gain, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "torgb_bwd_prep: unsupported channel count %d", C);
+    DGE_CHECK(gain > 0.f, "torgb_bwd_prep: gain must be positive");
+    DGE_CHECK(!dge_get_deterministic(), "torgb_bwd_prep: two flushes per workgroup - not offered in deterministic mode; run dge_torgb_bwd + dge_modconv_bwd_prep");
+    dim3 grid(dge_stream_grid(HW, 256 / (C / ep), B), B);
+    const int nbs = noise_batch > 1 ? HW : 0;
+    if (dtype == DGE_BF16)
+        hipLaunchKernelGGL(torgb_bwd_prep_kernel<bf16_t>, grid, dim3(256), 0, s, gimg, (const bf16_t*)x, wrgb, style, noise, noise_strength,
+                           (bf16_t*)gz, gs, P, HW, C, wscale, gain, nbs);
+    else
+        hipLaunchKernelGGL(torgb_bwd_prep_kernel<float>, grid, dim3(256), 0, s, gimg, (const float*)x, wrgb, style, noise, noise_strength,
+                           (float*)gz, gs, P, HW, C, wscale, gain, nbs);
+    DGE_LAUNCH_CHECK("torgb_bwd_prep");
     return 0;
 }
 

@@ -306,8 +306,10 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False):
-    """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout]."""
+           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None):
+    """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout].
+    `prep`: dict(gain, noise [1|B,OH,OW] or None, ns (device scalar) or None, stats=SlotStats(B, cout)) - the fused tail backward of
+    the layer that produced `dot_src` (dge_conv_desc.prep): y is then g_z and prep['stats'] receives (sum g_z*(z - ns*noise), sum g_z)."""
     B, H, W, Cin = x.shape
     if in_s2d:            # x is the fine grid [B,2H,2W,C]; logical input is [B,H,W,4C]
         H, W, Cin = H // 2, W // 2, Cin * 4
@@ -336,6 +338,14 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d.ksize, d.up, d.in_s2d, d.in_up2 = ksize, 1 if up else 0, 1 if in_s2d else 0, 1 if in_up2 else 0
     d.in_relu = 1 if in_relu else 0
     d.w_layout = 1 if getattr(w_packed, "_dge_frag", False) else 0
+    if prep is not None:
+        if stats is None or dot_src is None:
+            raise DgeError("conv2d: prep needs stats and dot_src")
+        pn = prep.get("noise")
+        d.prep, d.prep_gain = 1, float(prep["gain"])
+        d.prep_noise, d.prep_ns = _f32(pn), _f32(prep.get("ns") if pn is not None else None)
+        d.prep_noise_batch = 1 if pn is None else pn.shape[0]
+        d.prep_stats = _f32(prep["stats"].alloc(nslot))
     d.noise_batch = 1 if noise is None else noise.shape[0]
     d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
     d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt
@@ -429,6 +439,29 @@ def modconv_bwd_prep(gx, x, d, noise, gain, R=None):
                                      1 if noise is None else noise.shape[0], float(gain), dtype_of(x), _stream()),
           "dge_modconv_bwd_prep")
     return gy
+
+
+def torgb_bwd_prep(gimg, x, wrgb, style, wscale, noise, ns, gain):
+    """top of the synthesis backward: toRGB adjoint + tail backward of the layer in one pass -> (g_z, gs [B,C], P [B,C,2])"""
+    B, H, W, Cc = x.shape
+    gz = torch.empty_like(x)
+    gs = zeros((B, Cc), x.device)
+    P = zeros((B, Cc, 2), x.device)
+    check(lib().dge_torgb_bwd_prep(_f32(gimg), _p(x), _f32(wrgb), _f32(style), _f32(noise), _f32(ns if noise is not None else None),
+                                   1 if noise is None else noise.shape[0], _p(gz), _p(gs), _p(P), B, H * W, Cc, float(wscale),
+                                   float(gain), dtype_of(x), _stream()), "dge_torgb_bwd_prep")
+    return gz, gs, P
+
+
+def demod_bwd_prep(P, d, bias, bscale=1.0):
+    """t [B,C] from the fused tail-backward sums P (a [B,C,2] tensor or a SlotStats filled by conv2d(prep=...))"""
+    B, Cc = d.shape
+    nslot = 1
+    if isinstance(P, SlotStats):
+        nslot, P = P.nslot, P.buf
+    t = torch.empty_like(d)
+    check(lib().dge_demod_bwd_prep(_f32(P), nslot, _f32(d), _f32(bias), _p(t), B, Cc, float(bscale), _stream()), "dge_demod_bwd_prep")
+    return t
 
 
 def demod_bwd(R, d, bias, noise_strength, bscale=1.0):

@@ -77,6 +77,18 @@ typedef struct dge_conv_desc {
     int w_layout;             /* 0: [tap][N][K] rows; 1: MFMA-fragment order (pack mode | DGE_PACK_FRAG) - only where
                                  dge_conv_small_supported() says so: the low-resolution layers (4^2 .. 16^2 at 512 channels:
                                  stylegan2_generator.py:488-490 layers 0-4, E.py blocks at <= 16^2, LPIPS conv5_x) */
+    /* Fused tail backward of the layer BELOW (data gradients of the synthesis chain; needs dot_src = that layer's stored
+     * activation x = lrelu(yraw*d + noise*ns + bias)*gain, stylegan2_generator.py:908-921): instead of g = acc*out_scale + addend
+     * (the gradient w.r.t. x) the launch stores g_z = g * prep_gain * lrelu'(x) and adds, per (b, c),
+     * prep_stats[..][0] += sum g_z*(z - ns*noise), prep_stats[..][1] += sum g_z - what dge_modconv_bwd_prep does in a pass of
+     * its own, minus the demodulation factor d (hand it to the NEXT data-gradient launch as in_scale).  With in_s2d, in_scale /
+     * in_shift are per physical channel [B, Cin/4].  Not available in deterministic mode. */
+    int prep;                 /* 0 / 1 */
+    float prep_gain;          /* activation gain of the layer below (sqrt 2) */
+    const float* prep_noise;  /* its noise plane [prep_noise_batch, OH, OW] or NULL */
+    const float* prep_ns;     /* its noise strength, device scalar, or NULL */
+    int prep_noise_batch;     /* 1 = shared plane, else B */
+    float* prep_stats;        /* [stats_slots][B,Cout,2], pre-zeroed */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
@@ -208,6 +220,16 @@ int dge_linear_t(const float* x, int ldx, int incx, const float* w, const float*
 /* toRGB backward (:465-474): gx[b,p,i] = s[b,i]*wscale*sum_c g[b,c,p] Wrgb[c,i]; gs[b,i] (pre-zeroed) += sum_p (..)*x */
 int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb, const float* style, void* gx, float* gs, int B,
                   int HW, int C, float wscale, int dtype, dge_stream_t stream);
+/* Fused forms of the two calls above for the top of the synthesis backward and for the per-layer demodulation gradient when the
+ * tail backward ran inside the data-gradient launches (dge_conv_desc.prep):
+ * dge_torgb_bwd_prep = dge_torgb_bwd followed by dge_modconv_bwd_prep on the same layer (its output feeds only the last toRGB,
+ * stylegan2_generator.py:515-522,908-921): gz [B,HW,C] = g_z, gs [B,C] += toRGB style gradient, P [B,C,2] += (sum g_z*(z - ns*noise),
+ * sum g_z), all pre-zeroed.  dge_demod_bwd_prep: t[b,o] = -(P0 - bias[o]*bscale*P1) * d^2 with `nslot` copies of P added. */
+int dge_torgb_bwd_prep(const float* gimg, const void* x, const float* wrgb, const float* style, const float* noise,
+                       const float* noise_strength, int noise_batch, void* gz, float* gs, float* P, int B, int HW, int C,
+                       float wscale, float gain, int dtype, dge_stream_t stream);
+int dge_demod_bwd_prep(const float* P, int nslot, const float* d, const float* bias, float* t, int B, int C, float bscale,
+                       dge_stream_t stream);
 /* adjoint of the skip-branch 2x FIR upsample (:603-615): g [BC,2h,2w] -> gprev [BC,h,w] */
 int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, dge_stream_t stream);
 

@@ -485,3 +485,104 @@ def test_low_resolution_kernel_ragged_shapes(H, W, B):
         assert _one_rounding(_nchw(y, b), ref) <= 0, b
         refg = CR.conv_dgrad(_nchw(gy, b), w.cpu()) + _nchw(add, b)
         assert _one_rounding(_nchw(gx, b), refg) <= 0, b
+
+
+PREP_CASES = [
+    # (cout_fwd, cin_fwd, R, B, up, addend, kernel): data gradient of layer i (cin_fwd -> cout_fwd) with the tail backward of layer i-1 fused
+    (32, 32, 1024, 8, False, False, "conv_stream<bf16,32,32,dot_prep>"),            # layer16 -> g_z of layer15
+    (64, 64, 512, 8, False, False, "conv_stream<bf16,64,64,dot_prep>"),             # layer14 -> layer13
+    (128, 128, 256, 8, False, False, "conv_igemm<bf16,16,16,128,32,3,2,2>+prep"),   # layer12 -> layer11
+    (512, 512, 32, 8, False, False, "conv_igemm<bf16,16,16,64,32,3,4,1>+prep"),     # layer6 -> layer5
+    (512, 512, 16, 8, False, False, "conv_small<bf16,8,8,64,512>+prep"),            # layer4 -> layer3
+    (32, 64, 512, 8, True, True, "conv_igemm<bf16,16,16,64,32,3,4,1>+prep"),        # layer15 (up): space-to-depth read, toRGB addend -> layer14
+    (512, 512, 4, 8, True, True, "conv_igemm<bf16,8,8,64,128,3,2,2>+prep"),         # layer1 (up) -> layer0
+]
+
+
+@pytest.mark.parametrize("cof,cif,R,B,up,with_add,kernel", PREP_CASES)
+def test_data_gradient_with_fused_tail_backward_fullsize(cof, cif, R, B, up, with_add, kernel):
+    """The synthesis backward as the benchmark runs it (dge_amd/autograd_s2.py): the data-gradient conv of layer i takes g_z of
+    layer i (the demodulation d enters as its prologue scale), and its epilogue differentiates the noise / bias / lrelu*sqrt(2)
+    tail of layer i-1 from that layer's stored output (stylegan2_generator.py:908-921): output = g_z of layer i-1, plus the
+    style-gradient sum and the two demodulation-gradient sums.  Oracle: oracle/conv_ref.py (conv adjoint) + oracle/elem_ref.py
+    (autograd of the tail).  R = resolution of layer i-1's output (= the conv's output grid)."""
+    from dge_amd import ops
+    from oracle import elem_ref as ER
+    g = _gen(11000 + cof + cif + R)
+    gain = math.sqrt(2.0)
+    Rg = 2 * R if up else R                                   # grid of the incoming gradient
+    gz_in = _act(B, Rg, Rg, cof, g)
+    d_in = 0.5 + torch.rand(B, cof, device=DEV, generator=g)
+    xin = _act(B, R, R, cif, g, 1.5)                          # stored output of layer i-1
+    add = _act(B, R, R, cif, g) if with_add else None
+    w = _wgt(cof, cif, 3, g)
+    wscale = 1.0 / math.sqrt(9 * cif)
+    s = 1.0 + 0.3 * torch.randn(B, cif, device=DEV, generator=g)
+    noise = torch.randn(1, R, R, device=DEV, generator=g)
+    ns = torch.tensor([0.37], device=DEV)
+    st = ops.zeros((B, cif, 2), DEV)
+    P = ops.SlotStats(B, cif, DEV)
+    mode = ops.PACK_UPFOLD_DGRAD if up else ops.PACK_DGRAD
+    hg = R
+    out = ops.conv2d(gz_in, _pack(w, mode, hg, hg, wscale), cif, 3, in_s2d=up, in_scale=d_in, out_scale=s, addend=add, add_scale=1.0,
+                     stats=st, dot_src=xin, prep=dict(gain=gain, noise=noise, ns=ns, stats=P))
+    assert _kernel() == kernel
+    Pt = P.buf.sum(0).cpu()
+    stc = st.cpu()
+    wq = CR.bf16_round(w.cpu() * wscale)
+    for b in SAMPLES(B):
+        # the kernel stages bf16(g_z * d) (igemm / small: prologue affine) or folds d into the bf16 weights (conv_stream): both are one
+        # extra bf16 rounding of an operand, covered by the slack below; the oracle works on the exact product
+        gy = _nchw(gz_in, b) * d_in[b].cpu()[None, :, None, None]
+        raw = CR.up_dgrad(gy, wq, 1.0, R) if up else CR.conv_dgrad(gy, wq)
+        gref = raw * s[b].cpu()[None, :, None, None]
+        if with_add:
+            gref = gref + _nchw(add, b)
+        xb = _nchw(xin, b)
+        ones = torch.ones(cif)
+        ref_gz, ref_R = ER.modconv_tail_bwd(xb, gref, ones, noise[0].cpu(), gain)
+        viol = _one_rounding(_nchw(out, b), ref_gz, slack=6e-3)      # operand rounding of bf16(g_z*d): measured <= 3e-3 of max
+        assert viol <= 0, (b, viol)
+        gzd = ref_gz.double()
+        z = ER.lrelu_inverse(xb.double(), gain)
+        zt = z - 0.37 * noise[0].cpu().double()[None, None]
+        want = torch.stack([ref_R[:, 0] - 0.37 * ref_R[:, 1], ref_R[:, 2]], 1)
+        absum = torch.stack([(gzd * zt).abs().sum((0, 2, 3)), gzd.abs().sum((0, 2, 3))], 1)
+        e = ((Pt[b].double() - want).abs() / absum).max().item()
+        # sums of products of bf16-rounded operands (g_z*d staged as bf16, bf16 weights): each term carries up to 2 x 2^-9 relative
+        # error and a 4^2 layer has 16 terms per sum - no averaging: bound 2^-7 of the sum of |terms| (measured <= 4.9e-3)
+        assert e < 7.9e-3, (b, e)
+        rawd = raw.double()
+        es = ((stc[b, :, 0].double() - (rawd * xb.double()).sum((0, 2, 3))).abs() / (rawd * xb.double()).abs().sum((0, 2, 3))).max().item()
+        assert es < 7.9e-3, (b, es)
+
+
+@pytest.mark.parametrize("C,R,B", [(32, 1024, 8), (128, 256, 2)])
+def test_top_of_the_synthesis_backward_fullsize(C, R, B):
+    """dge_torgb_bwd_prep: toRGB adjoint of the last layer + that layer's tail backward in one pass (stylegan2_generator.py:515-522,
+    :908-921) against oracle/elem_ref.py (autograd of both stages)."""
+    from dge_amd import ops
+    from oracle import elem_ref as ER
+    g = _gen(12000 + C)
+    gain = math.sqrt(2.0)
+    x = _act(B, R, R, C, g, 1.5)
+    wrgb = torch.randn(3, C, device=DEV, generator=g)
+    s = 1.0 + 0.3 * torch.randn(B, C, device=DEV, generator=g)
+    gimg = torch.randn(B, 3, R, R, device=DEV, generator=g)
+    noise = torch.randn(1, R, R, device=DEV, generator=g)
+    ns = torch.tensor([0.37], device=DEV)
+    wscale = 1.0 / math.sqrt(C)
+    gz, gs, P = ops.torgb_bwd_prep(gimg, x, wrgb, s, wscale, noise, ns, gain)
+    for b in range(B):
+        xb = _nchw(x, b)
+        gx, ref_gs = ER.torgb_bwd(xb, wrgb.cpu(), s[b].cpu(), wscale, gimg[b:b + 1].cpu())
+        ref_gz, ref_R = ER.modconv_tail_bwd(xb, gx, torch.ones(C), noise[0].cpu(), gain)
+        if b in SAMPLES(B):
+            assert _one_rounding(_nchw(gz, b), ref_gz) <= 0, b
+        t = gx / s[b].cpu().double()[None, :, None, None]
+        assert ((gs[b].cpu().double() - ref_gs).abs() / (t * xb.double()).abs().sum((0, 2, 3))).max().item() < 5e-5, b
+        gzd = ref_gz.double()
+        zt = ER.lrelu_inverse(xb.double(), gain) - 0.37 * noise[0].cpu().double()[None, None]
+        want = torch.stack([ref_R[:, 0] - 0.37 * ref_R[:, 1], ref_R[:, 2]], 1)
+        absum = torch.stack([(gzd * zt).abs().sum((0, 2, 3)), gzd.abs().sum((0, 2, 3))], 1)
+        assert ((P[b].cpu().double() - want).abs() / absum).max().item() < 5e-5, b

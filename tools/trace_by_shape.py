@@ -16,9 +16,10 @@ if not gcols:
     gcols = [k for k in cols if "grid" in k.lower() or "workgroup" in k.lower()][:4]
 print("# columns:", cols)
 rows = c.execute(f"select name, start, end, {', '.join(gcols)} from kernels order by start").fetchall()
-adam = [i for i, r in enumerate(rows) if "lreq_adam" in r[0]]
-if len(adam) >= 2 * nsteps + 2:
-    rows = rows[adam[-2 * nsteps - 1] + 1: adam[-1] + 1]
+# step marker: the mapping network's pixel-norm runs once per E_align step (first kernel of the G forward)
+marks = [i for i, r in enumerate(rows) if "pixelnorm_kernel" in r[0]]
+if len(marks) >= nsteps + 1:
+    rows = rows[marks[-nsteps - 1]: marks[-1]]
 else:
     nsteps = 1
 agg = collections.OrderedDict()
