@@ -68,6 +68,29 @@ class LREQAdam(Optimizer):
         self._graph_t = 0
 
     @torch.no_grad()
+    def tick(self):
+        """One step() with ZERO gradients on every parameter that already has optimizer state: t += 1, v *= beta_2, p unchanged
+        (custom_adam.py:35-62 with grad == 0).  This is what the reference's first optimizer step of a stage-1 iteration does under
+        torch < 2.0, whose `zero_grad()` zero-fills gradient tensors instead of dropping them (E_align_cropping_s1.py:203-205: the
+        image-space loss reaches no encoder parameter, so every .grad is the zero tensor left by zero_grad)."""
+        for group in self.param_groups:
+            live = [p for p in group["params"] if len(self.state.get(p, {}))]
+            if not live:
+                continue
+            n_max = max(p.numel() for p in live)
+            z = getattr(self, "_zero_grad_buf", None)
+            if z is None or z.numel() < n_max or z.device != live[0].device:
+                z = self._zero_grad_buf = torch.zeros(n_max, dtype=torch.float32, device=live[0].device)
+            saved = [(p, p.grad) for p in group["params"]]
+            try:
+                for p in group["params"]:
+                    p.grad = z[:p.numel()].view_as(p) if len(self.state.get(p, {})) else None
+                self.step()
+            finally:
+                for p, g in saved:
+                    p.grad = g
+
+    @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
         """grad_scale: optional device scalar multiplied into every gradient (DDP mean)."""
         loss = None

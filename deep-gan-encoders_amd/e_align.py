@@ -144,13 +144,20 @@ def _all_reduce(t, async_op=False):
 
 class EAlignStep:
     def __init__(self, generator, E, lpips_model, lr=0.0015, beta_1=0.0, batch_size=2, z_dim=512,
-                 reference_noise=False, exact_ddp=True, mapping=None, stage=2):
+                 reference_noise=False, exact_ddp=True, mapping=None, stage=2, zero_grad_to_none=True):
         """`generator`: StyleGAN2Generator (mtype 2), the StyleGAN1 synthesis network Gs together with
         `mapping` = Gm (mtype 1), a PGGANGenerator (mtype 3) or a BigGAN (mtype 4; z_dim is taken from its config).
         `stage`: 2 = E_align_s2.py (image phase 1/5/9-weighted with gradient, then the latent phase); 1 = the stage-1 variant
         E_align_cropping_s1.py:185-218: the image-space losses are evaluated on detached inputs and summed unweighted (they are
         reported, not trained on: no gradient reaches E, the script's first optimizer step changes nothing) and only the
-        latent phase updates the encoder."""
+        latent phase updates the encoder.
+        `zero_grad_to_none` (stage 1 only): True = `optimizer.zero_grad()` of torch >= 2.0 drops the gradients, so the script's
+        first optimizer step finds none and changes nothing (tests/golden/step_s1.npz).  False = the torch < 2.0 default the
+        reference's pinned environment has (python 3.7, torch 1.8 .. 1.13): gradients are zero-FILLED, so from the second
+        iteration on that step runs LREQAdam with zero gradients - every step counter advances and every second moment decays
+        by beta_2 (custom_adam.py:35-62), which makes the latent-phase updates ~1.4x larger in steady state
+        (tests/golden/step_s1_legacy.npz).  Stage 2 is unaffected: both of its phases give every trained parameter a gradient."""
+        self.zero_grad_to_none = bool(zero_grad_to_none)
         if stage not in (1, 2):
             raise ValueError("EAlignStep: stage must be 1 or 2")
         self.stage = stage
@@ -342,6 +349,8 @@ class EAlignStep:
             # E_align_cropping_s1.py:185-203: .detach().clone() on every loss input, loss_tsa = imgs + medium + small
             with torch.no_grad():
                 loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2.detach(), self.lpips, weights=(1.0, 1.0, 1.0), global_batch=gctx)
+            if not self.zero_grad_to_none:
+                self.opt.tick()          # E_align_cropping_s1.py:203-205 under torch < 2.0: optimizer step on zero-filled gradients
         else:
             loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, global_batch=gctx)
             self.opt.zero_grad()
@@ -517,7 +526,7 @@ def train(tensor_writer=None, args=None):
     load_lpips_weights(LP, getattr(args, "vgg_weights", None), getattr(args, "lpips_weights", None),
                        allow_standin=getattr(args, "allow_standin_lpips", False))
     st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm,
-                    stage=getattr(args, "stage", 2))
+                    stage=getattr(args, "stage", 2), zero_grad_to_none=not getattr(args, "legacy_zero_grad", False))
     for iteration in range(args.iterations):
         r = st.step(iteration)
         if iteration % 100 == 0:
@@ -538,6 +547,8 @@ def main(argv=None):
     parser.add_argument("--experiment_dir", default=None)
     add_model_args(parser)
     parser.add_argument("--stage", type=int, default=2, help="2: E_align_s2.py; 1: E_align_cropping_s1.py (latent phase only trains E)")
+    parser.add_argument("--legacy_zero_grad", action="store_true", help="stage 1: optimizer.zero_grad() as torch < 2.0 (zero-filled gradients, the "
+                        "reference's pinned environment): the first optimizer step of an iteration ticks every Adam state")
     parser.add_argument("--vgg_weights", default=None, help="torchvision vgg16 checkpoint (features.*) or an lpips.LPIPS state_dict")
     parser.add_argument("--lpips_weights", default=None, help="the lpips package's weights/v0.1/vgg.pth (lin{k}.model.1.weight)")
     parser.add_argument("--deterministic", action="store_true", help="bit-reproducible reductions (training_utils.py:51 cudnn.deterministic): ops.set_deterministic")

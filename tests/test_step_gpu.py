@@ -117,6 +117,54 @@ def test_stage1_step_matches_reference_run():
         EAlignStep(G, E, LP, stage=3)
 
 
+def test_stage1_step_legacy_zero_grad_matches_reference_run():
+    """stage=1 with the torch < 2.0 zero_grad semantics of the reference's pinned environment (zero-filled gradient tensors: the
+    script's first optimizer step advances t and decays v for every parameter, custom_adam.py:35-62): three iterations against
+    the reference's own run with `zero_grad(set_to_none=False)` (tests/golden/step_s1_legacy.npz, tools/gen_golden.py
+    step_s1_legacy).  The default mode must NOT match that run from the second iteration on."""
+    import dge_amd
+    from dge_amd.encoder import BE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.e_align import EAlignStep
+    g = golden("step_s1_legacy.npz")
+
+    def run(legacy):
+        G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="f32").cuda()
+        G.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+        G.train()
+        for p in G.parameters():
+            p.requires_grad_(False)
+        E = BE(startf=16, maxf=64, layer_count=5, compute_dtype="f32").cuda()
+        E.load_state_dict(R.fill_encoder(enc_shapes(16, 64, 5), seed=31))
+        LP = LPIPS(compute_dtype="f32").cuda()
+        LP.load_state_dict(LR.seeded_params(0))
+        st = EAlignStep(G, E, LP, lr=0.0015, batch_size=2, stage=1, zero_grad_to_none=not legacy)
+        new_z = R.randn("step.new_z", (2, 512), 1).cuda()
+        errs = []
+        for it in range(3):
+            z = R.randn(f"step.z{it}", (2, 512), 1)
+            noises = [R.randn(f"step.it{it}.noise{i}", s, 1).cuda() for i, s in enumerate(O.enc_noise_shapes(5, 2, 64))]
+            st.step(it, z=z, noises=noises, new_z=new_z)
+            sd = E.state_dict()
+            worst = 0.0
+            for key in g.files:
+                if key.startswith(f"it{it}_after_phase2:"):
+                    k = key.split(":", 1)[1]
+                    before = R.fill_encoder(enc_shapes(16, 64, 5), seed=31)[k]
+                    du_ref = torch.as_tensor(g[key]) - before
+                    du = sd[k].cpu() - before
+                    worst = max(worst, ((du - du_ref).abs().max() / du_ref.abs().max()).item())
+            errs.append(worst)
+        return errs, st
+    errs, st = run(legacy=True)
+    print("stage-1 legacy zero_grad, error of the accumulated parameter update per iteration:", errs)
+    assert max(errs) < 0.05, errs
+    t = [s["step"] for s in st.opt.state.values() if len(s)]
+    assert t and min(t) == max(t) == 5              # 1 + 2 + 2: the zero-gradient tick counts from the second iteration on
+    errs_default, _ = run(legacy=False)
+    assert errs_default[0] < 0.05 and errs_default[2] > 0.1, errs_default      # same first iteration, then the two semantics part
+
+
 def test_two_phase_step_bf16_matches_reference_run():
     """The BENCHMARKED precision (bf16 storage, f32 accumulation) through two complete two-phase iterations against the
     reference's own fp32 run (tests/golden/step_s2.npz).  Tolerances = 2x the error measured on MI355X (in the comments),

@@ -382,8 +382,12 @@ def gen_step():
     save_npz("step_s2.npz", **out)
 
 
-def gen_step_s1():
-    """Two iterations of the STAGE-1 variant (E_align_cropping_s1.py:185-218) of the REFERENCE's modules at reduced size: the
+def gen_step_s1(legacy=False):
+    """legacy=True: the same loop with `zero_grad(set_to_none=False)` - what torch < 2.0 (the reference pins torch >= 1.8 on
+    python 3.7, i.e. <= 1.13) does by default: from the second iteration on the gradients are zero TENSORS at the script's first
+    optimizer step, so LREQAdam advances every step counter and decays every second moment there (custom_adam.py:35-62) - three
+    iterations, tests/golden/step_s1_legacy.npz.
+    Two iterations of the STAGE-1 variant (E_align_cropping_s1.py:185-218) of the REFERENCE's modules at reduced size: the
     three image-space losses are computed on `.detach().clone()` inputs and summed unweighted (:185-203) - they carry no
     gradient to the encoder, so the first backward / optimizer step of the script changes nothing in E (gradients stay None
     after zero_grad) - and only the latent phase loss_w * 0.01 (:207-218) trains it."""
@@ -407,7 +411,7 @@ def gen_step_s1():
     orig_randn_like = torch.randn_like
     torch.randn_like = lambda t, **kw: new_z.clone()
     try:
-        for it in range(2):
+        for it in range(3 if legacy else 2):
             np.random.seed(it)
             z = R.randn(f"step.z{it}", (B, 512), 1)
             with torch.no_grad():
@@ -426,12 +430,12 @@ def gen_step_s1():
                 s1, s2 = imgs1[:, :, o:-o, o:-o].detach().clone(), imgs2[:, :, o:-o, o:-o].detach().clone()
                 l_s, i_s = TU.space_loss(s1, s2, lpips_model=lp)
                 loss_tsa = l_i + l_m + l_s
-                opt.zero_grad()
+                opt.zero_grad(set_to_none=not legacy)
                 assert not loss_tsa.requires_grad          # nothing of E is reachable: the script's backward() only touches lpips' own layers
-                opt.step()                                  # all gradients None: no parameter, no Adam state changes
+                opt.step()                                  # gradients None: nothing changes; legacy: zero tensors -> t += 1, v *= beta2
                 l_w, i_w = TU.space_loss(w1, w2, image_space=False)
                 loss_mtv = l_w * 0.01
-                opt.zero_grad()
+                opt.zero_grad(set_to_none=not legacy)
                 loss_mtv.backward()
                 opt.step()
             flat = lambda inf: [inf[0][0], inf[0][1], inf[0][2], inf[1], inf[2], inf[3], inf[4]]
@@ -445,7 +449,7 @@ def gen_step_s1():
                 out[f"it{it}_after_phase2:{k}"] = E.state_dict()[k].clone()
     finally:
         torch.randn_like = orig_randn_like
-    save_npz("step_s1.npz", **out)
+    save_npz("step_s1_legacy.npz" if legacy else "step_s1.npz", **out)
 
 
 # --------------------------------------------------------------------------- StyleGAN1
@@ -723,6 +727,7 @@ def gen_step_sg1():
 
 SECTIONS["step_sg1"] = gen_step_sg1
 SECTIONS["step_s1"] = gen_step_s1
+SECTIONS["step_s1_legacy"] = lambda: gen_step_s1(legacy=True)
 
 def gen_encblurgrad():
     """Gradients of the reference E_Blur.BE w.r.t. every parameter AND the input image for a seeded linear functional of
