@@ -5,13 +5,13 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libdge_hip.so
-SRCS="capi.hip conv_igemm.hip conv_stream.hip conv_small.hip s2_kernels.hip $(ls *_kernels.hip | grep -v s2_kernels.hip || true)"
+SRCS="capi.hip conv_igemm.hip conv_igemm_f32.hip conv_stream.hip conv_small.hip s2_kernels.hip $(ls *_kernels.hip | grep -v s2_kernels.hip || true)"
 mkdir -p build
 objs=""
 pids=""
 for f in $SRCS; do
   o="build/${f%.hip}.o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ conv_epilogue.h -nt "$o" ] || [ ../../include/dge_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ conv_params.h -nt "$o" ] || [ conv_epilogue.h -nt "$o" ] || [ conv_igemm_impl.h -nt "$o" ] || [ ../../include/dge_hip.h -nt "$o" ]; then
     echo "hipcc $f"
     rm -f "$o"
     ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$f" -o "$o.tmp.$$" && mv "$o.tmp.$$" "$o" ) &

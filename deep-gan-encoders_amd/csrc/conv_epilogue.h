@@ -12,21 +12,25 @@
 // `lds`: base of the workgroup's LDS (staging area of wave w at lds + w*32*C::ESTR; all main-loop reads are done);
 // `ldsN`: the noise tile staged by the prologue.  Only waves 0 .. WM*WN-1 carry tiles (`carrier`); in deterministic mode
 // every thread of the workgroup must call.
-// PREP (compile time): the fused tail backward of ConvParams::prep - its 16 extra per-lane sums cost the instantiations that
-// never use it a wave of occupancy, so they are built without it.
-template <typename T, class C, int TH, int TW, int BN, int WM, int WN, int NTHREADS, bool PREP = false>
+// MODE (compile time; the registers of a stage cost every instantiation that carries it a wave of occupancy, so launches
+// that never use a stage get a kernel built without it):
+//   0  no addend / dot_src (the forward convolutions)
+//   1  addend and / or dot_src, requested one tile ahead of their use
+//   2  mode 1 + the fused tail backward of ConvParams::prep (16 more per-lane sums)
+template <typename T, class C, int TH, int TW, int BN, int WM, int WN, int NTHREADS, int MODE = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&acc)[C::MT][C::NT], unsigned char* lds, const float* ldsN,
                                               int b, int x0, int y0, int bn0, int ntile, int vbid, int tx_i, int ty_i,
                                               int wave, int lane, int tid, bool carrier) {
     constexpr int EP16 = Elem<T>::PER16;
+    constexpr bool PREP = MODE == 2;
     const int wm = wave / WN, wn = wave % WN;
     // NOTE: every accumulator index below is a compile-time constant (StaticFor): a run-time index
     // into acc[][] would push the whole accumulator file to scratch on every main-loop iteration.
     unsigned char* est = lds + wave * (32 * C::ESTR);     // (the noise tile at the end of `lds` stays valid)
     const int OH = p.up ? 2 * p.H : p.H, OW = p.up ? 2 * p.W : p.W;
     T* __restrict__ Y = (T*)p.y;
-    const T* __restrict__ ADD = (const T*)p.addend;
-    const T* __restrict__ DOT = (const T*)p.dot_src;
+    const T* __restrict__ ADD = MODE >= 1 ? (const T*)p.addend : nullptr;      // (the launcher picks MODE from these pointers)
+    const T* __restrict__ DOT = MODE >= 1 ? (const T*)p.dot_src : nullptr;
     constexpr int CPR = 32 / EP16;              // 16-byte chunks per 32-channel row
     constexpr int PPP = 64 / CPR;               // pixels per read-back pass
     // Two kinds of epilogue work:
@@ -51,6 +55,31 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
     T* __restrict__ Yb = Y + (size_t)b * OH * OW * p.Cout;           // in-image offsets fit 32 bits
     const T* __restrict__ ADDb = ADD ? ADD + (size_t)b * OH * OW * p.Cout : nullptr;
     const T* __restrict__ DOTb = DOT ? DOT + (size_t)b * OH * OW * p.Cout : nullptr;
+    // The addend / dot_src vectors of a tile are requested ONE TILE AHEAD of their use (register double buffer): requested inside
+    // the read-back loop, every pass exposed a full memory latency - the data-gradient launches of the 512^2 / 1024^2 layers
+    // spent half their time there (tools/perf_s2d.py: 692 us with, 353 us without the dot / addend stages on layer 15).
+    constexpr int NPASS = 32 / PPP;
+    // (f32 tiles take 4 passes: 64 staging registers; the 8-tile wave of the 128-wide configuration has none to spare next to
+    //  the prep sums: loads stay in place there)
+    constexpr bool PF = MODE >= 1 && NPASS <= 2 && !(MODE == 2 && C::MT * C::NT >= 8);
+    const bool pf = PF && !p.up && (DOT || ADD);
+    uint4 pfd[2][PF ? NPASS : 1], pfa[2][PF ? NPASS : 1];
+    auto pf_issue = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int jj = t / C::MT, ii = t % C::MT;
+        const int oc_ = bn0 + wn * C::WTN + jj * 32 + (lane % CPR) * EP16;
+#pragma unroll
+        for (int q = 0; q < (PF ? NPASS : 0); q++) {
+            const int m = wm * C::WTM + ii * 32 + q * PPP + lane / CPR;
+            const int gy = y0 + m / TW, gx = x0 + m % TW;
+            if ((gy < p.H) & (gx < p.W) & (oc_ < p.Cout)) {
+                const int off = (gy * OW + gx) * p.Cout + oc_;
+                if (DOT) pfd[t & 1][q] = *(const uint4*)(DOTb + off);
+                if (ADD) pfa[t & 1][q] = *(const uint4*)(ADDb + off);
+            }
+        }
+    };
+    if (pf && carrier && !(p.dbg & 4)) pf_issue(std::integral_constant<int, 0>{});
     if (!(p.dbg & 4) && carrier)
     StaticFor<C::NT>::run([&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -92,6 +121,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
         const float* nzb = ldsN + phase * C::BM + wm * C::WTM + 4 * lh;          // + i*32 + 8(r>>2) + (r&3)
         StaticFor<C::MT>::run([&](auto ic) {
             constexpr int i = decltype(ic)::value;
+            constexpr int tcur = j * C::MT + i;
+            if constexpr (PF && tcur + 1 < C::MT * C::NT) { if (pf) pf_issue(std::integral_constant<int, tcur + 1>{}); }
             const f32x16_t a = acc[i][j];
             float nz[16], val[16];
             if (p.noise) {
@@ -137,13 +168,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
                     if (DOT || ADD) {
                         float d[EP16];
                         if (DOT) {
-                            unpack16(*(const uint4*)(DOTb + off), d, (T*)nullptr);
+                            uint4 dv;
+                            if constexpr (PF) dv = pf ? pfd[tcur & 1][q] : *(const uint4*)(DOTb + off);
+                            else dv = *(const uint4*)(DOTb + off);
+                            unpack16(dv, d, (T*)nullptr);
 #pragma unroll
                             for (int e = 0; e < EP16; e++) { ps0[e] += f[e] * d[e]; ps1[e] += f[e]; f[e] *= posc[e]; }
                         }
                         if (ADD) {
                             float ad[EP16];
-                            unpack16(*(const uint4*)(ADDb + off), ad, (T*)nullptr);
+                            uint4 av;
+                            if constexpr (PF) av = pf ? pfa[tcur & 1][q] : *(const uint4*)(ADDb + off);
+                            else av = *(const uint4*)(ADDb + off);
+                            unpack16(av, ad, (T*)nullptr);
 #pragma unroll
                             for (int e = 0; e < EP16; e++) f[e] += p.add_scale * ad[e];
                         }

@@ -1,0 +1,435 @@
+// Implicit-GEMM 3x3 / 1x1 convolution for gfx950 (MI355X), NHWC activations.
+//
+//   M = output pixels of a TH x TW spatial tile, N = output channels, K = taps x Cin.
+//   The input halo tile ((TH+2) x (TW+2) x KC channels) is staged ONCE per K-chunk into LDS
+//   and re-read at 9 shifted offsets (one per tap), so activations cross HBM/L2 once, not 9x.
+//   Weights are pre-packed [tap][N][Cin] (K contiguous) so both MFMA operands are read from
+//   LDS as 16-byte K-contiguous fragments (ds_read_b128, rows padded by 16 B: conflict free).
+//   MFMA: v_mfma_f32_32x32x16_bf16 (bf16 storage) or v_mfma_f32_32x32x2_f32 (f32 storage,
+//   exact f32 - the parity path); 64-wide wavefronts, 4 waves per workgroup.
+//
+//   Pipeline: one stage = one kernel ROW (3 taps) of one K chunk.  While the MFMAs of stage s run,
+//   the weight tile of stage s+1 (and, at the first row of a chunk, the next chunk's input halo
+//   tile) is in flight from L2/HBM into registers; it is written to the other LDS buffer after the
+//   MFMAs and ONE barrier closes the stage.  A and B are both double-buffered in LDS.
+//
+// Fused prologue : per-(sample, in-channel) affine a*x+b applied while staging
+//                  (StyleGAN2 style modulation s[b,i]; instance-norm apply in the encoder).
+// Fused epilogue : per-(sample, out-channel) scale (demodulation d[b,o]), noise*weight, bias,
+//                  lrelu/relu, gain, optional addend (residual blend), optional per-(b,c)
+//                  sum / sum-of-squares for the next instance norm, depth-to-space x2 store
+//                  (the folded transposed-conv+FIR up layer: N = 4 phases x Cout).
+//
+// Reference math: model/stylegan2_generator.py:855-922 (ModulateConvBlock.forward, shared-weight
+// form :876-877,:908-909), model/E/E.py:50-85 (BEBlock.forward).
+#pragma once
+#include <type_traits>
+#include <stdlib.h>
+#include "common.h"
+#include "conv_params.h"
+#include "conv_epilogue.h"
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x16_t& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+// N uint4 values with compile-time-only indexing (keeps prefetch buffers in VGPRs: a plain array
+// indexed inside a lambda was being demoted to scratch / LDS by the compiler).
+template <int N> struct Regs {
+    uint4 v; Regs<N - 1> rest;
+    template <int I> __device__ __forceinline__ uint4& get() { if constexpr (I == 0) return v; else return rest.template get<I - 1>(); }
+};
+template <> struct Regs<0> { template <int I> __device__ __forceinline__ uint4& get(); };
+
+// 16-byte-per-lane global -> LDS DMA issued from inline asm, so that hipcc does NOT track it: with the
+// builtin form the compiler inserts s_waitcnt vmcnt(0) in front of the next ds_read (it cannot prove
+// the read does not alias the DMA destination), which serialises the weight stream behind the MFMAs.
+// The LDS destination is wave-uniform base (M0) + lane*16; completion is awaited by hand
+// (s_waitcnt vmcnt(0) right before the stage barrier).
+__device__ __forceinline__ void glds16_untracked(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+// the same with a wave-uniform 64-bit base (SGPR pair) + a 32-bit per-lane byte offset: no per-lane 64-bit address arithmetic
+__device__ __forceinline__ void glds16_saddr(unsigned voff, unsigned long long sbase, unsigned lds_dst_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst_uniform) : "memory");
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+static constexpr int cmin(int a, int b) { return a < b ? a : b; }
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
+struct ConvCfg {
+    static constexpr int BM = TH * TW;
+    static constexpr int WTM = BM / WM, WTN = BN / WN;
+    static constexpr int MT = WTM / 32, NT = WTN / 32;
+    static constexpr int KCB = KC * (int)sizeof(T);
+    static constexpr int CH = KCB / 16;
+    static constexpr int PSTR = KCB + 16;
+    static constexpr int HALO = KS / 2;
+    static constexpr int HH = TH + 2 * HALO, HW = TW + 2 * HALO;
+    static constexpr int RPITCH = rup(HW * PSTR, 256);
+    static constexpr int A_BYTES = HH * RPITCH;              // one halo tile
+    static constexpr int B_BYTES = KS * BN * KCB;            // one stage: KS taps (a kernel row), rows unpadded, 16-B chunks XOR-swizzled
+    static constexpr int RP = 16 / CH;                       // weight rows per 256-byte LDS bank row
+    static constexpr int B_PIECES = B_BYTES / 1024;          // 1 KiB wave-level LDS-DMA pieces per stage
+    static constexpr int ESTR = 32 * 4 + 16;                  // epilogue staging is always f32
+    static constexpr int E_BYTES = 4 * 32 * ESTR;
+    // noise values of the tile (x4 phases in up mode; up mode has N = 4*Cout >= 64, so 32-wide N tiles never see it and
+    // keep 3 KB: that puts the 16x16x32 configuration under the 3-workgroups-per-CU LDS line)
+    static constexpr int N_BYTES = (BN >= 64 ? 4 : 1) * BM * 4;
+    // weight-stage ring.  Large pixel tiles: 4 deep (DMA issued 3 stages ahead) when two workgroups still fit a CU, else
+    // 2 deep.  Small pixel tiles serve the low-resolution layers, whose grids do not fill the chip and whose stages are
+    // short (6-12 MFMAs per wave): there the serial K loop is bound by the L2 latency of the weight stream, so the ring
+    // takes the whole LDS (one workgroup per CU) and runs up to 5 stages ahead.
+    static constexpr int NBUF_SMALL = cmin(6, cmax(2, (150 * 1024 - A_BYTES - N_BYTES) / B_BYTES));
+    static constexpr int NBUF = (BM <= 128) ? NBUF_SMALL : ((A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2);
+    static constexpr int DPW = B_PIECES / 4;                   // DMA instructions every wave issues per stage (floor)
+    static constexpr int LDS_BYTES = cmax(A_BYTES + NBUF * B_BYTES, E_BYTES) + N_BYTES;
+    static constexpr int NA_ITEMS = HH * HW * CH, NA_PER = (NA_ITEMS + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(MT >= 1 && NT >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+    static_assert(KCB % 32 == 0 && 256 % CH == 0, "K chunk");
+    static_assert(B_BYTES % 1024 == 0 && BN % 16 == 0 && (BN / RP) % CH == 0, "weight stage must be whole 1 KiB pieces");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    // workgroups per CU the LDS footprint allows (1..3) = waves per SIMD to ask the register allocator for
+    // (a 128-wide N tile holds 128 accumulator registers per lane: never ask for more than 2 waves/SIMD there)
+    static constexpr int MINW = (LDS_BYTES <= 53 * 1024 && MT * NT < 8) ? 3 : (LDS_BYTES <= 80 * 1024 ? 2 : 1);
+};
+
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)) void conv_igemm_kernel(ConvParams p) {
+    using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>;
+    constexpr int EP16 = Elem<T>::PER16;
+    __shared__ __attribute__((aligned(256))) unsigned char lds[C::LDS_BYTES];
+    unsigned char* ldsA = lds;                         // halo tile of the current K chunk
+    unsigned char* ldsB = lds + C::A_BYTES;            // 2 weight stages
+    float* ldsN = (float*)(lds + C::LDS_BYTES - C::N_BYTES);   // noise tile, lives until the epilogue
+    const unsigned ldsB_off = lds_offset_of(ldsB);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: keeps tile/DMA index math on the scalar unit
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (private L2 each), so workgroup id i runs on
+    // XCD i % 8.  Give every XCD a CONTIGUOUS range of tiles: neighbouring tiles share halo rows and the same weight
+    // slice, which then hit in that XCD's L2 instead of being fetched once per XCD.
+    int bid = blockIdx.x;
+    {
+        const int nb = gridDim.x, per = nb >> 3;
+        if (per > 0 && bid < (per << 3) && !(p.dbg & 32)) bid = (bid & 7) * per + (bid >> 3);
+    }
+    const int vbid = bid;             // tile id in (tx, ty, b, ntile) order: statistics slots are dealt by THIS id, so that the
+                                      // workgroups sharing a slot stay spread over the samples (same-address atomics)
+    const int tx_i = bid % p.tiles_x; bid /= p.tiles_x;
+    const int ty_i = bid % p.tiles_y; bid /= p.tiles_y;
+    const int b = bid % p.B;
+    const int ntile = bid / p.B;
+    const int x0 = tx_i * TW, y0 = ty_i * TH;
+    const int bn0 = ntile * BN;
+    const T* __restrict__ X = (const T*)p.x;
+    const T* __restrict__ Wp = (const T*)p.w;
+
+    f32x16_t acc[C::MT][C::NT];
+#pragma unroll
+    for (int i = 0; i < C::MT; i++)
+#pragma unroll
+        for (int j = 0; j < C::NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    int aoff[C::MT];
+#pragma unroll
+    for (int i = 0; i < C::MT; i++) {
+        const int m = wm * C::WTM + i * 32 + (lane & 31);
+        aoff[i] = (m / TW) * C::RPITCH + (m % TW) * C::PSTR + (lane >> 5) * 16;
+    }
+    int bbase[C::NT], bsw[C::NT];           // weight row byte offset and its chunk swizzle
+#pragma unroll
+    for (int j = 0; j < C::NT; j++) {
+        const int n = wn * C::WTN + j * 32 + (lane & 31);
+        bbase[j] = n * C::KCB; bsw[j] = (n / C::RP) % C::CH;
+    }
+
+    const int nchunks = p.Cin / KC;
+    const bool affine = p.in_scale || p.in_shift;
+    const int cphys = p.in_s2d ? (p.Cin >> 2) : p.Cin;
+    const int achunk = tid % C::CH;                    // the 16-byte channel sub-range this thread stages
+
+    Regs<C::NA_PER> areg;
+    float asc[EP16], ash[EP16];                        // affine of the chunk held in areg
+    unsigned inmask = 0;                               // bit i: halo item i lies inside the image
+
+    // Source geometry of the fused read modes, folded into shifts so the per-item address math is
+    // branch-free: plain (sl=sh=0), in_up2 (nearest x2: source pixel = (y>>1, x>>1)), in_s2d
+    // (space-to-depth: logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid).
+    const int sl = p.in_s2d ? 1 : 0, sh = p.in_up2 ? 1 : 0;
+    const int Ws = (p.W << sl) >> sh;
+    const T* __restrict__ Xb = X + (size_t)b * ((p.H << sl) >> sh) * Ws * cphys;   // in-image offsets fit 32 bits
+
+    // ---- input halo tile: global -> registers (zero outside the image)
+    auto load_a = [&](int kc) {
+        const int cbase = kc * KC;
+        int ph = 0, cb = cbase;
+        if (p.in_s2d) { ph = cbase / cphys; cb = cbase - ph * cphys; }
+        const int ay = ph >> 1, ax = ph & 1;
+        const int coff = cb + achunk * EP16;
+        if (affine) {
+            // (space-to-depth reads: the affine is per physical channel, [B, Cin/4] - the four phases of a channel share it)
+            const int ci = b * cphys + cb + achunk * EP16;
+            if (p.in_scale) {
+#pragma unroll
+                for (int e4 = 0; e4 < EP16 / 4; e4++) *(float4*)&asc[e4 * 4] = *(const float4*)(p.in_scale + ci + e4 * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EP16; e++) asc[e] = 1.f;
+            }
+            if (p.in_shift) {
+#pragma unroll
+                for (int e4 = 0; e4 < EP16 / 4; e4++) *(float4*)&ash[e4 * 4] = *(const float4*)(p.in_shift + ci + e4 * 4);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EP16; e++) ash[e] = 0.f;
+            }
+        }
+        inmask = 0;
+        StaticFor<C::NA_PER>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int idx = tid + i * 256;
+            const int pix = idx / C::CH;
+            const int hx = pix % C::HW, hy = pix / C::HW;
+            const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
+            const bool inside = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W) &
+                                (C::NA_ITEMS % 256 == 0 || idx < C::NA_ITEMS);
+            const int sy = ((gy << sl) >> sh) + ay, sx = ((gx << sl) >> sh) + ax;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (inside) v = *(const uint4*)(Xb + (sy * Ws + sx) * cphys + coff);
+            inmask |= (inside ? 1u : 0u) << i;
+            areg.template get<i>() = v;
+        });
+    };
+    // ---- registers -> LDS with the fused per-(b,c) affine (inside the image only)
+    auto store_a = [&]() {
+        StaticFor<C::NA_PER>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int idx = tid + i * 256;
+            if (C::NA_ITEMS % 256 == 0 || idx < C::NA_ITEMS) {
+                const int pix = idx / C::CH;
+                const int hx = pix % C::HW, hy = pix / C::HW;
+                uint4 v = areg.template get<i>();
+                if (affine && ((inmask >> i) & 1u)) {     // padding stays zero
+                    float f[EP16];
+                    unpack16(v, f, (T*)nullptr);
+#pragma unroll
+                    for (int e = 0; e < EP16; e++) f[e] = f[e] * asc[e] + ash[e];
+                    if (p.in_relu) {
+#pragma unroll
+                        for (int e = 0; e < EP16; e++) f[e] = fmaxf(f[e], 0.f);
+                    }
+                    v = pack16(f, (T*)nullptr);
+                }
+                *(uint4*)(ldsA + hy * C::RPITCH + hx * C::PSTR + achunk * 16) = v;
+            }
+        });
+    };
+    // ---- weight stage (kernel row `row` of chunk kc): KS taps x BN rows x KC, global -> LDS directly
+    // (global_load_lds: no VGPR round trip; the LDS image is lane-linear per 1 KiB piece, so the
+    // bank-conflict swizzle is applied to the per-lane SOURCE chunk and undone by the fragment reads)
+    // The per-lane part of the source address (piece, tap within the row, weight row, swizzled chunk) does not depend on the
+    // stage: it is computed once as a 32-bit byte offset per piece; a stage adds a scalar base (kernel row, K chunk), so a
+    // piece costs one M0 write and one instruction (the address arithmetic used to be ~18 instructions per piece, ~15 % of
+    // the 128-wide configuration's time).
+    constexpr int NPW = (C::B_PIECES + 3) / 4;               // pieces per wave (the last one may not exist for every wave)
+    unsigned boff[NPW];
+    {
+        constexpr int RPP = 1024 / C::KCB;                   // weight rows per piece
+#pragma unroll
+        for (int k = 0; k < NPW; k++) {
+            const int pc = wave + 4 * k;
+            const int r = pc * RPP + lane / C::CH;           // row within the stage = t*BN + n
+            const int c = (lane % C::CH) ^ ((r / C::RP) % C::CH);
+            const int t = r / BN, n = r % BN;
+            boff[k] = (unsigned)((((size_t)t * p.Ntot + bn0 + n) * p.Cin + c * EP16) * sizeof(T));
+        }
+    }
+    auto dma_b = [&](int kc, int row, int buf) {
+        const unsigned long long sb = (unsigned long long)Wp + ((size_t)row * KS * p.Ntot * p.Cin + (size_t)kc * KC) * sizeof(T);
+        StaticFor<NPW>::run([&](auto kcst) {
+            constexpr int k = decltype(kcst)::value;
+            const int pc = wave + 4 * k;
+            if (C::B_PIECES % 4 == 0 || pc < C::B_PIECES)
+                glds16_saddr(boff[k], sb, __builtin_amdgcn_readfirstlane(ldsB_off + buf * C::B_BYTES + pc * 1024));
+        });
+    };
+
+    // ---- prologue: first halo tile, first NBUF-1 weight stages, noise tile
+    const int nstages = nchunks * KS;
+#pragma unroll
+    for (int q = 0; q < C::NBUF - 1; q++)
+        if (q < nstages) dma_b(q / KS, q % KS, q);
+    load_a(0);
+    // noise tile of the epilogue: this layer's plane (forward), or - fused tail backward, ConvParams::prep - the plane of the layer below
+    const float* __restrict__ nz_src = p.prep ? p.prep_noise : p.noise;
+    if (nz_src) {
+        const int nz_bs = p.prep ? p.prep_noise_bstride : p.noise_bstride;
+        const int OHn = p.up ? 2 * p.H : p.H, OWn = p.up ? 2 * p.W : p.W;
+        const int nph = p.up ? 4 : 1;
+        for (int idx = tid; idx < nph * C::BM; idx += 256) {
+            const int m = idx % C::BM, ph = idx / C::BM;
+            const int gy = y0 + m / TW, gx = x0 + m % TW;
+            const int oy = p.up ? 2 * gy + (ph >> 1) : gy, ox = p.up ? 2 * gx + (ph & 1) : gx;
+            ldsN[idx] = (gy < p.H && gx < p.W) ? nz_src[(size_t)b * nz_bs + (size_t)oy * OWn + ox] : 0.f;
+        }
+    }
+    store_a();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the untracked weight DMAs
+    __syncthreads();
+
+    // One K chunk = KS stages (kernel rows), unrolled so that `row` is a compile-time constant; the
+    // last chunk is a separate instantiation (LAST) so that the halo prefetch of the next chunk is
+    // unconditional in the steady-state loop (a conditional prefetch turns the staging registers
+    // into loop-carried copies and costs 2x their count in VGPRs).
+    auto chunk = [&](int kc, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        StaticFor<KS>::run([&](auto rowc) {
+            constexpr int row = decltype(rowc)::value;
+            const int s = kc * KS + row;
+            const int sbuf = s % C::NBUF;
+            const int sn = s + C::NBUF - 1;                        // stage whose weights are requested now
+            if (sn < nstages && !(p.dbg & 1)) dma_b(sn / KS, sn % KS, sn % C::NBUF);   // ring slot last read in stage s-1
+            if (row == 0 && !LAST) load_a(kc + 1);                 // consumed after the last row of this chunk
+            const unsigned char* aa = ldsA + row * C::RPITCH;
+            const unsigned char* bb = ldsB + sbuf * C::B_BYTES;
+            if (!(p.dbg & 2)) {
+                // Software-pipelined fragment loads: the LDS reads of step q+1 are issued before the
+                // MFMAs of step q, so their latency hides behind MT*NT matrix instructions instead of
+                // being exposed in front of every pair of them (a step = one 32-byte K slice of one tap).
+                constexpr int KSL = C::KCB / 32, NSTEP = KS * KSL;
+                uint4 af[2][C::MT], bf[2][C::NT];
+                auto frag = [&](int q, uint4 (&a)[C::MT], uint4 (&bq)[C::NT]) {
+                    const int t = q / KSL, ks = q % KSL;
+#pragma unroll
+                    for (int i = 0; i < C::MT; i++) a[i] = *(const uint4*)(aa + aoff[i] + t * C::PSTR + ks * 32);
+#pragma unroll
+                    for (int j = 0; j < C::NT; j++)
+                        bq[j] = *(const uint4*)(bb + t * BN * C::KCB + bbase[j] + (((ks * 2 + (lane >> 5)) ^ bsw[j]) << 4));
+                };
+                frag(0, af[0], bf[0]);
+                StaticFor<NSTEP>::run([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if (q + 1 < NSTEP) frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+#pragma unroll
+                    for (int i = 0; i < C::MT; i++)
+#pragma unroll
+                        for (int j = 0; j < C::NT; j++) Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                });
+            }
+            // Stage s+1's weights must have landed; DMA groups requested after it may stay in flight.
+            // vmcnt retires in order, so allowing (groups still wanted in flight) x DPW outstanding ops is
+            // exact for the DMAs and conservative w.r.t. the ordinary halo loads interleaved with them.
+            {
+                int fly = nstages - 2 - s; fly = fly < 0 ? 0 : (fly > C::NBUF - 2 ? C::NBUF - 2 : fly);
+                static_assert(C::NBUF <= 6 && 4 * C::DPW <= 63, "vmcnt immediate");
+                if (C::DPW == 0 || fly == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (fly == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(C::DPW) : "memory");
+                else if (fly == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * C::DPW) : "memory");
+                else if (fly == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(3 * C::DPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * C::DPW) : "memory");
+            }
+            __syncthreads();                                       // ... for every wave: stage closed
+            if (row == KS - 1 && !LAST) {                          // chunk boundary: replace the halo tile
+                store_a();
+                __syncthreads();
+            }
+        });
+    };
+    if (!(p.dbg & 8)) {
+        for (int kc = 0; kc + 1 < nchunks; kc++) chunk(kc, std::false_type{});
+        chunk(nchunks - 1, std::true_type{});
+    }
+    // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
+    // LDS is re-used as the transpose buffer from here (all reads done: barrier above); the noise tile at its end stays valid
+    conv_epilogue<T, C, TH, TW, BN, WM, WN, 256, MODE>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
+}
+
+// ------------------------------------------------------------------------- dispatch
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
+static int launch_cfg(const ConvParams& p0, hipStream_t s) {
+    ConvParams p = p0;
+    { const char* e = getenv("DGE_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.tiles_x = (p.W + TW - 1) / TW;
+    p.tiles_y = (p.H + TH - 1) / TH;
+    const int ntiles = (p.Ntot + BN - 1) / BN;
+    const long grid = (long)p.tiles_x * p.tiles_y * p.B * ntiles;
+    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN, p.prep ? "+prep" : "");
+    // epilogue mode (conv_epilogue.h): 0 plain, 1 addend / dot_src with prefetch, 2 = 1 + fused tail backward (3x3 only).
+    // The f32 parity path has no prefetch, so its mode 1 is its mode 0 with the stages enabled: it always takes >= 1.
+    const bool da = p.addend || p.dot_src;
+    DGE_CHECK(!p.prep || (KS == 3 && p.dot_src), "conv: prep is offered for 3x3 data-gradient launches only");
+#define DGE_GO(MODE) hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN, MODE>), dim3((unsigned)grid), dim3(256), 0, s, p)
+    if constexpr (KS == 3) {
+        if (p.prep) DGE_GO(2);
+        else if (da || sizeof(T) == 4) DGE_GO(1);
+        else DGE_GO(0);
+    } else {
+        if (da || sizeof(T) == 4) DGE_GO(1);
+        else DGE_GO(0);
+    }
+#undef DGE_GO
+    DGE_LAUNCH_CHECK("conv_igemm");
+    return 0;
+}
+
+// K-chunk (elements): 64 bytes when the channel count allows it, else 32 bytes.
+static int kchunk(int cin, int esize) { return cin % (64 / esize) == 0 ? 64 / esize : 32 / esize; }
+
+template <typename T, int KS>
+static int launch_t(const ConvParams& p, hipStream_t s) {
+    constexpr int E = (int)sizeof(T);
+    constexpr int K0 = 64 / E, K1 = 32 / E;
+    int bn = dge_conv_ntile(p.Ntot);
+    if (bn == 128) {             // 128-wide N tiles only when they still give every CU two workgroups (measured: 223 vs 263 us
+                                 // on 256->256 @128^2 B=8, but 117 vs 88 us on 512->512 @64^2 B=2)
+        const long blocks128 = (long)((p.H + 15) / 16) * ((p.W + 15) / 16) * p.B * (p.Ntot / 128);
+        if (blocks128 < 512) bn = 64;
+    }
+    { const char* e = getenv("DGE_CONV_BN"); if (e) bn = atoi(e); }
+    if (p.up && bn < 64) bn = 64;       // the 32-wide configurations hold a single-phase noise tile
+    int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
+    { const char* e = getenv("DGE_CONV_KC"); if (e) kc = atoi(e); }
+    const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
+    bool small = (p.H <= 8 && p.W <= 8) || work < 256L * 256;
+    { const char* e = getenv("DGE_CONV_SMALL"); if (e) small = atoi(e) != 0; }
+#define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
+    if (small) {           // 8x8 pixel tiles, narrower N tiles: more workgroups for the low-resolution layers
+        if (bn >= 64) {
+            // 256- / 128-byte K chunks when the channel count allows: fewer stages / barriers / halo restages in the serial K
+            // loop (measured 512->512 @8^2 B=8: 41 us with 64-byte chunks, 32 us with 128, 27 us with 256)
+            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (4 * K0) == 0 && !getenv("DGE_CONV_NOK4")) GO(8, 8, 64, 4 * K0, 2, 2);
+            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (2 * K0) == 0 && !getenv("DGE_CONV_NOK2")) GO(8, 8, 64, 2 * K0, 2, 2);
+            if (kc == K0) GO(8, 8, 64, K0, 2, 2);
+            GO(8, 8, 64, K1, 2, 2);
+        }
+        if (kc == K0) GO(8, 16, 32, K0, 4, 1); GO(8, 16, 32, K1, 4, 1);
+    }
+    if (bn == 128) { if (kc == K0) GO(16, 16, 128, K0, 2, 2); GO(16, 16, 128, K1, 2, 2); }
+    if (bn == 64)  { if (kc == K0) GO(16, 16, 64, K0, 4, 1);  GO(16, 16, 64, K1, 4, 1); }
+    if (kc == K0) GO(16, 16, 32, K0, 4, 1); GO(16, 16, 32, K1, 4, 1);
+#undef GO
+}
+

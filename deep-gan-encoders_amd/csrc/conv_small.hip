@@ -46,7 +46,7 @@ __device__ __forceinline__ f32x16_t mma(const uint4& a, const uint4& b, f32x16_t
 }
 
 // KQ = K steps (16 channels) per wave and tap = Cin / 64
-template <int KQ, bool PREP>
+template <int KQ, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
     constexpr int CIN = KQ * 64, CH = CIN / 8;                 // CH = 16-byte chunks per pixel
     constexpr int PSTR = pstr_of(CIN), RPITCH = rpitch_of(CIN);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
             tile[0][0][r] = s;
         }
     }
-    conv_epilogue<bf16_t, SmallCfg, TH, TW, BN, 2, 2, 512, PREP>(p, tile, lds + RED_BYTES, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i,
+    conv_epilogue<bf16_t, SmallCfg, TH, TW, BN, 2, 2, 512, MODE>(p, tile, lds + RED_BYTES, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i,
                                                             wave, lane, tid, carrier);
 }
 
@@ -219,13 +219,11 @@ int dge_conv_small_launch(const ConvParams& p0, hipStream_t s) {
     const long grid = (long)p.tiles_x * p.tiles_y * p.B * (p.Ntot / BN);
     DGE_CHECK(grid > 0 && grid < (1L << 31), "conv_small: bad grid");
     dge_note_kernel("conv_small<bf16,8,8,64,%d>%s", p.Cin, p.prep ? "+prep" : "");
-    if (p.Cin == 512) {
-        if (p.prep) hipLaunchKernelGGL((conv_small_kernel<8, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_small_kernel<8, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
-    } else {
-        if (p.prep) hipLaunchKernelGGL((conv_small_kernel<4, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_small_kernel<4, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
-    }
+    const int mode = p.prep ? 2 : ((p.addend || p.dot_src) ? 1 : 0);      // epilogue mode (conv_epilogue.h)
+#define DGE_GO(KQ, MODE) hipLaunchKernelGGL((conv_small_kernel<KQ, MODE>), dim3((unsigned)grid), dim3(512), 0, s, p)
+    if (p.Cin == 512) { if (mode == 2) DGE_GO(8, 2); else if (mode == 1) DGE_GO(8, 1); else DGE_GO(8, 0); }
+    else { if (mode == 2) DGE_GO(4, 2); else if (mode == 1) DGE_GO(4, 1); else DGE_GO(4, 0); }
+#undef DGE_GO
     DGE_LAUNCH_CHECK("conv_small");
     return 0;
 }
