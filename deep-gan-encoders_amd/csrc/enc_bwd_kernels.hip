@@ -654,12 +654,18 @@ __global__ void head_bwd_param_kernel(const HeadEntry* __restrict__ tab, const f
 // =================================================================== C ABI
 #define CHAN_OK(C, ep) ((C) % (ep) == 0 && (C) / (ep) <= 256 && 256 % ((C) / (ep)) == 0)
 
+int dge_wgrad_dma_try(const void* g, const void* x, const float* sc, const float* sh, float* dw, int B, int H, int W, int cout, int cin,
+                      hipStream_t s);       // wgrad_dma.hip: 0 done, 1 shape not covered, < 0 error
 extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H,
                               int W, int cout, int cin, int ksize, int dtype, hipStream_t s) {
     DGE_CHECK(ksize == 1 || ksize == 3, "conv_wgrad: ksize %d unsupported", ksize);
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(cout % ep == 0 && cin % ep == 0, "conv_wgrad: channels must be multiples of %d", ep);
     DGE_CHECK((in_scale == nullptr) == (in_shift == nullptr), "conv_wgrad: in_scale and in_shift go together");
+    if (dtype == DGE_BF16 && ksize == 3) {       // the streaming kernel (LDS-DMA ring, affine on the accumulators)
+        const int r = dge_wgrad_dma_try(g, x, in_scale, in_shift, dw, B, H, W, cout, cin, s);
+        if (r <= 0) return r;
+    }
     const bool tall = dtype == DGE_BF16 && H >= 16 && !getenv("DGE_WGRAD_TH8");
     const int tx = (W + 15) / 16, ty = tall ? (H + 15) / 16 : (H + 7) / 8;
     const int ntiles = tx * ty * B;

@@ -328,9 +328,11 @@ def test_up_layer_data_gradient_fullsize(cin, cout, Rin, B, kernel):
 
 WGRADS = [
     # (cin, cout, R, B, k, affine, kernel)
-    (16, 16, 1024, 8, 3, True, "conv_wgrad_tr<3,16>"),             # encoder block 0 conv_1
-    (16, 32, 1024, 8, 3, True, "conv_wgrad_tr<3,16>"),             # block 0 conv_2
-    (32, 32, 512, 8, 3, True, "conv_wgrad_tr<3,16>"),
+    (16, 16, 1024, 8, 3, True, "wgrad_dma<16,32,32,3>"),           # encoder block 0 conv_1
+    (16, 32, 1024, 8, 3, True, "wgrad_dma<16,64,32,2>"),           # block 0 conv_2
+    (32, 32, 512, 8, 3, True, "wgrad_dma<16,64,64,2>"),
+    (128, 128, 128, 8, 3, True, "wgrad_dma<16,64,64,2>"),          # block 3 conv_1 (16 (o, i) tiles share every pixel tile)
+    (256, 512, 64, 8, 3, True, "wgrad_dma<16,64,64,2>"),           # block 4 conv_2 (one workgroup per sample and (o, i) tile)
     (512, 512, 16, 8, 3, True, "conv_wgrad_tr<3,16>"),
     (512, 512, 8, 8, 3, True, "conv_wgrad_tr<3,8>"),
     (16, 32, 512, 8, 1, False, "conv_wgrad_tr<1,16>"),             # block 0 conv_3
@@ -354,9 +356,11 @@ def test_weight_gradient_fullsize(cin, cout, R, B, k, affine, kernel):
     if affine:
         xs = CR.affine(xs, sc.cpu(), sh.cpu())
     gc = gy.float().permute(0, 3, 1, 2).cpu()
-    # exact-arithmetic bound: the affine result is a bf16 MFMA operand (as in the forward conv); f32 accumulation over up to
-    # 2^23 pixels in MFMA accumulators + f32 atomics across workgroups (measured: L2 1e-7 .. 3.8e-6, max 2e-7 .. 5.7e-6)
-    want_q = CR.conv_wgrad(gc, CR.bf16_round(xs), k)
+    # exact-arithmetic bound.  conv_wgrad_tr: the affine result is a bf16 MFMA operand (as in the forward conv).  wgrad_dma: x
+    # enters the MFMA as stored and the affine is applied in f32 to the sums (scale) / through the border-corrected sums of g
+    # (shift), i.e. the plain f32 oracle.  Both: f32 accumulation over up to 2^23 pixels in MFMA accumulators + f32 atomics across
+    # workgroups (measured: L2 1e-7 .. 3.8e-6, max 2e-7 .. 5.7e-6)
+    want_q = CR.conv_wgrad(gc, xs if kernel.startswith("wgrad_dma") else CR.bf16_round(xs), k)
     err_q = ((dw.cpu() - want_q).norm() / want_q.norm()).item()
     err_max = ((dw.cpu() - want_q).abs().max() / want_q.abs().max()).item()
     print(f"wgrad {cin}->{cout}@{R} k{k}: L2 {err_q:.2e} max {err_max:.2e}")

@@ -17,4 +17,5 @@ e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / N
 fl = 2 * k * k * cin * cout * H * H * B
 byts = (x.numel() + g.numel()) * 2
-print(f"wgrad B={B} {cin}->{cout} H={H} k={k}: {t*1e3:.1f} us  {fl/t/1e9:.1f} TF/s  {byts/t/1e6:.0f} GB/s")
+from dge_amd._lib import last_kernel
+print(f"wgrad B={B} {cin}->{cout} H={H} k={k}: {t*1e3:.1f} us  {fl/t/1e9:.1f} TF/s  {byts/t/1e6:.0f} GB/s  {last_kernel()}")
