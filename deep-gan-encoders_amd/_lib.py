@@ -20,14 +20,21 @@ class ConvDesc(C.Structure):
         ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float), ("add_scale", C.c_float),
         ("dtype", C.c_int), ("in_up2", C.c_int), ("in_relu", C.c_int), ("stats_slots", C.c_int), ("w_layout", C.c_int),
         ("prep", C.c_int), ("prep_gain", C.c_float), ("prep_noise", C.c_void_p), ("prep_ns", C.c_void_p), ("prep_noise_batch", C.c_int),
-        ("prep_stats", C.c_void_p),
+        ("prep_stats", C.c_void_p), ("mask_relu", C.c_int),
     ]
+
+
+class S2GradEntry(C.Structure):
+    _fields_ = [("P", C.c_void_p), ("st", C.c_void_p), ("d", C.c_void_p), ("s", C.c_void_p), ("bias", C.c_void_p), ("wsq", C.c_void_p),
+                ("gs", C.c_void_p), ("wstyle", C.c_void_p),
+                ("nslot_p", C.c_int), ("nslot_s", C.c_int), ("in_c", C.c_int), ("out_c", C.c_int), ("row", C.c_int), ("bscale", C.c_float)]
 
 
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes; every symbol declared in include/dge_hip.h must be listed here
 SIGNATURES = {
     "dge_conv2d": [C.POINTER(ConvDesc), _P],
+    "dge_s2_style_grads": [C.POINTER(S2GradEntry), _I, _P, _I, _I, _I, _F, _P],
     "dge_conv_small_supported": [_I, _I, _I, _I, _I, _I, _I, _I],
     "dge_torgb_bwd_prep": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P],
     "dge_demod_bwd_prep": [_P, _I, _P, _P, _P, _I, _I, _F, _P],
@@ -108,6 +115,7 @@ SIGNATURES = {
     "dge_rgb_tanh": [_P, _P, _I, _I, _I, _I, _P],
     "dge_guided_relu_bwd": [_P, _P, _P, C.c_long, _I, _I, _P],
     "dge_maxpool2_relu_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dge_maxpool2_bwd_relu": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dge_adaptive_pool7": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dge_adaptive_pool7_bwd": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dge_class_target": [_P, _P, _P, _P, _I, _I, _P],

@@ -146,7 +146,12 @@ def synthesis_backward(mod, wp, saved, g_image):
                                             layers[top]["noise"], Lt.noise_strength.detach().reshape(1), Lt.gain)
     else:
         g_x, g_srgb = ops.torgb_bwd(g_img, layers[top]["y"], Ot.weight.detach().reshape(3, -1), saved["rgb"][top // 2]["s"], Ot.wscale)
-    ops.linear_t(g_srgb, Ot.style.weight.detach(), g_wp[:, top + 1], scale=Ot.style.wscale, accumulate=True)
+    # fused mode: every style gradient leaves in ONE launch at the end (dge_s2_style_grads) - none of them feeds the chain
+    blocks = [] if fused else None
+    if fused:
+        blocks.append(dict(gs=g_srgb, wstyle=Ot.style.weight.detach(), row=top + 1))
+    else:
+        ops.linear_t(g_srgb, Ot.style.weight.detach(), g_wp[:, top + 1], scale=Ot.style.wscale, accumulate=True)
     if top // 2 > 0:
         g_img = ops.up2_bwd(g_img)
     for i in range(top, -1, -1):
@@ -166,10 +171,13 @@ def synthesis_backward(mod, wp, saved, g_image):
             Op = getattr(mod, f"output{kp}")
             # g_img has already been brought down to this resolution by up2_bwd above
             addend, g_srgb = ops.torgb_bwd(g_img, x_in, Op.weight.detach().reshape(3, -1), saved["rgb"][kp]["s"], Op.wscale)
-            ops.linear_t(g_srgb, Op.style.weight.detach(), g_wp[:, i], scale=Op.style.wscale, accumulate=True)
+            if fused:
+                blocks.append(dict(gs=g_srgb, wstyle=Op.style.weight.detach(), row=i))
+            else:
+                ops.linear_t(g_srgb, Op.style.weight.detach(), g_wp[:, i], scale=Op.style.wscale, accumulate=True)
             if kp > 0:
                 g_img = ops.up2_bwd(g_img)
-        st = ops.zeros((B, L.in_c, 2), dev)
+        st = ops.SlotStats(B, L.in_c, dev) if fused else ops.zeros((B, L.in_c, 2), dev)
         prep, P_next = None, None
         # (the space-to-depth data gradient of a narrow up layer - layer 15: 64 -> 32 channels - loses more in its 64-wide tile
         #  than the separate pass costs: measured 890 vs 747 us; tools/perf_prep.py)
@@ -180,16 +188,27 @@ def synthesis_backward(mod, wp, saved, g_image):
         g_xprev = ops.conv2d(g_y, _dgrad_weight(L, dt), L.in_c, 3, in_s2d=L.up, in_scale=d_in, out_scale=rec["s"], addend=addend,
                              add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
         # ---- style / demodulation gradients -> g_wp[:, i]
+        _, wsq = L._prepared(dt)
+        if fused and P is not None:
+            blocks.append(dict(P=P, st=st, d=rec["d"], s=rec["s"], bias=L.bias.detach(), wsq=wsq, bscale=L.bscale,
+                               wstyle=L.style.weight.detach(), row=i))
+            g_x, P = g_xprev, P_next
+            continue
+        if fused:            # (a layer whose tail backward ran as a pass of its own: its sums sit in R)
+            st_t = ops.zeros((B, L.in_c, 2), dev)
+            ops.check(ops.lib().dge_sum_slots(ops._p(st.buf), ops._p(st_t), st.nslot, st_t.numel(), 0, ops._stream()), "dge_sum_slots")
+            st = st_t
         if P is not None:
             t = ops.demod_bwd_prep(P, rec["d"], L.bias.detach(), L.bscale)
         else:
             t = ops.demod_bwd(R, rec["d"], L.bias.detach(), L.noise_strength.detach().reshape(1), L.bscale)
-        _, wsq = L._prepared(dt)
         gs_view = st.view(B, -1)      # [B, 2*Cin]: element (b, 2*i) = g_s[b,i]
         ops.linear_t(t, wsq, gs_view, mul=rec["s"], accumulate=True, incy=2, ldy=2 * L.in_c)
         ops.linear_t(gs_view, L.style.weight.detach(), g_wp[:, i], scale=L.style.wscale, accumulate=True, incx=2,
                      ldx=2 * L.in_c, O=L.in_c)
         g_x, P = g_xprev, P_next
+    if blocks:
+        ops.s2_style_grads(blocks, g_wp, getattr(mod, "layer0").style.wscale)
     return g_wp
 
 

@@ -48,7 +48,8 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(!(d->up && d->in_s2d), "conv2d: up and in_s2d are exclusive");
     DGE_CHECK(!d->in_up2 || (!d->in_s2d && d->H % 2 == 0 && d->W % 2 == 0), "conv2d: in_up2 needs even H, W and no in_s2d");
     DGE_CHECK(!d->in_s2d || d->Cin % 4 == 0, "conv2d: in_s2d needs Cin %% 4 == 0");
-    DGE_CHECK(!d->dot_src || d->stats, "conv2d: dot_src needs a stats buffer");
+    DGE_CHECK(!d->dot_src || d->stats || d->mask_relu, "conv2d: dot_src needs a stats buffer");
+    DGE_CHECK(!d->mask_relu || (d->dot_src && !d->prep && !d->up), "conv2d: mask_relu needs dot_src and excludes prep / up");
     DGE_CHECK(!d->in_relu || d->in_scale || d->in_shift, "conv2d: in_relu is applied together with the prologue affine");
     DGE_CHECK(d->gain > 0.f, "conv2d: gain must be positive (it is folded through the activation)");
     DGE_CHECK((((uintptr_t)d->in_scale | (uintptr_t)d->in_shift) & 15) == 0, "conv2d: in_scale/in_shift must be 16-byte aligned");
@@ -68,6 +69,7 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.tiles_x = p.tiles_y = 0;
     p.w_frag = d->w_layout == 1 ? 1 : 0;
     p.prep = d->prep ? 1 : 0;
+    p.mask_relu = d->mask_relu ? 1 : 0;
     p.prep_gain = d->prep_gain; p.prep_noise = d->prep_noise; p.prep_ns = d->prep_ns; p.prep_stats = d->prep_stats;
     p.prep_noise_bstride = d->prep_noise_batch > 1 ? OH * OW : 0;
     DGE_CHECK(!d->prep || (d->dot_src && d->prep_stats && d->prep_gain > 0.f && !d->up), "conv2d: prep needs dot_src, prep_stats, a positive prep_gain and no up mode");

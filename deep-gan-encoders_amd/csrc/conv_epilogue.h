@@ -184,6 +184,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
 #pragma unroll
                             for (int e = 0; e < EP16; e++) f[e] += p.add_scale * ad[e];
                         }
+                        if (DOT && p.mask_relu) {          // ReLU backward of the layer below (ConvParams::mask_relu)
+#pragma unroll
+                            for (int e = 0; e < EP16; e++) f[e] = d[e] > 0.f ? f[e] : 0.f;
+                        }
                         if constexpr (PREP) if (prep) {
                             const float nzs = pnz ? pns * ldsN[m] : 0.f;
 #pragma unroll

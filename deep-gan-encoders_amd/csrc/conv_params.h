@@ -41,6 +41,7 @@ struct ConvParams {
     const float* prep_ns;     // its noise strength (device scalar), or null
     int prep_noise_bstride;   // 0 (shared plane) or OH*OW
     float* prep_stats;        // [slots][B,Cout,2], pre-zeroed (same slot count as `stats`)
+    int mask_relu;            // 1: result *= [dot_src > 0] (ReLU backward of the layer below), no dot statistics
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);

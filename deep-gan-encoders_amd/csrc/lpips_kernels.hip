@@ -86,7 +86,7 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ gy, const T* __restrict
             for (int q = 1; q < 4; q++) if (f[q][e] > mv) { mv = f[q][e]; am = q; }
             if (am == me) out[e] = g[e];
             // (the gradient lands on the arg-max only, whose value is mv)
-            if (relu_mode && !(mv > 0.f && (relu_mode == 1 || out[e] > 0.f))) out[e] = 0.f;
+            if (relu_mode && relu_mode != 3 && !(mv > 0.f && (relu_mode == 1 || out[e] > 0.f))) out[e] = 0.f;
         }
     }
     if (addend) {
@@ -94,6 +94,12 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ gy, const T* __restrict
         unpack16(*(const uint4*)(addend + o), a, (T*)nullptr);
 #pragma unroll
         for (int e = 0; e < EP; e++) out[e] += a[e];
+    }
+    if (relu_mode == 3) {           // ReLU backward of the layer that produced x, on the complete gradient (pool route + addend)
+        float xs[EP];
+        unpack16(*(const uint4*)(x + o), xs, (T*)nullptr);
+#pragma unroll
+        for (int e = 0; e < EP; e++) out[e] = xs[e] > 0.f ? out[e] : 0.f;
     }
     *(uint4*)(gx + o) = pack16(out, (T*)nullptr);
 }
@@ -222,7 +228,7 @@ static int maxpool2_bwd_launch(const void* gy, const void* x, const void* addend
                                int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0, "maxpool2_bwd: C %% %d != 0", ep);
-    DGE_CHECK(H % 2 == 0 && W % 2 == 0 || relu_mode == 0, "maxpool2_relu_bwd: H and W must be even");
+    DGE_CHECK((H % 2 == 0 && W % 2 == 0) || relu_mode == 0 || relu_mode == 3, "maxpool2_relu_bwd: H and W must be even");
     const long n = (long)B * H * W * (C / ep);
     if (dtype == DGE_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, (const bf16_t*)addend, (bf16_t*)gx, B, H, W, C, relu_mode);
     else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)gy, (const float*)x, (const float*)addend, (float*)gx, B, H, W, C, relu_mode);
@@ -233,6 +239,11 @@ static int maxpool2_bwd_launch(const void* gy, const void* x, const void* addend
 extern "C" int dge_maxpool2_bwd(const void* gy, const void* x, const void* addend, void* gx, int B, int H, int W, int C, int dtype,
                                 hipStream_t s) {
     return maxpool2_bwd_launch(gy, x, addend, gx, B, H, W, C, 0, dtype, s);
+}
+
+extern "C" int dge_maxpool2_bwd_relu(const void* gy, const void* x, const void* addend, void* gx, int B, int H, int W, int C, int dtype,
+                                     hipStream_t s) {
+    return maxpool2_bwd_launch(gy, x, addend, gx, B, H, W, C, 3, dtype, s);
 }
 
 extern "C" int dge_maxpool2_relu_bwd(const void* gy, const void* x, void* gx, int B, int H, int W, int C, int guided, int dtype,

@@ -233,6 +233,72 @@ extern "C" int dge_demod_bwd(const float* R, const float* d, const float* bias, 
     return 0;
 }
 
+// ------------------------------------------------------------------ every style gradient of a synthesis backward in one launch
+// Per modulated block the backward ends in three small steps (stylegan2_generator.py:858-864,908-909 differentiated):
+//   t[b,o]   = -(P0 - bias[o]*bscale*P1) * d[b,o]^2                      (demodulation gradient from the fused tail sums)
+//   g_s[b,c] = st[b,c,0] + s[b,c] * sum_o t[b,o] * wsq[o,c]              (direct part from the data-gradient statistics)
+//   g_wp[b,row,:] += wscale * sum_c g_s[b,c] * Wstyle[c,:]               (transposed style DenseBlock)
+// (toRGB blocks: g_s comes from dge_torgb_bwd).  None of it feeds the data-gradient chain, so the per-layer launches (4 x 17 + 9
+// of 5 us each) are replaced by ONE launch at the end of the backward over a table of the blocks, passed by value.
+// Two blocks may share a row (layer 2k+1 and toRGB k): their contributions meet in g_wp (pre-zeroed) through atomics; a sum of
+// two terms is order independent.
+struct S2GradTable { dge_s2_grad_entry e[32]; };
+__global__ __launch_bounds__(512) void s2_style_grads_kernel(S2GradTable tab, float* __restrict__ g_wp, int B, int nrows, int K, float wscale) {
+    __shared__ float t[512], gs[512];
+    const dge_s2_grad_entry e = tab.e[blockIdx.x];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (e.P) {
+        for (int o = tid; o < e.out_c; o += 512) {
+            const int idx = b * e.out_c + o;
+            const float2 pp = sum_slot_pairs(e.P + (size_t)idx * 2, (size_t)B * e.out_c * 2, e.nslot_p);
+            const float dv = e.d[idx];
+            t[o] = -(pp.x - e.bias[o] * e.bscale * pp.y) * dv * dv;
+        }
+        __syncthreads();
+        for (int c = tid; c < e.in_c; c += 512) {
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int o = 0;
+            for (; o + 3 < e.out_c; o += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[j] = fmaf(t[o + j], e.wsq[(size_t)(o + j) * e.in_c + c], acc[j]);
+            }
+            for (; o < e.out_c; o++) acc[0] = fmaf(t[o], e.wsq[(size_t)o * e.in_c + c], acc[0]);
+            const int idx = b * e.in_c + c;
+            const float2 ss = sum_slot_pairs(e.st + (size_t)idx * 2, (size_t)B * e.in_c * 2, e.nslot_s);
+            gs[c] = ss.x + e.s[idx] * ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        }
+    } else {
+        for (int c = tid; c < e.in_c; c += 512) gs[c] = e.gs[b * e.in_c + c];
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 512) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int c = 0;
+        for (; c + 3 < e.in_c; c += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] = fmaf(gs[c + j], e.wstyle[(size_t)(c + j) * K + k], acc[j]);
+        }
+        for (; c < e.in_c; c++) acc[0] = fmaf(gs[c], e.wstyle[(size_t)c * K + k], acc[0]);
+        atomicAdd(g_wp + ((size_t)b * nrows + e.row) * K + k, wscale * ((acc[0] + acc[1]) + (acc[2] + acc[3])));
+    }
+}
+
+extern "C" int dge_s2_style_grads(const dge_s2_grad_entry* entries, int n, float* g_wp, int B, int nrows, int K, float wscale,
+                                  hipStream_t s) {
+    DGE_CHECK(entries && n >= 1 && n <= 32 && B >= 1 && B <= 65535, "s2_style_grads: 1..32 blocks");
+    S2GradTable tab;
+    for (int i = 0; i < n; i++) {
+        const dge_s2_grad_entry& e = entries[i];
+        DGE_CHECK(e.in_c >= 1 && e.in_c <= 512 && e.row >= 0 && e.row < nrows && e.wstyle, "s2_style_grads: bad block %d", i);
+        DGE_CHECK(e.P ? (e.st && e.d && e.s && e.bias && e.wsq && e.out_c >= 1 && e.out_c <= 512 && e.nslot_p >= 1 && e.nslot_s >= 1) : e.gs != nullptr,
+                  "s2_style_grads: block %d is neither a conv block (P, st, d, s, bias, wsq) nor a toRGB block (gs)", i);
+        tab.e[i] = e;
+    }
+    hipLaunchKernelGGL(s2_style_grads_kernel, dim3(n, B), dim3(512), 0, s, tab, g_wp, B, nrows, K, wscale);
+    DGE_LAUNCH_CHECK("s2_style_grads");
+    return 0;
+}
+
 extern "C" int dge_demod_bwd_prep(const float* P, int nslot, const float* d, const float* bias, float* t, int B, int C, float bscale,
                                   hipStream_t s) {
     DGE_CHECK(nslot >= 1, "demod_bwd_prep: bad slot count");

@@ -102,7 +102,6 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
             sctab[idx] = ch < Ci ? sc[b * Ci + ch] : 1.f;
             ktab[idx] = ch < Ci ? sh[b * Ci + ch] : 0.f;
         }
-        for (int idx = tid; idx < 9 * 32; idx += NT) gtab[idx] = 0.f;
     }
     __syncthreads();
     f32x16_t acc[9];
@@ -188,17 +187,27 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
     // compute side of the tile sequence
     int crem = t_begin - smp * tps, cty = crem / tiles_x, ctx = crem - cty * tiles_x;
 
-    // the running sample's border / total sums of g: waves and pixel halves are combined in gtab
+    // the sample's border / total sums of g after the last tile: the pixel halves are combined by a lane exchange, the waves in
+    // wave order through the (now free) ring memory - a fixed summation order, whatever the mode
     auto gather_sums = [&]() {
         float v[9] = {s_tot, s_top, s_bot, s_lft, s_rgt, s_tl, s_tr, s_bl, s_br};
+        float* part = (float*)lds;                         // [NW][9][32]
+        __syncthreads();                                   // every wave is done with the last stage
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             v[k] += __shfl_xor(v[k], 32, 64);
-            if (lane < 32) atomicAdd(&gtab[k * 32 + lane], v[k]);
+            if (lane < 32) part[(wave * 9 + k) * 32 + lane] = v[k];
         }
-        s_tot = s_top = s_bot = s_lft = s_rgt = s_tl = s_tr = s_bl = s_br = 0.f;
+        __syncthreads();
+        for (int idx = tid; idx < 9 * 32; idx += NT) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; w++) t += part[w * 9 * 32 + idx];
+            gtab[idx] = t;
+        }
         __syncthreads();
     };
+
 #pragma unroll
     for (int s = 0; s < NS - 1; s++) if (t_begin + s < t_end) issue(s);
     int stage = 0;

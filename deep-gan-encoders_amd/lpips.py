@@ -181,32 +181,25 @@ class LPIPS(nn.Module):
         check(L.dge_mean(_p(val), _p(out), B, _stream()), "dge_mean")
         if not need_grad:
             return out, None
-        # ---- backward through VGG16 for the b half of the batch
-        g = None                     # gradient w.r.t. acts[ci][B:] (post-relu)
+        # ---- backward through VGG16 for the b half of the batch.  g_pre = gradient w.r.t. the PRE-activation of conv ci; the ReLU
+        #      backward of conv ci-1 rides in the launch that produces its input gradient (data-gradient epilogue / pool adjoint),
+        #      except where that launch runs on the streaming kernel (64 -> 64 at 256^2), which has no such stage.
+        g_pre = ops.act_bwd(heads[_TAP_AFTER.index(12)], acts[12][B:], slope=0.0)
         for ci in range(12, -1, -1):
-            f_b = acts[ci][B:]
-            if ci in _TAP_AFTER:
-                hk = heads[_TAP_AFTER.index(ci)]
-                if g is None:
-                    g = hk
-            # relu backward -> gradient w.r.t. the conv output (pre-activation)
-            g_pre = ops.act_bwd(g, f_b, slope=0.0)
             cin = _CPAD if ci == 0 else _VGG_CIN[ci]
-            # input of conv ci and whether it came through a max pool
-            g_in = ops.conv2d(g_pre, self._packed(ci, dt, ops.PACK_DGRAD, g_pre.shape[1:3]), cin, 3,
-                              addend=(heads[_TAP_AFTER.index(ci - 1)] if (ci - 1 in _TAP_AFTER and ci not in pools) else None))
+            wd = self._packed(ci, dt, ops.PACK_DGRAD, g_pre.shape[1:3])
             if ci == 0:
-                g = g_in
+                g = ops.conv2d(g_pre, wd, cin, 3)
                 break
-            if ci in pools:          # conv ci read a pooled tensor: route through the max pool, add the tap gradient
-                src = acts[ci - 1][B:]
-                _, Hs, Ws, Cs = src.shape
-                gx = torch.empty_like(src)
-                add = heads[_TAP_AFTER.index(ci - 1)] if (ci - 1) in _TAP_AFTER else None
-                check(L.dge_maxpool2_bwd(_p(g_in), _p(src), _p(add), _p(gx), B, Hs, Ws, Cs, dt, _stream()), "dge_maxpool2_bwd")
-                g = gx
+            below = acts[ci - 1][B:]
+            head = heads[_TAP_AFTER.index(ci - 1)] if (ci - 1) in _TAP_AFTER else None
+            if ci in pools:          # conv ci read a pooled tensor: route through the max pool, add the tap gradient, ReLU backward
+                g_in = ops.conv2d(g_pre, wd, cin, 3)
+                g_pre = ops.maxpool2_bwd(g_in, below, head, relu=True)
+            elif head is None and cin <= 64 and _VGG_COUT[ci] <= 64 and g_pre.shape[1] >= 128:
+                g_pre = ops.act_bwd(ops.conv2d(g_pre, wd, cin, 3), below, slope=0.0)
             else:
-                g = g_in
+                g_pre = ops.conv2d(g_pre, wd, cin, 3, addend=head, relu_mask=below)
         gb = torch.empty((B, 3, h, w), dtype=torch.float32, device=dev)
         check(L.dge_lpips_prep_bwd(_p(g), _p(gb), B, h * w, _CPAD, scale, 1.0, 0, dt, _stream()), "dge_lpips_prep_bwd")
         return out, gb
@@ -221,3 +214,4 @@ class LPIPS(nn.Module):
 
 
 _VGG_CIN = [item[0] for item in _VGG if item != "M"]
+_VGG_COUT = [item[1] for item in _VGG if item != "M"]

@@ -306,10 +306,11 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None):
+           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout].
     `prep`: dict(gain, noise [1|B,OH,OW] or None, ns (device scalar) or None, stats=SlotStats(B, cout)) - the fused tail backward of
-    the layer that produced `dot_src` (dge_conv_desc.prep): y is then g_z and prep['stats'] receives (sum g_z*(z - ns*noise), sum g_z)."""
+    the layer that produced `dot_src` (dge_conv_desc.prep): y is then g_z and prep['stats'] receives (sum g_z*(z - ns*noise), sum g_z).
+    `relu_mask`: stored activation a = relu(pre) of the layer below: the result is multiplied by [a > 0] (dge_conv_desc.mask_relu)."""
     B, H, W, Cin = x.shape
     if in_s2d:            # x is the fine grid [B,2H,2W,C]; logical input is [B,H,W,4C]
         H, W, Cin = H // 2, W // 2, Cin * 4
@@ -320,6 +321,11 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     if out is None:
         out = torch.empty((B, OH, OW, cout), dtype=x.dtype, device=x.device)
     d = ConvDesc()
+    if relu_mask is not None:
+        if dot_src is not None or prep is not None:
+            raise DgeError("conv2d: relu_mask excludes dot_src / prep")
+        dot_src = relu_mask
+    d.mask_relu = 0 if relu_mask is None else 1
     d.x, d.w_packed, d.y, d.addend, d.dot_src = _p(x), _p(w_packed), _p(out), _p(addend), _p(dot_src)
     d.in_scale, d.in_shift, d.out_scale = _f32(in_scale), _f32(in_shift), _f32(out_scale)
     # statistics atomics of large grids are spread over several copies (same-address contention), then combined
@@ -483,6 +489,30 @@ def linear_t(x, w, y, mul=None, scale=1.0, accumulate=False, incx=1, incy=1, ldx
     check(lib().dge_linear_t(C.c_void_p(x.data_ptr()), ldx, incx, _f32(w), _f32(mul), C.c_void_p(y.data_ptr()), ldy, incy,
                              B, O, K, float(scale), 1 if accumulate else 0, _stream()), "dge_linear_t")
     return y
+
+
+def s2_style_grads(blocks, g_wp, wscale):
+    """blocks: list of dicts - conv block: P (SlotStats or [B,out_c,2]), st (SlotStats), d, s, bias, wsq, bscale, wstyle, row;
+    toRGB block: gs, wstyle, row.  One launch for every style gradient of the synthesis backward (dge_s2_style_grads)."""
+    from ._lib import S2GradEntry
+    arr = (S2GradEntry * len(blocks))()
+    B, nrows, K = g_wp.shape
+    for e, blk in zip(arr, blocks):
+        e.wstyle, e.row = _f32(blk["wstyle"]), int(blk["row"])
+        if "gs" in blk:
+            e.gs, e.in_c = _f32(blk["gs"]), blk["gs"].shape[1]
+            continue
+        P, st = blk["P"], blk["st"]
+        e.nslot_p, e.nslot_s = 1, 1
+        if isinstance(P, SlotStats):
+            e.nslot_p, P = P.nslot, P.buf
+        if isinstance(st, SlotStats):
+            e.nslot_s, st = st.nslot, st.buf
+        e.P, e.st, e.d, e.s, e.bias, e.wsq = _f32(P), _f32(st), _f32(blk["d"]), _f32(blk["s"]), _f32(blk["bias"]), _f32(blk["wsq"])
+        e.out_c, e.in_c = blk["d"].shape[1], blk["s"].shape[1]
+        e.bscale = float(blk["bscale"])
+    check(lib().dge_s2_style_grads(arr, len(blocks), _p(g_wp), B, nrows, K, float(wscale), _stream()), "dge_s2_style_grads")
+    return g_wp
 
 
 def torgb_bwd(gimg, x, wrgb, style, wscale):
@@ -775,11 +805,12 @@ def rgb_tanh_bwd(gimg, img, Cc, dtype):
     return gy
 
 
-def maxpool2_bwd(gy, x, addend=None):
-    """gy [B,H/2,W/2,C], x [B,H,W,C] (the pooled tensor) -> gx [B,H,W,C] (+ addend)"""
+def maxpool2_bwd(gy, x, addend=None, relu=False):
+    """gy [B,H/2,W/2,C], x [B,H,W,C] (the pooled tensor) -> gx [B,H,W,C] (+ addend); relu: times [x > 0] (the ReLU that made x)"""
     B, H, W, Cc = x.shape
     gx = torch.empty_like(x)
-    check(lib().dge_maxpool2_bwd(_p(gy), _p(x), _p(addend), _p(gx), B, H, W, Cc, dtype_of(x), _stream()), "dge_maxpool2_bwd")
+    fn = lib().dge_maxpool2_bwd_relu if relu else lib().dge_maxpool2_bwd
+    check(fn(_p(gy), _p(x), _p(addend), _p(gx), B, H, W, Cc, dtype_of(x), _stream()), "dge_maxpool2_bwd")
     return gx
 
 

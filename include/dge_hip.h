@@ -89,6 +89,10 @@ typedef struct dge_conv_desc {
     const float* prep_ns;     /* its noise strength, device scalar, or NULL */
     int prep_noise_batch;     /* 1 = shared plane, else B */
     float* prep_stats;        /* [stats_slots][B,Cout,2], pre-zeroed */
+    /* ReLU backward of the layer BELOW fused into a data-gradient launch (LPIPS VGG16 backward, third-party lpips algorithm at the
+     * call site training_utils.py:93): dot_src = that layer's stored activation a = relu(pre); the stored result is
+     * (acc*out_scale + addend) * [a > 0].  No dot-product statistics in this mode (stats may be NULL). */
+    int mask_relu;            /* 0 / 1 */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
@@ -228,6 +232,18 @@ int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb, const flo
 int dge_torgb_bwd_prep(const float* gimg, const void* x, const float* wrgb, const float* style, const float* noise,
                        const float* noise_strength, int noise_batch, void* gz, float* gs, float* P, int B, int HW, int C,
                        float wscale, float gain, int dtype, dge_stream_t stream);
+/* Every style gradient of a synthesis backward in one launch (stylegan2_generator.py:858-864,908-909 differentiated; replaces
+ * dge_demod_bwd_prep + 2 x dge_linear_t per conv block and one dge_linear_t per toRGB block).  Conv block: P = fused tail sums
+ * [nslot_p][B,out_c,2], st = data-gradient statistics [nslot_s][B,in_c,2], d [B,out_c], s [B,in_c], bias [out_c], wsq [out_c][in_c];
+ * toRGB block: P = NULL, gs [B,in_c].  wstyle [in_c][K] = the block's style DenseBlock weight, row = its row of wp.
+ * g_wp [B,nrows,K] must be pre-zeroed; n <= 32, channels <= 512. */
+typedef struct dge_s2_grad_entry {
+    const float* P; const float* st; const float* d; const float* s; const float* bias; const float* wsq;
+    const float* gs; const float* wstyle;
+    int nslot_p, nslot_s, in_c, out_c, row;
+    float bscale;
+} dge_s2_grad_entry;
+int dge_s2_style_grads(const dge_s2_grad_entry* entries, int n, float* g_wp, int B, int nrows, int K, float wscale, dge_stream_t stream);
 int dge_demod_bwd_prep(const float* P, int nslot, const float* d, const float* bias, float* t, int B, int C, float bscale,
                        dge_stream_t stream);
 /* adjoint of the skip-branch 2x FIR upsample (:603-615): g [BC,2h,2w] -> gprev [BC,h,w] */
@@ -375,6 +391,9 @@ int dge_rgb_tanh_bwd(const float* gimg, const float* img, void* gy, int B, int H
  * (grad_cam.py:208-217, clamp(grad_in, min=0)); a = the ReLU's output */
 int dge_guided_relu_bwd(const void* g, const void* a, void* gpre, long n, int guided, int dtype, dge_stream_t stream);
 /* MaxPool2d(2,2) backward followed by the backward of the ReLU that produced x (guided: grad_cam.py:208-217), one pass */
+/* adjoint of max-pool 2x2 + addend, then the ReLU backward of the layer that produced x: gx = (route(gy) + addend) * [x > 0] */
+int dge_maxpool2_bwd_relu(const void* gy, const void* x, const void* addend, void* gx, int B, int H, int W, int C, int dtype,
+                          dge_stream_t stream);
 int dge_maxpool2_relu_bwd(const void* gy, const void* x, void* gx, int B, int H, int W, int C, int guided, int dtype,
                           dge_stream_t stream);
 /* vgg16.avgpool + torch.flatten: x NHWC [B,H,W,C] -> y [B, C*49] f32 in (c, i, j) order; and its adjoint */
