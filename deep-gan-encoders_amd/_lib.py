@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
         ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float), ("add_scale", C.c_float),
         ("dtype", C.c_int), ("in_up2", C.c_int), ("in_relu", C.c_int), ("stats_slots", C.c_int), ("w_layout", C.c_int),
         ("prep", C.c_int), ("prep_gain", C.c_float), ("prep_noise", C.c_void_p), ("prep_ns", C.c_void_p), ("prep_noise_batch", C.c_int),
-        ("prep_stats", C.c_void_p), ("mask_relu", C.c_int),
+        ("prep_stats", C.c_void_p), ("mask_relu", C.c_int), ("in_t2d", C.c_int),
     ]
 
 
@@ -34,6 +34,7 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes; every symbol declared in include/dge_hip.h must be listed here
 SIGNATURES = {
     "dge_conv2d": [C.POINTER(ConvDesc), _P],
+    "dge_fir_t2d": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dge_s2_style_grads": [C.POINTER(S2GradEntry), _I, _P, _I, _I, _I, _F, _P],
     "dge_conv_small_supported": [_I, _I, _I, _I, _I, _I, _I, _I],
     "dge_torgb_bwd_prep": [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P],

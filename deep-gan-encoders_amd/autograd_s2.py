@@ -109,11 +109,23 @@ def synthesis_run(mod, wp, randomize_noise=False, save=False):
     return results, saved
 
 
+def _up_phase_form(L):
+    """Up layers whose data gradient runs in phase form (FIR^T pass + 4-tap conv on the t grid, dge_fir_t2d / in_t2d: 16 tap-units
+    per input pixel instead of the 36 of the folded space-to-depth form): the MFMA-bound ones, 32^2 .. 128^2 input (measured at
+    batch 8, tools/perf_t2d.py, folded -> FIR pass + conv: 512->512 @32^2 221 -> 174 us, 256<-512 @64^2 310 -> 243, 128<-256 @128^2
+    344 -> 313; at 256^2 / 512^2 the launch is bound by its epilogue and the extra pass loses: 430 -> 504, 951 -> 1223).  The small
+    grids stay on the folded form (low-resolution kernel)."""
+    import os
+    return L.up and 32 <= L.res // 2 <= 128 and L.in_c >= 64 and L.in_c % 32 == 0 and L.out_c % 8 == 0 and not os.environ.get("DGE_NO_T2D")
+
+
 def _dgrad_weight(L, dtype):
-    mode = ops.PACK_UPFOLD_DGRAD if L.up else ops.PACK_DGRAD
     hg = L.res // 2 if L.up else L.res          # grid the data-gradient conv runs on (space-to-depth grid for the up layers)
-    mode = ops.pack_mode_for(L.weight, mode, hg, hg, dtype)
-    key = ("dg", dtype, L.weight._version, L.weight.data_ptr(), getattr(L.weight, "_dge_gen", 0))
+    if _up_phase_form(L):
+        mode = ops.PACK_UPT2D_DGRAD
+    else:
+        mode = ops.pack_mode_for(L.weight, ops.PACK_UPFOLD_DGRAD if L.up else ops.PACK_DGRAD, hg, hg, dtype)
+    key = ("dg", dtype, mode, L.weight._version, L.weight.data_ptr(), getattr(L.weight, "_dge_gen", 0))
     c = L._cache.get("dg")
     if c is None or c[0] != key:
         c = (key, ops.pack_conv_weight(L.weight, mode, dtype, L.wscale))
@@ -181,12 +193,17 @@ def synthesis_backward(mod, wp, saved, g_image):
         prep, P_next = None, None
         # (the space-to-depth data gradient of a narrow up layer - layer 15: 64 -> 32 channels - loses more in its 64-wide tile
         #  than the separate pass costs: measured 890 vs 747 us; tools/perf_prep.py)
-        if fused and i >= 1 and not (L.up and L.in_c < 128):
+        t2d = _up_phase_form(L)
+        if fused and i >= 1 and (t2d or not (L.up and L.in_c < 128)):
             Lp = getattr(mod, f"layer{i - 1}")
             P_next = ops.SlotStats(B, L.in_c, dev)
             prep = dict(gain=Lp.gain, noise=layers[i - 1]["noise"], ns=Lp.noise_strength.detach().reshape(1), stats=P_next)
-        g_xprev = ops.conv2d(g_y, _dgrad_weight(L, dt), L.in_c, 3, in_s2d=L.up, in_scale=d_in, out_scale=rec["s"], addend=addend,
-                             add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
+        if t2d:      # phase form: FIR^T (times the demodulation factor) to the t grid, then the 4-tap conv
+            g_xprev = ops.conv2d(ops.fir_t2d(g_y, d_in), _dgrad_weight(L, dt), L.in_c, 3, in_t2d=True, out_scale=rec["s"], addend=addend,
+                                 add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
+        else:
+            g_xprev = ops.conv2d(g_y, _dgrad_weight(L, dt), L.in_c, 3, in_s2d=L.up, in_scale=d_in, out_scale=rec["s"], addend=addend,
+                                 add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
         # ---- style / demodulation gradients -> g_wp[:, i]
         _, wsq = L._prepared(dt)
         if fused and P is not None:

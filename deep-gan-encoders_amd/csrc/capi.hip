@@ -70,6 +70,9 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.w_frag = d->w_layout == 1 ? 1 : 0;
     p.prep = d->prep ? 1 : 0;
     p.mask_relu = d->mask_relu ? 1 : 0;
+    p.in_t2d = d->in_t2d ? 1 : 0;
+    DGE_CHECK(!d->in_t2d || (d->ksize == 3 && !d->up && !d->in_s2d && !d->in_up2 && !d->in_scale && !d->in_shift && d->w_layout == 0),
+              "conv2d: in_t2d is a plain 3x3 launch (no other read mode, no prologue affine, row-major weights)");
     p.prep_gain = d->prep_gain; p.prep_noise = d->prep_noise; p.prep_ns = d->prep_ns; p.prep_stats = d->prep_stats;
     p.prep_noise_bstride = d->prep_noise_batch > 1 ? OH * OW : 0;
     DGE_CHECK(!d->prep || (d->dot_src && d->prep_stats && d->prep_gain > 0.f && !d->up), "conv2d: prep needs dot_src, prep_stats, a positive prep_gain and no up mode");

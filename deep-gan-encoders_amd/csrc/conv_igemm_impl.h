@@ -116,6 +116,10 @@ struct ConvCfg {
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)) void conv_igemm_kernel(ConvParams p) {
     using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>;
+    // MODE: bits 0-1 = epilogue mode (conv_epilogue.h); bit 2 = in_t2d (phase-form adjoint of the up layer: compile time, because a
+    // run-time choice between two unrolled step sequences in the main loop doubled its code and spilled the accumulators)
+    constexpr bool T2D = (MODE & 4) != 0;
+    constexpr int EMODE = MODE & 3;
     constexpr int EP16 = Elem<T>::PER16;
     __shared__ __attribute__((aligned(256))) unsigned char lds[C::LDS_BYTES];
     unsigned char* ldsA = lds;                         // halo tile of the current K chunk
@@ -178,9 +182,12 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     // Source geometry of the fused read modes, folded into shifts so the per-item address math is
     // branch-free: plain (sl=sh=0), in_up2 (nearest x2: source pixel = (y>>1, x>>1)), in_s2d
     // (space-to-depth: logical channel (phase, c) lives at pixel (2y+py, 2x+px) of the fine grid).
+    // in_t2d (phase-form adjoint of the up layer): the input tensor has one more row and column than the output grid
+    // ([B,H+1,W+1,Cin] from dge_fir_t2d) and only the taps that read pixels m, m+1 per axis are computed (below).
     const int sl = p.in_s2d ? 1 : 0, sh = p.in_up2 ? 1 : 0;
-    const int Ws = (p.W << sl) >> sh;
-    const T* __restrict__ Xb = X + (size_t)b * ((p.H << sl) >> sh) * Ws * cphys;   // in-image offsets fit 32 bits
+    const int Hin = p.H + (T2D ? 1 : 0), Win = p.W + (T2D ? 1 : 0);
+    const int Ws = (Win << sl) >> sh;
+    const T* __restrict__ Xb = X + (size_t)b * ((Hin << sl) >> sh) * Ws * cphys;   // in-image offsets fit 32 bits
 
     // ---- input halo tile: global -> registers (zero outside the image)
     auto load_a = [&](int kc) {
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
             const int pix = idx / C::CH;
             const int hx = pix % C::HW, hy = pix / C::HW;
             const int gy = y0 + hy - C::HALO, gx = x0 + hx - C::HALO;
-            const bool inside = ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W) &
+            const bool inside = ((unsigned)gy < (unsigned)Hin) & ((unsigned)gx < (unsigned)Win) &
                                 (C::NA_ITEMS % 256 == 0 || idx < C::NA_ITEMS);
             const int sy = ((gy << sl) >> sh) + ay, sx = ((gx << sl) >> sh) + ax;
             uint4 v = make_uint4(0, 0, 0, 0);
@@ -329,15 +336,29 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                     for (int j = 0; j < C::NT; j++)
                         bq[j] = *(const uint4*)(bb + t * BN * C::KCB + bbase[j] + (((ks * 2 + (lane >> 5)) ^ bsw[j]) << 4));
                 };
-                frag(0, af[0], bf[0]);
-                StaticFor<NSTEP>::run([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    if (q + 1 < NSTEP) frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+                if constexpr (!T2D) {
+                    frag(0, af[0], bf[0]);
+                    StaticFor<NSTEP>::run([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        if (q + 1 < NSTEP) frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
 #pragma unroll
-                    for (int i = 0; i < C::MT; i++)
+                        for (int i = 0; i < C::MT; i++)
 #pragma unroll
-                        for (int j = 0; j < C::NT; j++) Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
-                });
+                            for (int j = 0; j < C::NT; j++) Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                    });
+                } else if constexpr (row > 0) {
+                    // in_t2d: kernel row 0 and tap 0 of the other rows hold zero weights (DGE_PACK_UPT2D_DGRAD) and are skipped:
+                    // 4 of 9 taps.  (Their weight stages are still requested: the ring's vmcnt accounting counts every stage.)
+                    frag(KSL, af[KSL & 1], bf[KSL & 1]);
+                    StaticFor<NSTEP - KSL>::run([&](auto qc) {
+                        constexpr int q = decltype(qc)::value + KSL;
+                        if (q + 1 < NSTEP) frag(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
+#pragma unroll
+                        for (int i = 0; i < C::MT; i++)
+#pragma unroll
+                            for (int j = 0; j < C::NT; j++) Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                    });
+                }
             }
             // Stage s+1's weights must have landed; DMA groups requested after it may stay in flight.
             // vmcnt retires in order, so allowing (groups still wanted in flight) x DPW outstanding ops is
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     }
     // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
     // LDS is re-used as the transpose buffer from here (all reads done: barrier above); the noise tile at its end stays valid
-    conv_epilogue<T, C, TH, TW, BN, WM, WN, 256, MODE>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
+    conv_epilogue<T, C, TH, TW, BN, WM, WN, 256, EMODE>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
 }
 
 // ------------------------------------------------------------------------- dispatch
@@ -376,14 +397,19 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     p.tiles_y = (p.H + TH - 1) / TH;
     const int ntiles = (p.Ntot + BN - 1) / BN;
     const long grid = (long)p.tiles_x * p.tiles_y * p.B * ntiles;
-    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN, p.prep ? "+prep" : "");
+    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s%s", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN,
+                    p.in_t2d ? "+t2d" : "", p.prep ? "+prep" : "");
     // epilogue mode (conv_epilogue.h): 0 plain, 1 addend / dot_src with prefetch, 2 = 1 + fused tail backward (3x3 only).
     // The f32 parity path has no prefetch, so its mode 1 is its mode 0 with the stages enabled: it always takes >= 1.
     const bool da = p.addend || p.dot_src;
     DGE_CHECK(!p.prep || (KS == 3 && p.dot_src), "conv: prep is offered for 3x3 data-gradient launches only");
 #define DGE_GO(MODE) hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN, MODE>), dim3((unsigned)grid), dim3(256), 0, s, p)
     if constexpr (KS == 3) {
-        if (p.prep) DGE_GO(2);
+        if (p.in_t2d) {         // data-gradient launches: always with addend / dot_src stages
+            if constexpr (TH == 16 && TW == 16 && BN >= 64) { if (p.prep) DGE_GO(6); else DGE_GO(5); }
+            else DGE_CHECK(false, "conv: in_t2d needs N >= 64 and a grid of at least 16 x 16");
+        }
+        else if (p.prep) DGE_GO(2);
         else if (da || sizeof(T) == 4) DGE_GO(1);
         else DGE_GO(0);
     } else {
@@ -415,6 +441,7 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
     const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
     bool small = (p.H <= 8 && p.W <= 8) || work < 256L * 256;
     { const char* e = getenv("DGE_CONV_SMALL"); if (e) small = atoi(e) != 0; }
+    if (p.in_t2d) small = false;        // (offered on the 16 x 16 tile configurations only)
 #define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
     if (small) {           // 8x8 pixel tiles, narrower N tiles: more workgroups for the low-resolution layers
         if (bn >= 64) {

@@ -42,6 +42,7 @@ struct ConvParams {
     int prep_noise_bstride;   // 0 (shared plane) or OH*OW
     float* prep_stats;        // [slots][B,Cout,2], pre-zeroed (same slot count as `stats`)
     int mask_relu;            // 1: result *= [dot_src > 0] (ReLU backward of the layer below), no dot statistics
+    int in_t2d;               // 1: x is [B,H+1,W+1,Cin] (dge_fir_t2d); only the taps (dy,dx) in {1,2}^2 are computed
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);

@@ -693,7 +693,7 @@ int launch_flavour(const ConvParams& p, hipStream_t s) {
 
 // Eligibility of the streaming kernel for a launch (bf16, 3x3, stride 1, no fused resampling / addend / ReLU prologue).
 bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
-    if (dtype != DGE_BF16 || ksize != 3 || p.up || p.in_s2d || p.in_up2 || p.in_relu || p.addend || p.mask_relu) return false;
+    if (dtype != DGE_BF16 || ksize != 3 || p.up || p.in_s2d || p.in_up2 || p.in_relu || p.addend || p.mask_relu || p.in_t2d) return false;
     if (!(p.Cin == 16 || p.Cin == 32 || p.Cin == 64) || !(p.Cout == 16 || p.Cout == 32 || p.Cout == 64)) return false;
     if (p.W % 4 != 0 || p.W < 64 || p.H < 32) return false;
     if ((long)p.H * p.W < 128L * 128) return false;

@@ -233,6 +233,85 @@ extern "C" int dge_demod_bwd(const float* R, const float* d, const float* bias, 
     return 0;
 }
 
+// ------------------------------------------------------------------ FIR^T of the up layer, stored t-grid-to-depth
+// Up layer (stylegan2_generator.py:879-896): t = conv_transpose2d(x, stride 2) on the (2H+1)^2 grid, y[v] = sum_j k1[j] t[v + j - 1]
+// per axis (k1 = [1,3,3,1]/4, pad 1, :603-615).  Adjoint of the filter: g_t[u] = sum_j k1[j] g_y[u - j + 1] (g_y zero outside
+// [0, 2H)).  The data-gradient conv wants the four phases of g_t around coarse pixel m side by side (dge_conv_desc.in_t2d):
+//   Z[b, m, (py,px)*C + c] = scale[b,c] * g_t[b, 2m + p, c],   m in [0,H] x [0,W],   zero where 2m + p > 2H (2W).
+// One thread = one 16-byte channel chunk of one m: the 5 x 5 window of g_y it needs is filtered separably (rows first).
+template <typename T>
+__global__ __launch_bounds__(256) void fir_t2d_kernel(const T* __restrict__ g, const float* __restrict__ scale, T* __restrict__ z,
+                                                       int H, int W, int C, long total) {
+    constexpr int EP = Elem<T>::PER16;
+    const int cpt = C / EP;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = idx % cpt; long r = idx / cpt;
+    const int mx = r % (W + 1); r /= (W + 1);
+    const int my = r % (H + 1); const int b = r / (H + 1);
+    const int FH = 2 * H, FW = 2 * W;
+    const T* gb = g + (size_t)b * FH * FW * C + ch * EP;
+    const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    // horizontal pass: for each of the 5 rows v = 2my-2 .. 2my+2, h[px][row] = sum_j k1[j] g[v][2mx + px + 1 - j]
+    float h0[5][EP], h1[5][EP];
+#pragma unroll
+    for (int rr = 0; rr < 5; rr++) {
+        const int v = 2 * my - 2 + rr;
+        float f[5][EP];
+#pragma unroll
+        for (int cc = 0; cc < 5; cc++) {
+            const int u = 2 * mx - 2 + cc;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if ((unsigned)v < (unsigned)FH && (unsigned)u < (unsigned)FW) val = *(const uint4*)(gb + ((size_t)v * FW + u) * C);
+            unpack16(val, f[cc], (T*)nullptr);
+        }
+        // px = 0: columns 2mx+1, 2mx, 2mx-1, 2mx-2 = f[3], f[2], f[1], f[0];   px = 1: 2mx+2 .. 2mx-1 = f[4], f[3], f[2], f[1]
+#pragma unroll
+        for (int e = 0; e < EP; e++) {
+            h0[rr][e] = k1[0] * f[3][e] + k1[1] * f[2][e] + k1[2] * f[1][e] + k1[3] * f[0][e];
+            h1[rr][e] = k1[0] * f[4][e] + k1[1] * f[3][e] + k1[2] * f[2][e] + k1[3] * f[1][e];
+        }
+    }
+    float sc[EP];
+#pragma unroll
+    for (int e = 0; e < EP; e++) sc[e] = scale ? scale[(size_t)b * C + ch * EP + e] : 1.f;
+    T* zb = z + (((size_t)b * (H + 1) + my) * (W + 1) + mx) * 4 * C + ch * EP;
+    const bool vy1 = 2 * my + 1 <= 2 * H, vx1 = 2 * mx + 1 <= 2 * W;     // (phase 0 always lies on the grid)
+#pragma unroll
+    for (int py = 0; py < 2; py++) {
+        // rows 2my+py+1-j, j = 0..3  = window rows (py + 3 - j)
+        float o0[EP], o1[EP];
+#pragma unroll
+        for (int e = 0; e < EP; e++) {
+            o0[e] = sc[e] * (k1[0] * h0[py + 3][e] + k1[1] * h0[py + 2][e] + k1[2] * h0[py + 1][e] + k1[3] * h0[py][e]);
+            o1[e] = sc[e] * (k1[0] * h1[py + 3][e] + k1[1] * h1[py + 2][e] + k1[2] * h1[py + 1][e] + k1[3] * h1[py][e]);
+        }
+        const bool vy = py == 0 || vy1;
+        if (!vy) {
+#pragma unroll
+            for (int e = 0; e < EP; e++) { o0[e] = 0.f; o1[e] = 0.f; }
+        }
+        if (!vx1) {
+#pragma unroll
+            for (int e = 0; e < EP; e++) o1[e] = 0.f;
+        }
+        *(uint4*)(zb + (size_t)(py * 2 + 0) * C) = pack16(o0, (T*)nullptr);
+        *(uint4*)(zb + (size_t)(py * 2 + 1) * C) = pack16(o1, (T*)nullptr);
+    }
+}
+
+extern "C" int dge_fir_t2d(const void* g, const float* scale, void* z, int B, int H, int W, int C, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(g && z && B > 0 && H > 0 && W > 0 && C > 0 && C % ep == 0, "fir_t2d: bad arguments");
+    const long total = (long)B * (H + 1) * (W + 1) * (C / ep);
+    DGE_CHECK((total + 255) / 256 < (1L << 31), "fir_t2d: grid too large");
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(fir_t2d_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)g, scale, (bf16_t*)z, H, W, C, total);
+    else hipLaunchKernelGGL(fir_t2d_kernel<float>, grid, dim3(256), 0, s, (const float*)g, scale, (float*)z, H, W, C, total);
+    DGE_LAUNCH_CHECK("fir_t2d");
+    return 0;
+}
+
 // ------------------------------------------------------------------ every style gradient of a synthesis backward in one launch
 // Per modulated block the backward ends in three small steps (stylegan2_generator.py:858-864,908-909 differentiated):
 //   t[b,o]   = -(P0 - bias[o]*bscale*P1) * d[b,o]^2                      (demodulation gradient from the fused tail sums)

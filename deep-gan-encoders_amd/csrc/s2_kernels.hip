@@ -51,6 +51,19 @@ __device__ __forceinline__ float upfold_weight(const float* __restrict__ w, int 
     return v;
 }
 
+// DGE_PACK_UPT2D_DGRAD (mode 6): adjoint of the up layer in PHASE form.  The data gradient runs on Z = FIR^T(g) stored
+// t-grid-to-depth (dge_fir_t2d: Z[m][(py,px), o] = g_t[2m + p][o]): g_x[m][i] = sum_{a in {0,1}^2} sum_p sum_o
+// Z[m + a][p, o] * w[o][i][2 - (2a + p)] for 2a + p <= 2 per axis (transposed conv t[2m + k] += x[m] w[2 - k], :879-895).
+// In the 3x3 tap frame of dge_conv2d tap (dy,dx) reads input pixel m + (dy-1, dx-1): a = (dy-1, dx-1); taps with dy = 0 or
+// dx = 0 are zero (and skipped by the kernel, dge_conv_desc.in_t2d).
+__device__ __forceinline__ float upt2d_weight(const float* __restrict__ w, int o, int i, int Cin, int ph, int tap) {
+    const int dy = tap / 3, dx = tap % 3;
+    if (dy == 0 || dx == 0) return 0.f;
+    const int ky = 2 * (dy - 1) + (ph >> 1), kx = 2 * (dx - 1) + (ph & 1);
+    if (ky > 2 || kx > 2) return 0.f;
+    return w[((size_t)o * Cin + i) * 9 + (2 - ky) * 3 + (2 - kx)];
+}
+
 // DGE_PACK_FRAG (mode bit 0x100): the same [tap][n][k] values stored in MFMA-fragment order for csrc/conv_small.hip, which loads
 // its weight operand straight from global memory: the 32 rows x 16 k block (tap, n/32, k/16) is one contiguous 1 KiB run in
 // lane order - lane = (n % 32) + 32 * ((k % 16) / 8) holds the 8 consecutive k of its v_mfma_f32_32x32x16_bf16 B operand - so a
@@ -67,7 +80,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     const int frag = mode & 0x100;
     mode &= 0xff;
     const int ntap = KS * KS;
-    const int Kdim = (mode == 2) ? Cout : ((mode == 3 || mode == 5) ? 4 * Cout : Cin);
+    const int Kdim = (mode == 2) ? Cout : ((mode == 3 || mode == 5 || mode == 6) ? 4 * Cout : Cin);
     const int total = ntap * Ntot * Kdim;            // < 2^31 (checked by the launcher): 32-bit index math
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int k = idx % Kdim;
@@ -84,6 +97,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
             if (n < 4 * Cout) v = sg1_up_weight(w, k, n % Cout, Cout, n / Cout, tap);
         } else if (mode == 5) {
             if (n < Cin) v = sg1_up_weight(w, n, k % Cout, Cout, k / Cout, 8 - tap);
+        } else if (mode == 6) {
+            if (n < Cin) v = upt2d_weight(w, k % Cout, n, Cin, k / Cout, tap);
         } else {
             if (n < Cin) v = upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap);
         }
@@ -106,6 +121,7 @@ __device__ __forceinline__ float pack_gather(const float* __restrict__ w, int mo
     if (mode == 1) return n < 4 * Cout ? upfold_weight(w, n % Cout, k, Cin, n / Cout, tap) : 0.f;
     if (mode == 4) return n < 4 * Cout ? sg1_up_weight(w, k, n % Cout, Cout, n / Cout, tap) : 0.f;
     if (mode == 5) return n < Cin ? sg1_up_weight(w, n, k % Cout, Cout, k / Cout, 8 - tap) : 0.f;
+    if (mode == 6) return n < Cin ? upt2d_weight(w, k % Cout, n, Cin, k / Cout, tap) : 0.f;
     return n < Cin ? upfold_weight(w, k % Cout, n, Cin, k / Cout, 8 - tap) : 0.f;
 }
 __global__ void pack_multi_kernel(const DgePackDesc* __restrict__ descs, int nd, long long total_pairs) {
@@ -388,11 +404,11 @@ extern "C" int dge_pack_conv_weight(const float* w_oihw, void* out, int cout, in
     const int frag = mode & 0x100;
     const int mode_full = mode;
     mode &= 0xff;
-    DGE_CHECK(mode >= 0 && mode <= 5 && (mode_full & ~0x1ff) == 0, "pack: bad mode %d", mode_full);
+    DGE_CHECK(mode >= 0 && mode <= 6 && (mode_full & ~0x1ff) == 0, "pack: bad mode %d", mode_full);
     DGE_CHECK((mode != 1 && mode < 3) || ksize == 3, "pack: up fold needs a 3x3 kernel");
     const int nvalid = (mode == 1 || mode == 4) ? 4 * cout : (mode >= 2 ? cin : cout);
     const int ntot = dge_packed_n(nvalid);
-    const int kdim = mode == 2 ? cout : ((mode == 3 || mode == 5) ? 4 * cout : cin);
+    const int kdim = mode == 2 ? cout : ((mode == 3 || mode == 5 || mode == 6) ? 4 * cout : cin);
     DGE_CHECK(!frag || (dtype == DGE_BF16 && ntot % 32 == 0 && kdim % 16 == 0), "pack: fragment order needs bf16, N %% 32 == 0, K %% 16 == 0");
     mode = mode_full;
     const long total = (long)ksize * ksize * ntot * kdim;
@@ -423,11 +439,11 @@ extern "C" int dge_pack_conv_weights_multi(const long long* table_host, void* de
         d.dtype = (int)r[4];
         const unsigned bits = (unsigned)r[5]; memcpy(&d.scale, &bits, 4);
         const int bm = d.mode & 0xff;
-        DGE_CHECK(bm >= 0 && bm <= 5 && (d.mode & ~0x1ff) == 0, "pack_multi: bad mode %d", d.mode);
+        DGE_CHECK(bm >= 0 && bm <= 6 && (d.mode & ~0x1ff) == 0, "pack_multi: bad mode %d", d.mode);
         DGE_CHECK((bm != 1 && bm < 3) || d.ks == 3, "pack_multi: up fold needs a 3x3 kernel");
         const int nvalid = (bm == 1 || bm == 4) ? 4 * d.cout : (bm >= 2 ? d.cin : d.cout);
         d.ntot = dge_packed_n(nvalid);
-        d.kdim = bm == 2 ? d.cout : ((bm == 3 || bm == 5) ? 4 * d.cout : d.cin);
+        d.kdim = bm == 2 ? d.cout : ((bm == 3 || bm == 5 || bm == 6) ? 4 * d.cout : d.cin);
         DGE_CHECK(!(d.mode & 0x100) || (d.dtype == DGE_BF16 && d.ntot % 32 == 0 && d.kdim % 16 == 0),
                   "pack_multi: fragment order needs bf16, N %% 32 == 0, K %% 16 == 0");
         d.pair_start = pairs;

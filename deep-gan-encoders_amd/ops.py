@@ -9,7 +9,7 @@ from ._lib import lib, check, ConvDesc, DgeError
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
-PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP, PACK_SG1_UP_DGRAD = 0, 1, 2, 3, 4, 5
+PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP, PACK_SG1_UP_DGRAD, PACK_UPT2D_DGRAD = 0, 1, 2, 3, 4, 5, 6
 PACK_FRAG = 0x100     # OR-ed into a pack mode: MFMA-fragment order for the low-resolution kernel (csrc/conv_small.hip)
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag, algorithmic_bytes) per conv launch
 
@@ -196,8 +196,8 @@ def pack_dims(w, mode):
     mode &= 0xff
     if mode in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):
         cin, cout = cout, cin
-    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cout)
-    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cin)
+    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD, PACK_UPT2D_DGRAD) else cout)
+    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD, PACK_UPT2D_DGRAD) else cin)
     return nvalid, kdim
 
 
@@ -216,8 +216,8 @@ def pack_conv_weight(w, mode=PACK_FWD, dtype=BF16, scale=1.0):
     cout, cin, k, _ = w.shape
     if mode in (PACK_SG1_UP, PACK_SG1_UP_DGRAD):          # ConvTranspose2d parameter layout [Cin, Cout, k, k]
         cin, cout = cout, cin
-    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cout)
-    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD) else cin)
+    nvalid = 4 * cout if mode in (PACK_UPFOLD, PACK_SG1_UP) else (cin if mode in (PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD, PACK_UPT2D_DGRAD) else cout)
+    kdim = cout if mode == PACK_DGRAD else (4 * cout if mode in (PACK_UPFOLD_DGRAD, PACK_SG1_UP_DGRAD, PACK_UPT2D_DGRAD) else cin)
     out = torch.empty((k * k, packed_n(nvalid), kdim), dtype=tdtype(dtype), device=w.device)
     check(lib().dge_pack_conv_weight(_f32(w.detach().contiguous()), _p(out), cout, cin, k, mode_full, dtype, float(scale),
                                      _stream()), "dge_pack_conv_weight")
@@ -306,7 +306,7 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None):
+           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None, in_t2d=False):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout].
     `prep`: dict(gain, noise [1|B,OH,OW] or None, ns (device scalar) or None, stats=SlotStats(B, cout)) - the fused tail backward of
     the layer that produced `dot_src` (dge_conv_desc.prep): y is then g_z and prep['stats'] receives (sum g_z*(z - ns*noise), sum g_z).
@@ -316,6 +316,8 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         H, W, Cin = H // 2, W // 2, Cin * 4
     if in_up2:            # x is the coarse grid; the conv runs on its nearest x2 upsample
         H, W = 2 * H, 2 * W
+    if in_t2d:            # x is fir_t2d output [B,H+1,W+1,4C]; the conv runs on the H x W grid (phase-form adjoint of the up layer)
+        H, W = H - 1, W - 1
     dt = dtype_of(x)
     OH, OW = (2 * H, 2 * W) if up else (H, W)
     if out is None:
@@ -326,6 +328,7 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
             raise DgeError("conv2d: relu_mask excludes dot_src / prep")
         dot_src = relu_mask
     d.mask_relu = 0 if relu_mask is None else 1
+    d.in_t2d = 1 if in_t2d else 0
     d.x, d.w_packed, d.y, d.addend, d.dot_src = _p(x), _p(w_packed), _p(out), _p(addend), _p(dot_src)
     d.in_scale, d.in_shift, d.out_scale = _f32(in_scale), _f32(in_shift), _f32(out_scale)
     # statistics atomics of large grids are spread over several copies (same-address contention), then combined
@@ -366,7 +369,7 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         # (9*Cin*Cout MACs per INPUT pixel), everything else k*k*Cin*Cout per output pixel
         if up:
             macs = 9.0 * Cin * cout * H * W
-        elif in_s2d:
+        elif in_s2d or in_t2d:
             macs = 9.0 * (Cin // 4) * cout * H * W
         else:
             macs = float(ksize * ksize) * Cin * cout * H * W
@@ -489,6 +492,15 @@ def linear_t(x, w, y, mul=None, scale=1.0, accumulate=False, incx=1, incy=1, ldx
     check(lib().dge_linear_t(C.c_void_p(x.data_ptr()), ldx, incx, _f32(w), _f32(mul), C.c_void_p(y.data_ptr()), ldy, incy,
                              B, O, K, float(scale), 1 if accumulate else 0, _stream()), "dge_linear_t")
     return y
+
+
+def fir_t2d(g, scale=None):
+    """g [B,2H,2W,C] -> Z [B,H+1,W+1,4C] = scale * FIR^T(g) stored t-grid-to-depth (dge_fir_t2d): the input of conv2d(in_t2d=True)"""
+    B, FH, FW, Cc = g.shape
+    H, W = FH // 2, FW // 2
+    z = torch.empty((B, H + 1, W + 1, 4 * Cc), dtype=g.dtype, device=g.device)
+    check(lib().dge_fir_t2d(_p(g), _f32(scale), _p(z), B, H, W, Cc, dtype_of(g), _stream()), "dge_fir_t2d")
+    return z
 
 
 def s2_style_grads(blocks, g_wp, wscale):

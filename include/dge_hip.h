@@ -38,6 +38,7 @@ typedef struct ihipStream_t* dge_stream_t;   /* == hipStream_t */
 #define DGE_PACK_UPFOLD_DGRAD 3 /* [tap][Cin][4*Cout]: adjoint of DGE_PACK_UPFOLD  */
 #define DGE_PACK_SG1_UP 4    /* w is [Cin][Cout][3][3] (ConvTranspose2d 3,s2,p1 + transform_kernel, lreq.py:129-131) -> [tap][4*Cout][Cin] */
 #define DGE_PACK_SG1_UP_DGRAD 5 /* same parameter layout -> [tap][Cin][4*Cout]: adjoint of DGE_PACK_SG1_UP */
+#define DGE_PACK_UPT2D_DGRAD 6 /* [tap][Cin][4*Cout]: adjoint of the up layer in phase form, read from dge_fir_t2d output (dge_conv_desc.in_t2d) */
 
 const char* dge_last_error(void);
 int dge_version(void);
@@ -93,6 +94,10 @@ typedef struct dge_conv_desc {
      * call site training_utils.py:93): dot_src = that layer's stored activation a = relu(pre); the stored result is
      * (acc*out_scale + addend) * [a > 0].  No dot-product statistics in this mode (stats may be NULL). */
     int mask_relu;            /* 0 / 1 */
+    /* Phase-form adjoint of the up layer (stylegan2_generator.py:879-896 differentiated): x is the output of dge_fir_t2d,
+     * [B,H+1,W+1,Cin] with Cin = 4*Cout_up, weights DGE_PACK_UPT2D_DGRAD; the launch computes y[m] = sum over the taps
+     * (dy,dx) in {1,2}^2 of x[m + (dy-1,dx-1)] * W[tap] (4 of 9 taps: 16 tap-units per pixel against the 36 of in_s2d). */
+    int in_t2d;               /* 0 / 1 */
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
@@ -232,6 +237,10 @@ int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb, const flo
 int dge_torgb_bwd_prep(const float* gimg, const void* x, const float* wrgb, const float* style, const float* noise,
                        const float* noise_strength, int noise_batch, void* gz, float* gs, float* P, int B, int HW, int C,
                        float wscale, float gain, int dtype, dge_stream_t stream);
+/* First half of the phase-form adjoint of the up layer: Z[b,m,(py,px),c] = scale[b,c] * (FIR^T g)[b, 2m + p, c] on the
+ * (2H+1)^2 grid of the transposed conv (FIR = outer([1,3,3,1]/4), pad 1, :603-615; entries beyond the grid are zero).
+ * g [B,2H,2W,C] -> z [B,H+1,W+1,4C]; scale optional [B,C] (the demodulation factor that multiplies the gradient). */
+int dge_fir_t2d(const void* g, const float* scale, void* z, int B, int H, int W, int C, int dtype, dge_stream_t stream);
 /* Every style gradient of a synthesis backward in one launch (stylegan2_generator.py:858-864,908-909 differentiated; replaces
  * dge_demod_bwd_prep + 2 x dge_linear_t per conv block and one dge_linear_t per toRGB block).  Conv block: P = fused tail sums
  * [nslot_p][B,out_c,2], st = data-gradient statistics [nslot_s][B,in_c,2], d [B,out_c], s [B,in_c], bias [out_c], wsq [out_c][in_c];

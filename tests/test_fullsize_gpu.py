@@ -291,6 +291,10 @@ def test_data_gradient_fullsize(cof, cif, R, B, k, oscale, kernel):
 UP_DGRADS = [
     (64, 32, 512, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>"),        # layer15: gradient [B,1024,1024,32] -> [B,512,512,64]
     (128, 64, 256, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),      # layer13
+    # phase form (dge_fir_t2d + in_t2d: FIR^T to the t grid, then 4 of 9 taps) - what the synthesis backward runs from 32^2 up
+    (64, 32, 512, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>+t2d"),    # layer15
+    (128, 64, 256, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>+t2d"),  # layer13
+    (512, 512, 32, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>+t2d"),   # layer7 (64-wide tiles: the 128-wide grid would not fill the chip)
 ]
 
 
@@ -307,8 +311,14 @@ def test_up_layer_data_gradient_fullsize(cin, cout, Rin, B, kernel):
     wscale = 1.0 / math.sqrt(9 * cin)
     s = 1.0 + 0.3 * torch.randn(B, cin, device=DEV, generator=g)
     st = ops.zeros((B, cin, 2), DEV)
-    gx = ops.conv2d(gy, ops.pack_conv_weight(w, ops.PACK_UPFOLD_DGRAD, ops.BF16, wscale), cin, 3, in_s2d=True, out_scale=s,
-                    addend=add, add_scale=1.0, stats=st, dot_src=xin)
+    if kernel.endswith("+t2d"):
+        z = ops.fir_t2d(gy)
+        assert z.shape == (B, Rin + 1, Rin + 1, 4 * cout)
+        gx = ops.conv2d(z, ops.pack_conv_weight(w, ops.PACK_UPT2D_DGRAD, ops.BF16, wscale), cin, 3, in_t2d=True, out_scale=s,
+                        addend=add, add_scale=1.0, stats=st, dot_src=xin)
+    else:
+        gx = ops.conv2d(gy, ops.pack_conv_weight(w, ops.PACK_UPFOLD_DGRAD, ops.BF16, wscale), cin, 3, in_s2d=True, out_scale=s,
+                        addend=add, add_scale=1.0, stats=st, dot_src=xin)
     assert _kernel() == kernel
     tot = st.cpu()
     for b in SAMPLES(B):
@@ -323,7 +333,10 @@ def test_up_layer_data_gradient_fullsize(cin, cout, Rin, B, kernel):
         e0 = _stat_close(tot[b, :, 0], (rawd * xb).sum((2, 3))[0], (rawd * xb).abs().sum((2, 3))[0])
         e1 = _stat_close(tot[b, :, 1], rawd.sum((2, 3))[0], rawd.abs().sum((2, 3))[0])
         print(f"   dot stats: {e0:.2e} {e1:.2e}")
-        assert e0 < 9e-5 and e1 < 9e-5, (b, e0, e1)      # measured 1.0e-5 .. 4.4e-5 (folded adjoint weights are bf16)
+        # measured 1.0e-5 .. 4.4e-5 (folded adjoint weights are bf16).  Phase form at 32^2: the operand g_t is rounded to bf16 and a
+        # sum has only 1024 pixels to average the roundings over: measured 4.1e-4
+        tol = 8e-4 if (kernel.endswith("+t2d") and Rin <= 64) else 9e-5
+        assert e0 < tol and e1 < tol, (b, e0, e1)
 
 
 WGRADS = [
@@ -500,6 +513,8 @@ PREP_CASES = [
     (512, 512, 16, 8, False, False, "conv_small<bf16,8,8,64,512>+prep"),            # layer4 -> layer3
     (32, 64, 512, 8, True, True, "conv_igemm<bf16,16,16,64,32,3,4,1>+prep"),        # layer15 (up): space-to-depth read, toRGB addend -> layer14
     (512, 512, 4, 8, True, True, "conv_igemm<bf16,8,8,64,128,3,2,2>+prep"),         # layer1 (up) -> layer0
+    (32, 64, 512, 8, True, True, "conv_igemm<bf16,16,16,64,32,3,4,1>+t2d+prep"),    # layer15 (up) in phase form
+    (256, 512, 64, 8, True, True, "conv_igemm<bf16,16,16,128,32,3,2,2>+t2d+prep"),  # layer9 (up) in phase form
 ]
 
 
@@ -528,8 +543,12 @@ def test_data_gradient_with_fused_tail_backward_fullsize(cof, cif, R, B, up, wit
     P = ops.SlotStats(B, cif, DEV)
     mode = ops.PACK_UPFOLD_DGRAD if up else ops.PACK_DGRAD
     hg = R
-    out = ops.conv2d(gz_in, _pack(w, mode, hg, hg, wscale), cif, 3, in_s2d=up, in_scale=d_in, out_scale=s, addend=add, add_scale=1.0,
-                     stats=st, dot_src=xin, prep=dict(gain=gain, noise=noise, ns=ns, stats=P))
+    if "+t2d" in kernel:
+        out = ops.conv2d(ops.fir_t2d(gz_in, d_in), ops.pack_conv_weight(w, ops.PACK_UPT2D_DGRAD, ops.BF16, wscale), cif, 3, in_t2d=True,
+                         out_scale=s, addend=add, add_scale=1.0, stats=st, dot_src=xin, prep=dict(gain=gain, noise=noise, ns=ns, stats=P))
+    else:
+        out = ops.conv2d(gz_in, _pack(w, mode, hg, hg, wscale), cif, 3, in_s2d=up, in_scale=d_in, out_scale=s, addend=add, add_scale=1.0,
+                         stats=st, dot_src=xin, prep=dict(gain=gain, noise=noise, ns=ns, stats=P))
     assert _kernel() == kernel
     Pt = P.buf.sum(0).cpu()
     stc = st.cpu()
