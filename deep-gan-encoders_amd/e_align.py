@@ -219,6 +219,12 @@ class EAlignStep:
         if len(names) != len(lay["early"]):
             return                                          # a different set than the layout was built for: leave it to _sync_grads
         torch._foreach_copy_([lay["views"][n] for n in names], [grads[n] for n in names])
+        # Stream order: the copies above are queued on the CURRENT (compute) stream; ProcessGroupNCCL enqueues every collective on
+        # its own stream behind an event it records on the current stream at call time (ProcessGroupNCCL::collective ->
+        # syncStream), so the all-reduce reads the bucket after the copies without an explicit wait_stream here.  The rest of
+        # the backward never touches [0, n_early) of the bucket (disjoint views), the bucket itself is owned by `self` (no
+        # allocator reuse while the collective runs), and `_sync_grads` joins with work.wait(), which makes the compute stream wait
+        # for RCCL's before the optimizer reads the sums.
         self._early_work = _all_reduce(self._flat[:lay["n_early"]], async_op=True)
 
     def _sync_grads(self):

@@ -1,7 +1,7 @@
 """Dev tool: the RCCL gradient-exchange path (early async bucket + remainder) on ONE GPU with a 1-rank group, against the
 non-distributed step and against the run-to-run spread of the non-distributed step (atomics + sign-like first Adam steps)."""
 import os, sys, torch, torch.distributed as dist
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", DGE_FORCE_DIST="1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
