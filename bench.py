@@ -41,8 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-2 and eval-mode-G entries")
-    ap.add_argument("--extra-graph", action="store_true", help="also replay the batch-2 step from a hipGraph inside this process (capturing after eager "
-                    "steps of the same models crashed the runtime once: opt-in; `--graph --batch 2` is the robust way)")
+    ap.add_argument("--no-extra-graph", action="store_true", help="skip the hipGraph replay of the batch-2 step (extras.batch2_graph).  (Round 2 made it "
+                    "opt-in after a crash; root cause fixed in round 3 - EAlignStep.capture: results that kept their autograd graph alive)")
+    ap.add_argument("--extra-graph", action="store_true", help="(accepted for compatibility: the replay is measured by default)")
     ap.add_argument("--no-synthesis", action="store_true", help="skip the synthesis-only timing (used by tools/pmc_traffic.sh so that "
                     "the profiled conv launches are exactly those of the training steps)")
     ap.add_argument("--cpu-size", type=int, default=1024, help="image size of the bounded CPU-oracle sample")
@@ -213,8 +214,8 @@ def main():
                                 "note": "reference default batch (E_align_s2.py:308), eager"}
             # the same batch replayed from a captured hipGraph: at this batch the eager step is bound by the host's launch rate
             try:
-                if not a.extra_graph:
-                    raise RuntimeError("skipped (opt-in: --extra-graph; `python bench.py --graph --batch 2` measures the same in its own process)")
+                if a.no_extra_graph:
+                    raise RuntimeError("skipped (--no-extra-graph)")
                 st2.capture()
                 for i in range(2):
                     st2.replay()

@@ -262,6 +262,16 @@ class EAlignStep:
         device generator.  `warmup` + 1 real iterations run inside this call."""
         if self.dist_on:
             raise RuntimeError("hipGraph capture is offered for single-process runs only (collectives are not captured)")
+        # Capturing after EAGER steps of the same encoder used to end in a segmentation fault inside capture_end (round 2:
+        # "crashed the runtime once"; reproduced with faulthandler in round 3).  Cause: the eager step's results (imgs2, w2) kept
+        # their autograd graph alive, and with it the AccumulateGrad nodes of E's parameters, created on the default stream.
+        # The captured iteration runs on a side stream; autograd re-uses the live nodes and inserts its cross-stream event
+        # record / wait between the default stream and the capturing one - an illegal dependency for a capture.  step() now
+        # returns detached results; dead graphs of earlier iterations are collected here before the warm-up, so that the
+        # warm-up iterations create fresh accumulator nodes on the capture's side stream.
+        import gc
+        self.last = {}
+        gc.collect()
         if isinstance(self.gen, _BigGANAdapter):
             raise RuntimeError("hipGraph capture is not offered for --mtype 4: z is a scipy truncnorm draw and the class id a host "
                                "decision of every iteration (E_align_s2.py:139-150); run the eager step")
@@ -371,7 +381,10 @@ class EAlignStep:
         gs = self._sync_grads()
         self.opt.step(grad_scale=gs)
         ops.zero_arena_end()
-        self.last = dict(imgs1=imgs1, imgs2=imgs2, w1=w1, w2=w2, const2=const2, loss_tsa=loss_tsa.detach(),
+        # (detached: a result that kept its grad_fn would keep this iteration's autograd graph alive - and with it the
+        #  AccumulateGrad nodes of E's parameters, bound to the stream they were created on; see capture())
+        det = lambda t: t.detach() if torch.is_tensor(t) else t
+        self.last = dict(imgs1=imgs1, imgs2=det(imgs2), w1=det(w1), w2=det(w2), const2=det(const2), loss_tsa=loss_tsa.detach(),
                          info_img=info_img, loss_w=loss_w.detach(), info_w=info_w)
         return self.last
 
