@@ -30,6 +30,10 @@ class S2GradEntry(C.Structure):
                 ("nslot_p", C.c_int), ("nslot_s", C.c_int), ("in_c", C.c_int), ("out_c", C.c_int), ("row", C.c_int), ("bscale", C.c_float)]
 
 
+class SumPlanarEntry(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("nslot", C.c_int), ("C", C.c_int), ("NS", C.c_int), ("pad", C.c_int)]
+
+
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes; every symbol declared in include/dge_hip.h must be listed here
 SIGNATURES = {
@@ -127,6 +131,9 @@ SIGNATURES = {
     "dge_mask2cam": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P],
     "dge_randn": [_P, _I, _P, _P, _P, _P, C.c_ulonglong, _P, _P],
     "dge_version": [],
+    "dge_env_reload": [],
+    "dge_sum_slots_planar_multi": [C.POINTER(SumPlanarEntry), _I, _P],
+    "dge_heads_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],
 }
 
 _lib = None

@@ -59,12 +59,12 @@ def heads_layout(E, B, dev):
     for j, blk in enumerate(E.decode_block):
         lins.append((blk.inver_mod1, 2 * (L - 1 - j) + 1))
         lins.append((blk.inver_mod2, 2 * (L - 1 - j)))
-    key = (B, str(dev), tuple(l.weight.data_ptr() for l, _ in lins))
+    key = (B, str(dev), tuple((l.weight.data_ptr(), l.bias.data_ptr()) for l, _ in lins))
     lay = E.__dict__.get("_heads_layout")
     if lay is not None and lay["key"] == key:
         return lay
     O = lins[0][0].weight.shape[0]
-    rec = np.dtype([("W", "u8"), ("moff", "i8"), ("woff", "i8"), ("I", "i4"), ("gcol", "i4"), ("boff", "i4"), ("pad", "i4")])
+    rec = np.dtype([("W", "u8"), ("moff", "i8"), ("woff", "i8"), ("I", "i4"), ("gcol", "i4"), ("boff", "i4"), ("pad", "i4"), ("bias", "u8")])
     assert rec.itemsize == ops.lib().dge_head_entry_size()
     tab = np.zeros(len(lins), dtype=rec)
     moff = woff = 0
@@ -72,7 +72,7 @@ def heads_layout(E, B, dev):
     for i, (lin, col) in enumerate(lins):
         I = lin.weight.shape[1]
         assert lin.weight.shape[0] == O and lin.weight.is_contiguous()
-        tab[i] = (lin.weight.data_ptr(), moff, woff, I, col * O, i * O, 0)
+        tab[i] = (lin.weight.data_ptr(), moff, woff, I, col * O, i * O, 0, lin.bias.data_ptr())
         items.append((moff, woff, i * O, I))
         moff += B * I
         woff += O * I
@@ -110,14 +110,12 @@ def encoder_forward(E, img, noises=None, save=False):
         H = R >> j
         last = not blk.has_last_conv
         musig1, sc1, sh1 = ops.stats_finalize(stats, H * H, musig_out=ms_slot(2 * j))
-        w1 = ops.linear(musig1, blk.inver_mod1.weight.detach(), blk.inver_mod1.bias.detach())
         n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
         st1 = zeros(Cc)
         x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD, H), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
                         noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
                         act=ops.ACT_LRELU, stats=st1)
         musig2, sc2, sh2 = ops.stats_finalize(st1, H * H, musig_out=ms_slot(2 * j + 1))
-        w2 = ops.linear(musig2, blk.inver_mod2.weight.detach(), blk.inver_mod2.bias.detach())
         rec = dict(x=x, musig1=musig1, sc1=sc1, sh1=sh1, n1=n1, x1=x1, musig2=musig2, sc2=sc2, sh2=sh2) if save else None
         has3 = Cc != C2
         nstats = zeros(C2) if not last else None
@@ -145,9 +143,12 @@ def encoder_forward(E, img, noises=None, save=False):
                 out = ops.blend(x1, z=x, sc=sc2, sh=sh2, alpha=0.111, beta=0.889)
         if save:
             saved["blocks"].append(rec)
-        ws = [w2, w1] + ws          # E.py:130-134: later (deeper) blocks come first
         x, stats = out, nstats
-    w = torch.stack(ws, dim=1)
+    # every inver_mod head (w_l = musig_l @ W_l^T + b_l, E.py:51-53,64-66) in one launch: none of them feeds the trunk; column order
+    # of w per E.py:130-134 (later / deeper blocks first) comes from the table
+    w = torch.empty((B, 2 * L, lay["O"]), dtype=torch.float32, device=dev)
+    ops.check(ops.lib().dge_heads_fwd(ops._p(lay["tab"]), lay["n"], ops._f32(musig_all), ops._p(w), w.stride(0), B, lay["O"],
+                                      ops._stream()), "dge_heads_fwd")
     return ops.nhwc_to_nchw(x), w, saved
 
 

@@ -36,6 +36,14 @@ def encoder_backward(E, saved, g_w):
     B = g_w.shape[0]
     grads = {}
     g_out = None
+    later = ops.DeferredSums()          # per-channel parameter-gradient reductions: one grouped launch (two with the DDP hook)
+    post = []                           # what reads a deferred sum runs after the flush
+
+    def flush_sums():
+        later.flush()
+        for f in post:
+            f()
+        post.clear()
     R = saved["img"].shape[2]
     dt = ops.dtype_of(saved["x0"])
     # every inver_mod head at once (their gradient g_w is complete before the backward starts): two launches instead of 4 per block
@@ -79,7 +87,7 @@ def encoder_backward(E, saved, g_w):
                 raise RuntimeError("non-final encoder block without an output gradient")
             # planar reductions ([k, C]): every parameter gradient below is a contiguous view, no strided copies
             red2 = ops.zeros((3 if has3 else 2, C2), dev)     # third row: sum of g_out = conv_3.bias gradient / 0.889
-            g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2, planar=True)
+            g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2, planar=True, defer=later)
             grads[pre + "bias_2"] = red2[0].reshape(1, C2, 1, 1)
             grads[pre + "noise_weight_2"] = red2[1].reshape(1, C2, 1, 1)
             gW2 = ops.zeros(tuple(blk.conv_2.weight.shape), dev)
@@ -88,7 +96,7 @@ def encoder_backward(E, saved, g_w):
             dots2 = ops.SlotStats(B, Cc, dev)                 # slot copies are added by in_bwd_coef
             g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
             if has3:
-                grads[pre + "conv_3.bias"] = red2[2] * 0.889
+                post.append(lambda n=pre + "conv_3.bias", t=red2[2]: grads.__setitem__(n, t * 0.889))
                 gW3 = ops.zeros(tuple(blk.conv_3.weight.shape), dev)
                 ops.conv_wgrad(g_out, rec["xp"], gW3)
                 grads[pre + "conv_3.weight"] = ops.scale_(gW3, 0.889)
@@ -102,7 +110,7 @@ def encoder_backward(E, saved, g_w):
             g_y2, dots2 = None, None
         coef2 = ops.in_bwd_coef(dots2, gms2, rec["musig2"], rec["sc2"], rec["sh2"], N)
         red1 = ops.zeros((2, Cc), dev)
-        g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1, planar=True)
+        g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1, planar=True, defer=later)
         grads[pre + "bias_1"] = red1[0].reshape(1, Cc, 1, 1)
         grads[pre + "noise_weight_1"] = red1[1].reshape(1, Cc, 1, 1)
         gW1 = ops.zeros(tuple(blk.conv_1.weight.shape), dev)
@@ -117,8 +125,10 @@ def encoder_backward(E, saved, g_w):
             # complete here, while the high-resolution blocks still to come take most of the backward's time
             hook = E.__dict__.get("_early_grad_hook")
             if hook is not None:
+                flush_sums()
                 hook(dict(grads))
-    fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float(), planar=True)
+    fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float(), planar=True, defer=later)
+    flush_sums()
     C0 = E.startf
     grads["FromRGB.from_rgb.weight"] = fr[:3].t().reshape(C0, 3, 1, 1)
     grads["FromRGB.from_rgb.bias"] = fr[3]

@@ -40,6 +40,29 @@ extern "C" int dge_set_deterministic(int on) {
 }
 extern "C" int dge_get_deterministic(void) { return g_det_host.enabled; }
 
+static DgeEnv g_env;
+static bool g_env_loaded = false;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static void env_load() {
+    g_env.force_stream = getenv("DGE_FORCE_STREAM") ? 1 : 0;
+    g_env.no_stream = getenv("DGE_NO_STREAM") ? 1 : 0;
+    g_env.stream_nseg = env_int("DGE_STREAM_NSEG", 0);
+    g_env.conv_dbg = env_int("DGE_CONV_DBG", 0);
+    g_env.conv_bn = env_int("DGE_CONV_BN", 0);
+    g_env.conv_kc = env_int("DGE_CONV_KC", 0);
+    g_env.conv_small = env_int("DGE_CONV_SMALL", -1);
+    g_env.conv_nok4 = getenv("DGE_CONV_NOK4") ? 1 : 0;
+    g_env.conv_nok2 = getenv("DGE_CONV_NOK2") ? 1 : 0;
+    g_env.torgb_thread = getenv("DGE_TORGB_THREAD") ? 1 : 0;
+    g_env.wgrad_th8 = getenv("DGE_WGRAD_TH8") ? 1 : 0;
+    g_env.wgrad_groups = env_int("DGE_WGRAD_GROUPS", 0);
+    if (g_env.wgrad_groups < 0) g_env.wgrad_groups = 0;
+    g_env.up_dbg = env_int("DGE_UP_DBG", 0);
+    g_env_loaded = true;
+}
+const DgeEnv& dge_env() { if (!g_env_loaded) env_load(); return g_env; }
+extern "C" void dge_env_reload(void) { env_load(); }
+
 extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(d && d->x && d->w_packed && d->y, "conv2d: null tensor");
     DGE_CHECK(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv2d: bad shape");
@@ -119,6 +142,40 @@ extern "C" int dge_sum_slots_planar(const float* partial, float* out, int nslot,
     DGE_CHECK(nslot >= 1 && C >= 1 && NS >= 1, "sum_slots_planar: bad sizes");
     hipLaunchKernelGGL(sum_slots_planar_kernel, dim3((C * NS + 255) / 256), dim3(256), 0, s, partial, out, nslot, C, NS);
     DGE_LAUNCH_CHECK("sum_slots_planar");
+    return 0;
+}
+// several planar slot sums in one launch (the per-channel parameter-gradient reductions of an encoder backward: none of them is
+// needed before the backward ends, so the per-layer launches are deferred and grouped); table passed by value
+struct SumPlanarTable { dge_sum_planar_entry e[32]; };
+__global__ void sum_slots_planar_multi_kernel(SumPlanarTable tab) {
+    const dge_sum_planar_entry e = tab.e[blockIdx.y];
+    const int n = e.C * e.NS;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        int k = 0;
+        for (; k + 8 <= e.nslot; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = e.partial[(size_t)(k + j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; j++) s += v[j];
+        }
+        for (; k < e.nslot; k++) s += e.partial[(size_t)k * n + i];
+        e.out[(size_t)(i % e.NS) * e.C + i / e.NS] = s;
+    }
+}
+extern "C" int dge_sum_slots_planar_multi(const dge_sum_planar_entry* entries, int n, hipStream_t s) {
+    DGE_CHECK(entries && n >= 1 && n <= 32, "sum_slots_planar_multi: 1..32 entries");
+    SumPlanarTable tab;
+    int maxn = 1;
+    for (int i = 0; i < n; i++) {
+        const dge_sum_planar_entry& e = entries[i];
+        DGE_CHECK(e.partial && e.out && e.nslot >= 1 && e.C >= 1 && e.NS >= 1, "sum_slots_planar_multi: bad entry %d", i);
+        tab.e[i] = e;
+        if (e.C * e.NS > maxn) maxn = e.C * e.NS;
+    }
+    hipLaunchKernelGGL(sum_slots_planar_multi_kernel, dim3((maxn + 255) / 256, n), dim3(256), 0, s, tab);
+    DGE_LAUNCH_CHECK("sum_slots_planar_multi");
     return 0;
 }
 extern "C" int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumulate, hipStream_t s) {

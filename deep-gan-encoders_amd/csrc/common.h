@@ -228,6 +228,15 @@ __device__ __forceinline__ float2 sum_slot_pairs(const float* __restrict__ base,
     return make_float2(s0, s1);
 }
 
+// Tuning / test overrides from the environment, read ONCE (at the first launch) instead of a getenv per launch on the production
+// path (~10 per conv launch, ~1300 launches per step); dge_env_reload() re-reads them (tests that toggle a switch mid-process).
+struct DgeEnv {
+    int force_stream, no_stream, stream_nseg;            // DGE_FORCE_STREAM, DGE_NO_STREAM, DGE_STREAM_NSEG (0 = default)
+    int conv_dbg, conv_bn, conv_kc, conv_small, conv_nok4, conv_nok2;   // DGE_CONV_* (bn / kc 0 = default, small -1 = default)
+    int torgb_thread, wgrad_th8, wgrad_groups, up_dbg;   // DGE_TORGB_THREAD, DGE_WGRAD_TH8, DGE_WGRAD_GROUPS (0 = default), DGE_UP_DBG
+};
+const DgeEnv& dge_env();
+
 // error plumbing shared by the C ABI translation units
 void dge_set_error(const char* fmt, ...);
 // name of the kernel instantiation the calling thread's last conv-family entry point selected (dge_last_kernel)

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
 static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     ConvParams p = p0;
-    { const char* e = getenv("DGE_CONV_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = dge_env().conv_dbg;
     p.tiles_x = (p.W + TW - 1) / TW;
     p.tiles_y = (p.H + TH - 1) / TH;
     const int ntiles = (p.Ntot + BN - 1) / BN;
@@ -434,21 +434,21 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
         const long blocks128 = (long)((p.H + 15) / 16) * ((p.W + 15) / 16) * p.B * (p.Ntot / 128);
         if (blocks128 < 512) bn = 64;
     }
-    { const char* e = getenv("DGE_CONV_BN"); if (e) bn = atoi(e); }
+    if (dge_env().conv_bn > 0) bn = dge_env().conv_bn;
     if (p.up && bn < 64) bn = 64;       // the 32-wide configurations hold a single-phase noise tile
     int kc = kchunk(p.in_s2d ? p.Cin / 4 : p.Cin, E);
-    { const char* e = getenv("DGE_CONV_KC"); if (e) kc = atoi(e); }
+    if (dge_env().conv_kc > 0) kc = dge_env().conv_kc;
     const long work = (long)p.B * p.H * p.W * ((p.Ntot + bn - 1) / bn);
     bool small = (p.H <= 8 && p.W <= 8) || work < 256L * 256;
-    { const char* e = getenv("DGE_CONV_SMALL"); if (e) small = atoi(e) != 0; }
+    if (dge_env().conv_small >= 0) small = dge_env().conv_small != 0;
     if (p.in_t2d) small = false;        // (offered on the 16 x 16 tile configurations only)
 #define GO(TH, TW, BN, KC, WM, WN) return launch_cfg<T, TH, TW, BN, KC, KS, WM, WN>(p, s)
     if (small) {           // 8x8 pixel tiles, narrower N tiles: more workgroups for the low-resolution layers
         if (bn >= 64) {
             // 256- / 128-byte K chunks when the channel count allows: fewer stages / barriers / halo restages in the serial K
             // loop (measured 512->512 @8^2 B=8: 41 us with 64-byte chunks, 32 us with 128, 27 us with 256)
-            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (4 * K0) == 0 && !getenv("DGE_CONV_NOK4")) GO(8, 8, 64, 4 * K0, 2, 2);
-            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (2 * K0) == 0 && !getenv("DGE_CONV_NOK2")) GO(8, 8, 64, 2 * K0, 2, 2);
+            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (4 * K0) == 0 && !dge_env().conv_nok4) GO(8, 8, 64, 4 * K0, 2, 2);
+            if (kc == K0 && (p.in_s2d ? p.Cin / 4 : p.Cin) % (2 * K0) == 0 && !dge_env().conv_nok2) GO(8, 8, 64, 2 * K0, 2, 2);
             if (kc == K0) GO(8, 8, 64, K0, 2, 2);
             GO(8, 8, 64, K1, 2, 2);
         }

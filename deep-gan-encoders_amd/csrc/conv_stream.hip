@@ -654,7 +654,7 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     const int nstrips = (p.W + 31) / 32;
     // segments: all workgroups resident at once when the strips alone do not fill the device; at least 16 rows each
     int nseg = cap / (p.B * nstrips);
-    { const char* e = getenv("DGE_STREAM_NSEG"); if (e) nseg = atoi(e); }
+    if (dge_env().stream_nseg > 0) nseg = dge_env().stream_nseg;
     int maxseg = p.H / 16; if (maxseg < 1) maxseg = 1;
     if (nseg > maxseg) nseg = maxseg;
     if (nseg < 1) nseg = 1;
@@ -701,7 +701,7 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
         // against conv_igemm (profiles/r02_conv_stream_*): data gradient always, generator >= 2^18 pixels, encoder >= 2^20
         const long px = (long)p.B * p.H * p.W;
         const bool enc = p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0);
-        if (!getenv("DGE_FORCE_STREAM")) {           // (tests run the kernel on small ragged shapes)
+        if (!dge_env().force_stream) {           // (tests run the kernel on small ragged shapes)
             if (!p.dot_src && px < (enc ? (1L << 20) : (1L << 18))) return false;
             if (p.dot_src && px < (1L << 16)) return false;
         }
@@ -712,7 +712,7 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     if (p.Cin == 64 && !p.dot_src && (p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0))) return false;
     if (p.dot_src && (p.bias || p.noise || p.in_shift || p.act != DGE_ACT_NONE)) return false;
     if (p.noise && p.noise_w == nullptr) return false;
-    if (getenv("DGE_NO_STREAM")) return false;
+    if (dge_env().no_stream) return false;
     return true;
 }
 

@@ -604,7 +604,7 @@ __global__ void dense_wgrad_kernel(const float* __restrict__ gy, int ldgy, const
 //   gms_l[b,k]  = sum_o g_w[b, col_l + o] * W_l[o,k]                               (head_bwd_data_kernel)
 //   gW_l[o,i]   = sum_b g_w[b, col_l + o] * musig_l[b,i],  gb_l[o] = sum_b g_w[..]  (head_bwd_param_kernel)
 // musig_l / gms_l live at moff_l in flat [sum_l B*I_l] buffers, gW_l at woff_l, gb_l at boff_l of flat buffers.
-struct HeadEntry { const float* W; long moff, woff; int I, gcol, boff, pad; };
+struct HeadEntry { const float* W; long moff, woff; int I, gcol, boff, pad; const float* bias; };
 __global__ __launch_bounds__(1024) void head_bwd_data_kernel(const HeadEntry* __restrict__ tab, const float* __restrict__ g, int ldg,
                                                              float* __restrict__ gms_all, int O) {
     __shared__ float part[16][64];
@@ -666,12 +666,12 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
         const int r = dge_wgrad_dma_try(g, x, in_scale, in_shift, dw, B, H, W, cout, cin, s);
         if (r <= 0) return r;
     }
-    const bool tall = dtype == DGE_BF16 && H >= 16 && !getenv("DGE_WGRAD_TH8");
+    const bool tall = dtype == DGE_BF16 && H >= 16 && !dge_env().wgrad_th8;
     const int tx = (W + 15) / 16, ty = tall ? (H + 15) / 16 : (H + 7) / 8;
     const int ntiles = tx * ty * B;
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
     int groups = 512 / noi; if (groups < 1) groups = 1;
-    { const char* e = getenv("DGE_WGRAD_GROUPS"); if (e) groups = atoi(e); }                  // tuning override
+    if (dge_env().wgrad_groups > 0) groups = dge_env().wgrad_groups;                          // tuning override (clamped below)
     if (groups > ntiles) groups = ntiles;   // few, long-running workgroups: one atomic flush each
     dim3 grid(noi, groups);
     if (dtype == DGE_BF16) dge_note_kernel("conv_wgrad_tr<%d,%d>", ksize, tall ? 16 : 8);
@@ -686,6 +686,27 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     else { if (ksize == 3) WG(float, 3); else WG(float, 1); }
 #undef WG
     DGE_LAUNCH_CHECK("conv_wgrad");
+    return 0;
+}
+
+// forward of all heads at once (E.py:51-53,64-66: w_l = musig_l @ W_l^T + b_l): one wave per (head, sample, output)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadEntry* __restrict__ tab, const float* __restrict__ musig_all,
+                                                       float* __restrict__ w, int ldw, int B, int O) {
+    const HeadEntry e = tab[blockIdx.y];
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= B * O) return;
+    const int b = wave / O, o = wave - b * O;
+    const float* xr = musig_all + e.moff + (size_t)b * e.I;
+    const float* wr = e.W + (size_t)o * e.I;
+    float s = 0.f;
+    for (int i = lane; i < e.I; i += 64) s = fmaf(xr[i], wr[i], s);
+    s = wave_sum(s);
+    if (lane == 0) w[(size_t)b * ldw + e.gcol + o] = s + (e.bias ? e.bias[o] : 0.f);
+}
+extern "C" int dge_heads_fwd(const void* dev_entries, int n, const float* musig_all, float* w, int ldw, int B, int O, hipStream_t s) {
+    DGE_CHECK(n >= 1 && n <= 65535 && B >= 1 && O >= 1, "heads_fwd: bad sizes");
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((B * O * 64 + 255) / 256, n), dim3(256), 0, s, (const HeadEntry*)dev_entries, musig_all, w, ldw, B, O);
+    DGE_LAUNCH_CHECK("heads_fwd");
     return 0;
 }
 

@@ -515,6 +515,11 @@ extern "C" int dge_pack_conv_weights_multi(const long long* table_host, void* de
     // upload = 0: descs_dev still holds the descriptors of an earlier call with the same table (the steady state of a
     // training loop: a pageable host -> device copy waits for the stream to drain, so it is paid once, not per step)
     if (upload) {
+        // (a memcpy node of a stream capture would record the address of this thread's host table, which the next call rewrites:
+        //  a replay would upload whatever table is current.  The table of a training loop is uploaded by its eager warm-up steps.)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) == hipSuccess)
+            DGE_CHECK(cs == hipStreamCaptureStatusNone, "pack_multi: the descriptor table changed inside a stream capture; run the step eagerly once first");
         hipError_t e = hipMemcpyAsync(descs_dev, host.data(), (size_t)n * sizeof(DgePackDesc), hipMemcpyHostToDevice, s);
         DGE_CHECK(e == hipSuccess, "pack_multi: descriptor upload failed: %s", hipGetErrorString(e));
     }
@@ -576,7 +581,7 @@ extern "C" int dge_torgb(const void* x, const float* wrgb, const float* style, c
     const int esz = dtype == DGE_BF16 ? 2 : 4;
     DGE_CHECK(cin % (16 / esz) == 0, "torgb: Cin=%d not a multiple of %d", cin, 16 / esz);
     const int hw = H * W;
-    if (cin >= 256 && cin % (64 * (16 / esz)) == 0 && (long)B * hw <= (1L << 16) && !getenv("DGE_TORGB_THREAD")) {
+    if (cin >= 256 && cin % (64 * (16 / esz)) == 0 && (long)B * hw <= (1L << 16) && !dge_env().torgb_thread) {
         // low resolutions: one wave per pixel (the channels are the only parallelism a 4^2 .. 64^2 image offers)
         const unsigned nblk = (unsigned)(((long)B * hw + 3) / 4);
         if (dtype == DGE_BF16)

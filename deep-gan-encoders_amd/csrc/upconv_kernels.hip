@@ -451,7 +451,7 @@ extern "C" int dge_upconv_fir(const void* x, const void* w_packed, void* y, cons
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.noise_bstride = noise_bstride; p.noise_w_stride = noise_w_stride; p.act = act; p.bias_scale = bias_scale; p.gain = gain;
     p.tiles_x = (W + 13) / 14; p.tiles_y = (H + 13) / 14;
-    { const char* e = getenv("DGE_UP_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = dge_env().up_dbg;
     const long nblk = (long)p.tiles_x * p.tiles_y * B * (Cout / 32);
     dge_note_kernel("upconv_fir<%s>", dtype == DGE_BF16 ? "bf16" : "f32");
     if (dtype == DGE_BF16) hipLaunchKernelGGL(upconv_fir_kernel<bf16_t>, dim3((unsigned)nblk), dim3(256), 0, s, p);

@@ -353,8 +353,7 @@ int launch(const void* g, const void* x, const float* sc, const float* sh, float
         if (dev >= 0 && dev < 16) attr_bytes[dev] = lds_bytes;
     }
     const int wg_per_cu = 2 * lds_bytes <= 160 * 1024 ? 2 : 1;        // registers allow two 4-wave workgroups per CU
-    static int groups_env = -1;
-    if (groups_env < 0) { const char* e = getenv("DGE_WGRAD_GROUPS"); groups_env = e ? atoi(e) : 0; }
+    const int groups_env = dge_env().wgrad_groups;
     // K split: `gps` workgroups per sample and (o, i) tile, one resident set of workgroups where the problem allows it
     int gps = groups_env > 0 ? groups_env : (256 * wg_per_cu + noi * B - 1) / (noi * B);
     gps = gps < 1 ? 1 : (gps > tps ? tps : gps);

@@ -553,14 +553,41 @@ def conv_wgrad(g, x, dw, in_scale=None, in_shift=None):
     return dw
 
 
-def _sum_planar(part, red):
+class DeferredSums:
+    """Planar slot sums whose results nobody reads before the end of a backward: collected, then run as ONE launch
+    (dge_sum_slots_planar_multi) by flush()."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, part, red):
+        self.items.append((part, red))
+        if len(self.items) == 32:
+            self.flush()
+        return red
+
+    def flush(self):
+        if not self.items:
+            return
+        from ._lib import SumPlanarEntry
+        arr = (SumPlanarEntry * len(self.items))()
+        for e, (part, red) in zip(arr, self.items):
+            e.partial, e.out = _p(part), _p(red)
+            e.nslot, e.C, e.NS = part.shape
+        check(lib().dge_sum_slots_planar_multi(arr, len(self.items), _stream()), "dge_sum_slots_planar_multi")
+        self.items = []
+
+
+def _sum_planar(part, red, defer=None):
     """part [B, C, NS] per-sample sums -> red [NS, C] (each reduction a contiguous vector)."""
+    if defer is not None:
+        return defer.add(part, red)
     B, Cc, NS = part.shape
     check(lib().dge_sum_slots_planar(_p(part), _p(red), B, Cc, NS, _stream()), "dge_sum_slots_planar")
     return red
 
 
-def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2, planar=False):
+def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2, planar=False, defer=None):
     """red [C, 2|3] (pre-zeroed; [2|3, C] when planar) receives the batch-summed reductions: the kernel writes per-sample
     partial sums (no cross-sample contention on the atomics) that are added over the batch here."""
     B, H, W, Cc = a.shape
@@ -570,7 +597,7 @@ def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2, plan
     check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(part), ncol, B, H, W, Cc,
                             1 if pool else 0, float(scale), float(slope), dtype_of(a), _stream()), "dge_act_bwd")
     if red is not None:
-        _sum_planar(part, red) if planar else _sum_over_batch(part, red)
+        _sum_planar(part, red, defer) if planar else _sum_over_batch(part, red)
     return gpre
 
 
@@ -585,7 +612,7 @@ def in_bwd_coef(dots, gms, musig, sc, sh, npix):
     return coef
 
 
-def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=None, act=False, red=None, planar=False):
+def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=None, act=False, red=None, planar=False, defer=None):
     """red [C, 2] (or [2, C] when planar)"""
     B, H, W, Cc = x.shape
     gout = torch.empty_like(x)
@@ -593,7 +620,7 @@ def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=Non
     check(lib().dge_in_bwd(_p(gy), _p(x), _f32(coef), _p(extra), _f32(noise), _p(gout), _f32(part), B, H, W, Cc,
                            1 if extra_pool else 0, float(extra_scale), 1 if act else 0, dtype_of(x), _stream()), "dge_in_bwd")
     if red is not None:
-        _sum_planar(part, red) if planar else _sum_over_batch(part, red)
+        _sum_planar(part, red, defer) if planar else _sum_over_batch(part, red)
     return gout
 
 
@@ -604,14 +631,14 @@ def chan_sum(x, scale=1.0):
     return _sum_over_batch(part)
 
 
-def fromrgb_bwd(gx, x0, img, planar=False):
+def fromrgb_bwd(gx, x0, img, planar=False, defer=None):
     """-> [C, 4] (weight gradient columns 0..2, bias gradient column 3); planar: [4, C]"""
     B, H, W, Cc = x0.shape
     part = zeros((B, Cc, 4), x0.device)
     check(lib().dge_fromrgb_bwd(_p(gx), _p(x0), _f32(img.contiguous()), _p(part), B, H * W, Cc, dtype_of(x0), _stream()),
           "dge_fromrgb_bwd")
     if planar:
-        return _sum_planar(part, torch.empty((4, Cc), dtype=torch.float32, device=x0.device))
+        return _sum_planar(part, torch.empty((4, Cc), dtype=torch.float32, device=x0.device), defer)
     return _sum_over_batch(part)
 
 

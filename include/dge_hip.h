@@ -109,9 +109,14 @@ int dge_conv_small_supported(int H, int W, int cin, int ntot, int ksize, int in_
  * "upconv_fir<bf16>", "conv_wgrad_tr<3,16>".  The parity tests assert by name that the configurations which carry the
  * benchmark (dispatch rules of csrc/conv_igemm.hip: launch_t) are the ones compared with the oracle. */
 const char* dge_last_kernel(void);
+/* The DGE_* tuning / test switches are read from the environment once, at the first launch; call this after changing one. */
+void dge_env_reload(void);
 int dge_sum_slots(const float* partial, float* out, int nslot, int n, int accumulate, dge_stream_t stream);
 /* the same sum over slots of [C][NS] partials, written planar: out[k*C + c] */
 int dge_sum_slots_planar(const float* partial, float* out, int nslot, int C, int NS, dge_stream_t stream);
+/* up to 32 of them in one launch (deferred parameter-gradient reductions of an encoder backward) */
+typedef struct dge_sum_planar_entry { const float* partial; float* out; int nslot, C, NS, pad; } dge_sum_planar_entry;
+int dge_sum_slots_planar_multi(const dge_sum_planar_entry* entries, int n, dge_stream_t stream);
 
 /* Weight preparation (once per weight update).  w_oihw: [Cout][Cin][k][k] f32 as stored by the
  * reference (model/stylegan2_generator.py:814-819; model/utils/lreq.py:107-110).  `out` holds
@@ -289,6 +294,9 @@ int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, i
  * per-sample partial sums [B,C,4], pre-zeroed, summed over b by the caller */
 int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img, float* out4, int B, int HW, int C, int dtype,
                     dge_stream_t stream);
+/* Forward of every inver_mod head of the encoder in one launch (E.py:51-53,64-66): w[b, gcol_l + o] = musig_l[b,:] . W_l[o,:] + bias_l[o]
+ * over the same entry table as dge_heads_bwd (entries carry the bias pointer); w [B, ldw]. */
+int dge_heads_fwd(const void* dev_entries, int n, const float* musig_all, float* w, int ldw, int B, int O, dge_stream_t stream);
 /* Backward of all `inver_mod` heads of the encoder (E.py:51-53,66-68: w_l = Linear(mean/std statistics)) in two launches.
  * dev_entries: n records {const float* W [O][I]; long moff, woff; int I, gcol, boff, pad} in DEVICE memory
  * (dge_head_entry_size() bytes); g [B][ldg] holds the gradient of head l at columns gcol .. gcol+O;

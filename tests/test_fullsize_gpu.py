@@ -427,12 +427,23 @@ RAGGED = [
 ]
 
 
+@pytest.fixture
+def force_stream(monkeypatch):
+    """DGE_FORCE_STREAM for one test: the library reads its DGE_* switches once (dge_env), so it is told to re-read them when the
+    variable is set and again when it is removed."""
+    from dge_amd import ops
+    monkeypatch.setenv("DGE_FORCE_STREAM", "1")
+    ops.lib().dge_env_reload()
+    yield
+    monkeypatch.delenv("DGE_FORCE_STREAM", raising=False)
+    ops.lib().dge_env_reload()
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,flavour", RAGGED)
-def test_conv_stream_ragged_shapes(B, H, W, cin, cout, flavour, monkeypatch):
+def test_conv_stream_ragged_shapes(B, H, W, cin, cout, flavour, force_stream):
     """csrc/conv_stream.hip on ragged geometry, every sample and pixel compared (exact-arithmetic bound).  The shapes are
     below the kernel's work thresholds (dge_conv_stream_eligible): DGE_FORCE_STREAM routes them to it."""
     from dge_amd import ops
-    monkeypatch.setenv("DGE_FORCE_STREAM", "1")
     g = _gen(9000 + H + W + cin)
     x = (torch.randn(B, H, W, cin, device=DEV, generator=g)).to(torch.bfloat16)
     w = (_wgt(cout, cin, 3, g) / math.sqrt(9 * cin)).to(torch.bfloat16).float()
