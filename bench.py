@@ -281,15 +281,15 @@ def main():
         # HBM bytes per launch from the PMC counters: collected offline by tools/pmc_traffic.sh (separate rocprofv3 --pmc
         # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
         traffic, tsrc = None, None
-        tname = "r02_conv_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_conv_traffic.json")) else "r01_conv_traffic.json"
+        tname = next((t for t in ("r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r01_conv_traffic.json")
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and a.mtype == 2 and a.img_size == 1024 and a.batch == 8 and a.dtype == "bf16":
             with open(tpath) as f:
                 tj = json.load(f)
-            traffic, tsrc = tj["traffic_bytes_per_launch"], "profiles/" + tname
+            traffic, tsrc = tj["traffic_bytes_per_launch"], "offline PMC (tools/pmc_traffic.sh, separate rocprofv3 --pmc passes over this command), profiles/" + tname
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + upconv_fir_kernel (all conv launches of a step: dge_conv2d)",
+                           "kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + upconv_fir_kernel (all conv launches of a step: dge_conv2d, dge_upconv_fir)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,
                            "algorithmic_bytes_per_launch": ab / max(nlaunch, 1),
