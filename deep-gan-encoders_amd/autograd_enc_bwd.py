@@ -108,7 +108,7 @@ def encoder_backward(E, saved, g_w):
             if g_out is not None:
                 raise RuntimeError("the final encoder block's activation output carries no gradient in E_align")
             g_y2, dots2 = None, None
-        coef2 = ops.in_bwd_coef(dots2, gms2, rec["musig2"], rec["sc2"], rec["sh2"], N)
+        coef2 = (dots2, gms2, rec["musig2"], rec["sc2"], rec["sh2"], N)          # computed inside in_bwd (dge_in_bwd_fused)
         red1 = ops.zeros((2, Cc), dev)
         g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1, planar=True, defer=later)
         grads[pre + "bias_1"] = red1[0].reshape(1, Cc, 1, 1)
@@ -118,7 +118,7 @@ def encoder_backward(E, saved, g_w):
         grads[pre + "conv_1.weight"] = gW1
         dots1 = ops.SlotStats(B, Cc, dev)
         g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
-        coef1 = ops.in_bwd_coef(dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
+        coef1 = (dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
         g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
         if j == L // 2:
             # data-parallel runs: the gradients of blocks L-1 .. L/2 (the 512-channel blocks: > 90 % of the parameter bytes) are

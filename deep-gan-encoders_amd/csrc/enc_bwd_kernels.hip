@@ -409,23 +409,49 @@ __global__ void in_bwd_coef_kernel(const float* __restrict__ dots, const float* 
 
 // g_X = A*g_y + Bc*X + Cc + extra_scale * extra[q(p)]   then, when act != 0 (X = lrelu(pre)):
 // g_pre = g_X * lrelu'(X) with the bias / noise-weight reductions as in act_bwd_kernel.
+// Sources of the coefficients when in_bwd computes them itself (dge_in_bwd_fused: no in_bwd_coef launch in front of it)
+struct InCoefSrc { const float* dots; const float* gms; const float* musig; const float* sc; const float* sh; int nslot, B; float inv_n; };
 template <typename T>
 __global__ __launch_bounds__(256) void in_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ X, const float* __restrict__ coef,
                                                       const T* __restrict__ extra, const float* __restrict__ noise,
                                                       T* __restrict__ gout, float* __restrict__ red_out, int H, int W, int C,
-                                                      int extra_pool, float extra_scale, int act) {
+                                                      int extra_pool, float extra_scale, int act, InCoefSrc cs) {
     constexpr int EP = Elem<T>::PER16;
     __shared__ float red[256 * 2 * EP];
+    __shared__ float lcoef[3 * 512];                    // fused form (C <= 512): this sample's coefficients, computed by the workgroup
     const int b = blockIdx.y;
     const int cpt = C / EP, ppi = 256 / cpt;
     const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
     const int HW = H * W, UW = extra_pool ? W / 2 : W, UHW = extra_pool ? HW / 4 : HW;
     float s[2][EP], A[EP], Bc[EP], Cc[EP];
+    if (!coef) {
+        // the math of in_bwd_coef_kernel for the C channels of sample b (every workgroup of the sample repeats it: C <= 512 channels,
+        // one thread each, slot copies summed with 8 loads in flight - cheaper than a launch of its own in front of this one)
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const int idx = b * C + c;
+            const float r = cs.sc[idx], sft = cs.sh[idx];
+            float S2 = 0.f, S1 = 0.f;
+            if (cs.dots) { const float2 ss = sum_slot_pairs(cs.dots + (size_t)idx * 2, (size_t)cs.B * C * 2, cs.nslot); S2 = ss.x; S1 = ss.y; }
+            const float m1 = S1 * cs.inv_n, m2 = (r * S2 + sft * S1) * cs.inv_n;
+            const float mu = cs.musig[(size_t)b * 2 * C + c], sg = cs.musig[(size_t)b * 2 * C + C + c];
+            const float gmu = cs.gms ? cs.gms[(size_t)b * 2 * C + c] : 0.f, gsg = cs.gms ? cs.gms[(size_t)b * 2 * C + C + c] : 0.f;
+            const float k = sg > 0.f ? gsg * cs.inv_n / sg : 0.f;
+            lcoef[c * 3 + 0] = r;
+            lcoef[c * 3 + 1] = -r * r * m2 + k;
+            lcoef[c * 3 + 2] = -r * m1 - r * m2 * sft + gmu * cs.inv_n - k * mu;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int e = 0; e < EP; e++) {
         s[0][e] = s[1][e] = 0.f;
-        const size_t ci = ((size_t)b * C + chunk * EP + e) * 3;
-        A[e] = coef[ci]; Bc[e] = coef[ci + 1]; Cc[e] = coef[ci + 2];
+        if (coef) {
+            const size_t ci = ((size_t)b * C + chunk * EP + e) * 3;
+            A[e] = coef[ci]; Bc[e] = coef[ci + 1]; Cc[e] = coef[ci + 2];
+        } else {
+            const int ci = (chunk * EP + e) * 3;
+            A[e] = lcoef[ci]; Bc[e] = lcoef[ci + 1]; Cc[e] = lcoef[ci + 2];
+        }
     }
     // two pixels per thread and iteration, all loads issued before the arithmetic (more bytes in flight per wave)
     const int stride = gridDim.x * ppi;
@@ -747,15 +773,28 @@ extern "C" int dge_in_bwd_coef(const float* dots, const float* gms, const float*
     return dge_in_bwd_coef_slots(dots, 1, gms, musig, sc, sh, coef, B, C, npix, s);
 }
 
-extern "C" int dge_in_bwd(const void* gy, const void* x, const float* coef, const void* extra, const float* noise, void* gout,
-                          float* red, int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, hipStream_t s) {
+static int in_bwd_launch(const void* gy, const void* x, const float* coef, const InCoefSrc& cs, const void* extra, const float* noise, void* gout,
+                         float* red, int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "in_bwd: unsupported channel count %d", C);
     dim3 grid(dge_stream_grid(H * W, 256 / (C / ep), B), B);
-    if (dtype == DGE_BF16) hipLaunchKernelGGL(in_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, coef, (const bf16_t*)extra, noise, (bf16_t*)gout, red, H, W, C, extra_pool, extra_scale, act);
-    else hipLaunchKernelGGL(in_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gy, (const float*)x, coef, (const float*)extra, noise, (float*)gout, red, H, W, C, extra_pool, extra_scale, act);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(in_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, coef, (const bf16_t*)extra, noise, (bf16_t*)gout, red, H, W, C, extra_pool, extra_scale, act, cs);
+    else hipLaunchKernelGGL(in_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gy, (const float*)x, coef, (const float*)extra, noise, (float*)gout, red, H, W, C, extra_pool, extra_scale, act, cs);
     DGE_LAUNCH_CHECK("in_bwd");
     return 0;
+}
+extern "C" int dge_in_bwd(const void* gy, const void* x, const float* coef, const void* extra, const float* noise, void* gout,
+                          float* red, int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, hipStream_t s) {
+    DGE_CHECK(coef, "in_bwd: null coefficients");
+    return in_bwd_launch(gy, x, coef, InCoefSrc{}, extra, noise, gout, red, B, H, W, C, extra_pool, extra_scale, act, dtype, s);
+}
+// dge_in_bwd_coef_slots + dge_in_bwd in one launch (C <= 512): every workgroup computes its sample's coefficients itself
+extern "C" int dge_in_bwd_fused(const void* gy, const void* x, const float* dots, int nslot, const float* gms, const float* musig,
+                                const float* sc, const float* sh, int npix, const void* extra, const float* noise, void* gout, float* red,
+                                int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, hipStream_t s) {
+    DGE_CHECK(C <= 512 && nslot >= 1 && musig && sc && sh && npix > 0, "in_bwd_fused: needs C <= 512, musig, sc, sh");
+    InCoefSrc cs{dots, gms, musig, sc, sh, nslot, B, 1.0f / (float)npix};
+    return in_bwd_launch(gy, x, nullptr, cs, extra, noise, gout, red, B, H, W, C, extra_pool, extra_scale, act, dtype, s);
 }
 
 extern "C" int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, int dtype, hipStream_t s) {

@@ -613,12 +613,24 @@ def in_bwd_coef(dots, gms, musig, sc, sh, npix):
 
 
 def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=None, act=False, red=None, planar=False, defer=None):
-    """red [C, 2] (or [2, C] when planar)"""
+    """red [C, 2] (or [2, C] when planar).  `coef`: [B,C,3] from in_bwd_coef, or the tuple (dots, gms, musig, sc, sh, npix) of its
+    arguments - the launch then computes the coefficients itself (dge_in_bwd_fused, C <= 512)."""
     B, H, W, Cc = x.shape
     gout = torch.empty_like(x)
     part = zeros((B, Cc, 2), x.device) if red is not None else None
-    check(lib().dge_in_bwd(_p(gy), _p(x), _f32(coef), _p(extra), _f32(noise), _p(gout), _f32(part), B, H, W, Cc,
-                           1 if extra_pool else 0, float(extra_scale), 1 if act else 0, dtype_of(x), _stream()), "dge_in_bwd")
+    if isinstance(coef, tuple) and Cc > 512:
+        coef = in_bwd_coef(*coef)
+    if isinstance(coef, tuple):
+        dots, gms, musig, sc, sh, npix = coef
+        nslot = 1
+        if isinstance(dots, SlotStats):
+            nslot, dots = dots.nslot, dots.buf
+        check(lib().dge_in_bwd_fused(_p(gy), _p(x), _f32(dots), nslot, _f32(gms), _f32(musig), _f32(sc), _f32(sh), int(npix), _p(extra),
+                                     _f32(noise), _p(gout), _f32(part), B, H, W, Cc, 1 if extra_pool else 0, float(extra_scale),
+                                     1 if act else 0, dtype_of(x), _stream()), "dge_in_bwd_fused")
+    else:
+        check(lib().dge_in_bwd(_p(gy), _p(x), _f32(coef), _p(extra), _f32(noise), _p(gout), _f32(part), B, H, W, Cc,
+                               1 if extra_pool else 0, float(extra_scale), 1 if act else 0, dtype_of(x), _stream()), "dge_in_bwd")
     if red is not None:
         _sum_planar(part, red, defer) if planar else _sum_over_batch(part, red)
     return gout

@@ -288,6 +288,11 @@ int dge_in_bwd_coef_slots(const float* dots, int nslot, const float* gms, const 
  * red [B,C,2] (per-sample partial sums, pre-zeroed; summed over b by the caller) */
 int dge_in_bwd(const void* gy, const void* x, const float* coef, const void* extra, const float* noise, void* gout, float* red,
                int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, dge_stream_t stream);
+/* dge_in_bwd_coef_slots followed by dge_in_bwd as ONE launch (C <= 512): the workgroups compute their sample's coefficients from
+ * (dots [nslot][B,C,2] or NULL, gms [B,2C] or NULL, musig [B,2C], sc, sh [B,C], npix) themselves. */
+int dge_in_bwd_fused(const void* gy, const void* x, const float* dots, int nslot, const float* gms, const float* musig,
+                     const float* sc, const float* sh, int npix, const void* extra, const float* noise, void* gout, float* red,
+                     int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, dge_stream_t stream);
 /* out [B,C] (per-sample partial sums, pre-zeroed) += scale * sum_p x[b,p,c] */
 int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, int dtype, dge_stream_t stream);
 /* out4[b][o][0..2] += sum g_pre*img[c], out4[b][o][3] += sum g_pre with g_pre = gx*lrelu'(x0)  (FromRGB, net.py:231-240);
