@@ -64,7 +64,7 @@ struct WCfg {
     static constexpr int GTAB_OFF = MAIN, TAB_OFF = GTAB_OFF + 9 * 32 * 4;
     static constexpr int RW = TH / NW;                                                 // tile rows per wave
     static_assert(TH % NW == 0 && (NS - 2) * PW <= 63 && GBYTES % 1024 == 0 && NS >= 2 && NS <= 5, "configuration");
-    static int lds_bytes(int B) { return TAB_OFF + B * 64 * 4; }
+    static int lds_bytes() { return TAB_OFF + 64 * 4; }
 };
 
 template <class C>
@@ -75,8 +75,8 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
     constexpr int TH = C::TH, GP = C::GP, XP = C::XP, NW = C::NW, NS = C::NS, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     float* gtab = (float*)(lds + C::GTAB_OFF);          // [9 kinds][32 o]: total, top row, bottom row, left col, right col, 4 corners
-    float* sctab = (float*)(lds + C::TAB_OFF);          // [B][32] clamped scale of this workgroup's input channels
-    float* ktab = sctab + B * 32;                       // [B][32] shift / scale
+    float* sctab = (float*)(lds + C::TAB_OFF);          // [32] scale of this workgroup's sample and input channels
+    float* ktab = sctab + 32;                           // [32] shift
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_it = (Ci + 31) / 32;
@@ -96,12 +96,10 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
     const int t_end = t_begin + per_group < (smp + 1) * tps ? t_begin + per_group : (smp + 1) * tps;
     if (t_begin >= t_end) return;
     const bool aff = sc != nullptr;
-    if (aff) {
-        for (int idx = tid; idx < B * 32; idx += NT) {
-            const int b = idx >> 5, ch = i0 + (idx & 31);
-            sctab[idx] = ch < Ci ? sc[b * Ci + ch] : 1.f;
-            ktab[idx] = ch < Ci ? sh[b * Ci + ch] : 0.f;
-        }
+    if (aff && tid < 32) {
+        const int ch = i0 + tid;
+        sctab[tid] = ch < Ci ? sc[smp * Ci + ch] : 1.f;
+        ktab[tid] = ch < Ci ? sh[smp * Ci + ch] : 0.f;
     }
     __syncthreads();
     f32x16_t acc[9];
@@ -308,7 +306,7 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
                 if (dy != 1) G -= gtab[(dy == 0 ? 32 : 64) + ol];
                 if (dx != 1) G -= gtab[(dx == 0 ? 96 : 128) + ol];
                 if (dy != 1 && dx != 1) G += gtab[160 + 32 * ((dy >> 1) * 2 + (dx >> 1)) + ol];
-                s = fmaf(s, sctab[smp * 32 + il], ktab[smp * 32 + il] * G);
+                s = fmaf(s, sctab[il], ktab[il] * G);
             }
             stg[(ol * 32 + il) * 9 + t] = s;
         }
@@ -339,7 +337,7 @@ int launch(const void* g, const void* x, const float* sc, const float* sh, float
     const int tx = (W + 15) / 16, ty = (H + C::TH - 1) / C::TH;
     const int tps = tx * ty;
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
-    const int lds_bytes = C::lds_bytes(B);
+    const int lds_bytes = C::lds_bytes();
     static int attr_bytes[16] = {0};          // dynamic LDS limit already granted to this instantiation, per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -377,7 +375,7 @@ int dge_wgrad_dma_try(const void* g, const void* x, const float* sc, const float
     static int off = -1;
     if (off < 0) off = getenv("DGE_NO_WGRAD_DMA") ? 1 : 0;
     if (off) return 1;
-    if (B > 32 || cout % 8 || cin % 8) return 1;
+    if (cout % 8 || cin % 8) return 1;
     if ((size_t)H * W * cout * 2 >= (1u << 30) || (size_t)H * W * cin * 2 >= (1u << 30)) return 1;      // 32-bit buffer offsets + DEAD
     const int tps = ((W + 15) / 16) * ((H + 15) / 16);
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
