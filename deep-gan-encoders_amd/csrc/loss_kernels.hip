@@ -214,6 +214,98 @@ __global__ void axpy_scalar_kernel(const float* __restrict__ x, const float* __r
     y[idx] = accumulate ? y[idx] + v : v;
 }
 
+// ------------------------------------------------------------------ the three attention windows of E_align in one pass each
+// E_align_s2.py:185-203 evaluates space_loss on the full image and on two nested crops (AT1, AT2) of the same pair.  Window by
+// window the two 100 MB images were read three times by the reduction, three times by the crop + pool and three times by the
+// gradient (which also re-read and re-wrote the 100 MB gradient as an accumulator).  These forms take up to 3 windows, all inside
+// window 0, and touch every pixel once.
+struct Win3 { int n; int y0[3], x0[3], h[3], w[3]; };
+__global__ __launch_bounds__(256) void loss_reduce3_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ sums, int B, int C, int H, int W, Win3 wn) {
+    __shared__ float red[7 * 4];
+    float v[3][7];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 7; i++) v[k][i] = 0.f;
+    const int h0 = wn.h[0], w0 = wn.w[0];
+    const long npix = (long)B * h0 * w0;
+    const size_t plane = (size_t)H * W;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < npix; idx += gridDim.x * 256L) {
+        const int x = idx % w0; const long r = idx / w0; const int y = r % h0; const int bb = r / h0;
+        const int gy = wn.y0[0] + y, gx = wn.x0[0] + x;
+        const size_t off = (size_t)bb * C * plane + (size_t)gy * W + gx;
+        float t[7] = {0, 0, 0, 0, 0, 0, 0};
+        float ma = -INFINITY, mb = -INFINITY;
+        for (int c = 0; c < C; c++) {
+            const float av = a[off + c * plane], bv = b[off + c * plane];
+            const float d = av - bv;
+            t[0] += d * d; t[1] += av * bv; t[2] += av * av; t[3] += bv * bv; t[4] += av; t[5] += bv;
+            ma = fmaxf(ma, av); mb = fmaxf(mb, bv);
+        }
+        float sa = 0.f, sb = 0.f;
+        for (int c = 0; c < C; c++) { sa += __expf(a[off + c * plane] - ma); sb += __expf(b[off + c * plane] - mb); }
+        const float lsa = __logf(sa) + ma, lsb = __logf(sb) + mb;
+        for (int c = 0; c < C; c++) {
+            const float la = a[off + c * plane] - lsa, lb = b[off + c * plane] - lsb;
+            t[6] += __expf(la) * (la - lb);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const bool in = k < wn.n && (unsigned)(gy - wn.y0[k]) < (unsigned)wn.h[k] && (unsigned)(gx - wn.x0[k]) < (unsigned)wn.w[k];
+#pragma unroll
+            for (int i = 0; i < 7; i++) v[k][i] += in ? t[i] : 0.f;
+        }
+    }
+    for (int k = 0; k < wn.n; k++) {                      // (not offered in deterministic mode: one slot domain per launch)
+        block_atomic_sums(v[k], 7, sums + (size_t)k * 16 * 8, red);
+        __syncthreads();
+    }
+}
+
+struct Pool6 { const float* src[6]; float* dst[6]; int y0[6], x0[6], h[6], w[6], k[6]; int n; };
+__global__ void crop_pool6_kernel(Pool6 t, int BC, int H, int W) {
+    const int e = blockIdx.y;
+    const int k = t.k[e], oh = t.h[e] / k, ow = t.w[e] / k;
+    const long n = (long)BC * oh * ow;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < n; idx += gridDim.x * 256L) {
+        const int x = idx % ow; const long r = idx / ow; const int y = r % oh; const int bc = r / oh;
+        const float* p = t.src[e] + (size_t)bc * H * W + (size_t)(t.y0[e] + y * k) * W + t.x0[e] + x * k;
+        float s = 0.f;
+        for (int i = 0; i < k; i++)
+            for (int j = 0; j < k; j++) s += p[(size_t)i * W + j];
+        t.dst[e][idx] = s / (float)(k * k);
+    }
+}
+
+struct Bwd3 { const float* sums[3]; const float* gp[3]; int k[3]; float n[3], wgt[3]; };
+__global__ void space_loss_bwd3_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ g,
+                                       int BC, int H, int W, Win3 wn, Bwd3 q) {
+    const long tot = (long)BC * wn.h[0] * wn.w[0];
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= tot) return;
+    const int x = idx % wn.w[0]; const long r = idx / wn.w[0]; const int y = r % wn.h[0]; const int bc = r / wn.h[0];
+    const int gy = wn.y0[0] + y, gx = wn.x0[0] + x;
+    const size_t off = (size_t)bc * H * W + (size_t)gy * W + gx;
+    const float av = a[off], bv = b[off];
+    float tot_v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k >= wn.n || q.wgt[k] == 0.f) continue;
+        const int ly = gy - wn.y0[k], lx = gx - wn.x0[k];
+        if ((unsigned)ly >= (unsigned)wn.h[k] || (unsigned)lx >= (unsigned)wn.w[k]) continue;
+        const float* sm = q.sums[k];
+        const float na = sqrtf(sm[2]), nb = sqrtf(sm[3]);
+        float v = 10.f * (bv - av) / q.n[k] + 3.f * (-av / (na * nb) + sm[1] * bv / (na * nb * nb * nb));
+        if (q.gp[k]) {
+            const int kk = q.k[k], oh = wn.h[k] / kk, ow = wn.w[k] / kk;
+            if (ly / kk < oh && lx / kk < ow) v += q.gp[k][((size_t)bc * oh + ly / kk) * ow + lx / kk] / (float)(kk * kk);
+        }
+        tot_v += v * q.wgt[k];
+    }
+    g[off] = tot_v;
+}
+
 // =================================================================== C ABI
 static Gauss11 gauss11() {
     Gauss11 G; float s = 0.f;
@@ -230,6 +322,68 @@ extern "C" int dge_loss_reduce(const float* a, const float* b, float* sums7, int
     int grid = (int)((npix + 255) / 256); if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(grid), dim3(256), 0, s, a, b, sums7, B, C, mk(H, W, y0, x0, h, w));
     DGE_LAUNCH_CHECK("loss_reduce");
+    return 0;
+}
+
+static int win3_from(const int* wins, int nwin, int H, int W, Win3& wn) {
+    DGE_CHECK(wins && nwin >= 1 && nwin <= 3, "multi-window loss: 1..3 windows");
+    wn.n = nwin;
+    for (int k = 0; k < 3; k++) {
+        const int j = k < nwin ? k : 0;
+        wn.y0[k] = wins[4 * j]; wn.x0[k] = wins[4 * j + 1]; wn.h[k] = wins[4 * j + 2]; wn.w[k] = wins[4 * j + 3];
+        DGE_CHECK(wn.y0[k] >= wn.y0[0] && wn.x0[k] >= wn.x0[0] && wn.y0[k] + wn.h[k] <= wn.y0[0] + wn.h[0] && wn.x0[k] + wn.w[k] <= wn.x0[0] + wn.w[0]
+                  && wn.h[k] > 0 && wn.w[k] > 0 && wn.y0[0] >= 0 && wn.x0[0] >= 0 && wn.y0[0] + wn.h[0] <= H && wn.x0[0] + wn.w[0] <= W,
+                  "multi-window loss: window %d must lie inside window 0, window 0 inside the image", k);
+    }
+    return 0;
+}
+// dge_loss_reduce for up to 3 windows (y0, x0, h, w each; all inside window 0) in one pass: sums [nwin][16][8] slot copies, pre-zeroed
+extern "C" int dge_loss_reduce3(const float* a, const float* b, float* sums, int B, int C, int H, int W, const int* wins, int nwin,
+                                hipStream_t s) {
+    Win3 wn;
+    if (win3_from(wins, nwin, H, W, wn)) return -1;
+    DGE_CHECK(!dge_get_deterministic(), "loss_reduce3 is not offered in deterministic mode (run dge_loss_reduce per window)");
+    const long npix = (long)B * wn.h[0] * wn.w[0];
+    int grid = (int)((npix + 255) / 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(loss_reduce3_kernel, dim3(grid), dim3(256), 0, s, a, b, sums, B, C, H, W, wn);
+    DGE_LAUNCH_CHECK("loss_reduce3");
+    return 0;
+}
+// dge_crop_pool of up to 6 (source, window, pooling factor) entries in one launch; entry e: src[e] [BC,H,W] -> dst[e] [BC,h/k,w/k]
+extern "C" int dge_crop_pool_multi(const float* const* src, float* const* dst, const int* wins, const int* ks, int n, int BC, int H, int W,
+                                   hipStream_t s) {
+    DGE_CHECK(n >= 1 && n <= 6 && src && dst && wins && ks, "crop_pool_multi: 1..6 entries");
+    Pool6 t; t.n = n;
+    long mx = 1;
+    for (int e = 0; e < n; e++) {
+        t.src[e] = src[e]; t.dst[e] = dst[e];
+        t.y0[e] = wins[4 * e]; t.x0[e] = wins[4 * e + 1]; t.h[e] = wins[4 * e + 2]; t.w[e] = wins[4 * e + 3]; t.k[e] = ks[e];
+        DGE_CHECK(t.k[e] >= 1 && t.h[e] % t.k[e] == 0 && t.w[e] % t.k[e] == 0 && t.y0[e] >= 0 && t.x0[e] >= 0 && t.y0[e] + t.h[e] <= H && t.x0[e] + t.w[e] <= W,
+                  "crop_pool_multi: bad entry %d", e);
+        const long ne = (long)BC * (t.h[e] / t.k[e]) * (t.w[e] / t.k[e]);
+        if (ne > mx) mx = ne;
+    }
+    long blocks = (mx + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(crop_pool6_kernel, dim3((unsigned)blocks, n), dim3(256), 0, s, t, BC, H, W);
+    DGE_LAUNCH_CHECK("crop_pool_multi");
+    return 0;
+}
+// dge_space_loss_bwd for up to 3 windows in one pass: g (window 0's pixels) = sum_k weight[k] * (window k's gradient); g is WRITTEN
+// (no accumulation); pixels of the image outside window 0 are not touched.  weight[k] = 0 leaves window k out.
+extern "C" int dge_space_loss_bwd3(const float* a, const float* b, const float* const* sums7, const float* const* g_pooled, float* g,
+                                   int BC, int H, int W, const int* wins, const int* ks, const float* n, const float* weight, int nwin,
+                                   hipStream_t s) {
+    Win3 wn;
+    if (win3_from(wins, nwin, H, W, wn)) return -1;
+    Bwd3 q;
+    for (int k = 0; k < 3; k++) {
+        const int j = k < nwin ? k : 0;
+        q.sums[k] = sums7[j]; q.gp[k] = g_pooled ? g_pooled[j] : nullptr; q.k[k] = ks[j]; q.n[k] = n[j]; q.wgt[k] = k < nwin ? weight[j] : 0.f;
+        DGE_CHECK(q.sums[k] && q.k[k] >= 1 && q.n[k] > 0.f, "space_loss_bwd3: bad window %d", k);
+    }
+    const long tot = (long)BC * wn.h[0] * wn.w[0];
+    hipLaunchKernelGGL(space_loss_bwd3_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, a, b, g, BC, H, W, wn, q);
+    DGE_LAUNCH_CHECK("space_loss_bwd3");
     return 0;
 }
 

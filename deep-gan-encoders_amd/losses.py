@@ -105,6 +105,76 @@ def _space_loss_windows(a, b, wins, image_space, lpips_model, weights, g_outs, a
     return [_window_finish(a, b, st, image_space, weights[i], g_outs[i], accumulate, world) for i, st in enumerate(sts)]
 
 
+def _space_loss_windows3(a, b, wins, lpips_model, weights, g, need, gb=None):
+    """The three nested attention windows of image_loss_tsa with every image pass merged (dge_loss_reduce3, dge_crop_pool_multi,
+    dge_space_loss_bwd3): `g` (or None) is WRITTEN with the weighted sum of the windows' gradients; need[i] False leaves window i
+    out of the gradient.  Same arithmetic as _window_reduce / _window_finish per window."""
+    import ctypes as C
+    B, Cc, H, W = a.shape
+    dev = a.device
+    L = lib()
+    world = gb.world if gb is not None else 1
+    nw = len(wins)
+    pack = ops.zeros((nw, _PK), dev)
+    slots = ops.zeros((nw, 16, 8), dev)
+    wflat = (C.c_int * (4 * nw))(*[int(v) for win in wins for v in win])
+    check(L.dge_loss_reduce3(_f32(a), _f32(b), _p(slots), B, Cc, H, W, wflat, nw, _stream()), "dge_loss_reduce3")
+    sums = ops.DeferredSums()
+    for i in range(nw):
+        sums.add(slots[i].view(16, 8, 1), pack[i, 0:8])      # [nslot, C = 8, NS = 1] -> the 8 sums of window i
+    sums.flush()
+    ks = [_pool_factor(win[2]) for win in wins]
+    aps = [torch.empty((B, Cc, win[2] // k, win[3] // k), dtype=torch.float32, device=dev) for win, k in zip(wins, ks)]
+    bps = [torch.empty_like(t) for t in aps]
+    srcs = (C.c_void_p * (2 * nw))(*([a.data_ptr()] * nw + [b.data_ptr()] * nw))
+    dsts = (C.c_void_p * (2 * nw))(*([t.data_ptr() for t in aps] + [t.data_ptr() for t in bps]))
+    w2 = (C.c_int * (8 * nw))(*([int(v) for win in wins for v in win] * 2))
+    k2 = (C.c_int * (2 * nw))(*(ks * 2))
+    check(L.dge_crop_pool_multi(srcs, dsts, w2, k2, 2 * nw, B * Cc, H, W, _stream()), "dge_crop_pool_multi")
+    sts = []
+    for i, win in enumerate(wins):
+        y0, x0, h, w = win
+        ap, bp, k = aps[i], bps[i], ks[i]
+        hp, wp = h // k, w // k
+        ng = g is not None and need[i]
+        dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if ng else None
+        check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(pack[i, 8:40]), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
+        st = dict(win=win, pk=pack[i], k=k, npool=float(B * Cc * hp * wp) * world, n=float(B * Cc * h * w) * world, ap=ap, bp=bp,
+                  dmap=dmap, g_lp=None, lp=None, ng=ng)
+        if lpips_model is not None:
+            lp, st["g_lp"] = lpips_model.value_and_grad(ap, bp, need_grad=ng)
+            if world > 1:
+                check(L.dge_axpy_scalar(_p(lp), None, _p(pack[i, 40:41]), 1, 1.0 / world, 0, _stream()), "dge_axpy_scalar")
+                lp = pack[i, 40:41]
+            st["lp"] = lp
+        sts.append(st)
+    if gb is not None:
+        gb.reduce(pack)
+    outs, gps = [], []
+    for i, st in enumerate(sts):
+        gp = None
+        if st["ng"]:
+            bp = st["bp"]
+            gp = torch.empty_like(bp)
+            check(L.dge_ssim_bwd(_p(st["ap"]), _p(bp), _p(st["dmap"]), _p(gp), B * Cc, bp.shape[2], bp.shape[3], -1.0 / st["npool"], 0,
+                                 _stream()), "dge_ssim_bwd")
+            if st["g_lp"] is not None:
+                check(L.dge_axpy_scalar(_p(st["g_lp"]), None, _p(gp), gp.numel(), 2.0 / world, 1, _stream()), "dge_axpy_scalar")
+        gps.append(gp)
+        out8 = torch.empty(8, dtype=torch.float32, device=dev)
+        check(L.dge_space_loss_finalize(_p(pack[i, 0:8]), _p(pack[i, 8:40]), _p(st["lp"]), _p(out8), st["n"], st["npool"], 1, _stream()),
+              "dge_space_loss_finalize")
+        outs.append(out8)
+    if g is not None:
+        sp = (C.c_void_p * nw)(*[pack[i, 0:8].data_ptr() for i in range(nw)])
+        gpp = (C.c_void_p * nw)(*[(t.data_ptr() if t is not None else None) for t in gps])
+        nn = (C.c_float * nw)(*[st["n"] for st in sts])
+        ww = (C.c_float * nw)(*[float(weights[i]) if sts[i]["ng"] else 0.0 for i in range(nw)])
+        kk = (C.c_int * nw)(*ks)
+        check(L.dge_space_loss_bwd3(_f32(a), _f32(b), sp, gpp, _p(g), B * Cc, H, W, wflat, kk, nn, ww, nw, _stream()), "dge_space_loss_bwd3")
+    return outs
+
+
 def _space_loss_window(a, b, win, image_space, lpips_model, weight, g_out, accumulate, gb=None):
     return _space_loss_windows(a, b, [win], image_space, lpips_model, [weight], [g_out], accumulate, gb)[0]
 
@@ -151,10 +221,15 @@ def image_loss_tsa(imgs1, imgs2, lpips_model=None, weights=(1.0, 5.0, 9.0), glob
     a = imgs1.detach().float().contiguous()
     b = imgs2.detach().float().contiguous()
     need = imgs2.requires_grad and torch.is_grad_enabled()
-    g = torch.zeros_like(b) if need else None
+    wins = attention_windows(a.shape[2], a.shape[3])
     # grad_windows[i] False: the window enters the loss VALUE only (embedding_img.py:95-107 detaches both crops)
-    infos = _space_loss_windows(a, b, attention_windows(a.shape[2], a.shape[3]), True, lpips_model, weights,
-                                [g if (need and grad_windows[i]) else None for i in range(3)], accumulate=True, gb=global_batch)
+    if not ops.is_deterministic():       # every pass over the two images merged over the three windows
+        g = torch.empty_like(b) if need else None
+        infos = _space_loss_windows3(a, b, wins, lpips_model, weights, g, [bool(need and grad_windows[i]) for i in range(3)], gb=global_batch)
+    else:
+        g = torch.zeros_like(b) if need else None
+        infos = _space_loss_windows(a, b, wins, True, lpips_model, weights,
+                                    [g if (need and grad_windows[i]) else None for i in range(3)], accumulate=True, gb=global_batch)
     info = torch.stack(infos)
     loss = info[0, 0] * float(weights[0]) + info[1, 0] * float(weights[1]) + info[2, 0] * float(weights[2])   # no host->device copy
     if need:

@@ -208,6 +208,15 @@ int dge_space_loss_finalize(const float* sums7, const float* ssim_sum, const flo
 /* g[window] (+)= weight * d(5*mse + 3*cos)/db + weight * unpool_k(g_pooled)   (g_pooled optional) */
 int dge_space_loss_bwd(const float* a, const float* b, const float* sums7, const float* g_pooled, float* g, int BC, int H,
                        int W, int y0, int x0, int h, int w, int k, float n, float weight, int accumulate, dge_stream_t stream);
+/* The same three kernels for the nested attention windows of E_align_s2.py:185-203 (full image, AT1, AT2), every pixel touched
+ * once: wins = nwin x (y0, x0, h, w), all inside window 0.  dge_loss_reduce3: sums [nwin][16][8] slot copies (pre-zeroed; add
+ * them with dge_sum_slots; not offered in deterministic mode).  dge_crop_pool_multi: n <= 6 (source plane set, window, pooling
+ * factor) entries.  dge_space_loss_bwd3: g over window 0 is WRITTEN with sum_k weight[k] * gradient of window k. */
+int dge_loss_reduce3(const float* a, const float* b, float* sums, int B, int C, int H, int W, const int* wins, int nwin, dge_stream_t stream);
+int dge_crop_pool_multi(const float* const* src, float* const* dst, const int* wins, const int* ks, int n, int BC, int H, int W,
+                        dge_stream_t stream);
+int dge_space_loss_bwd3(const float* a, const float* b, const float* const* sums7, const float* const* g_pooled, float* g, int BC, int H,
+                        int W, const int* wins, const int* ks, const float* n, const float* weight, int nwin, dge_stream_t stream);
 /* y (+)= x * scalar[0] * extra  (scalar may be NULL) */
 int dge_axpy_scalar(const float* x, const float* scalar, float* y, long n, float extra, int accumulate, dge_stream_t stream);
 
