@@ -132,6 +132,8 @@ SIGNATURES = {
     "dge_randn": [_P, _I, _P, _P, _P, _P, C.c_ulonglong, _P, _P],
     "dge_version": [],
     "dge_env_reload": [],
+    "dge_blend_pool_mask": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P],
+    "dge_act_bwd_mask": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],
     "dge_loss_reduce3": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     "dge_crop_pool_multi": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dge_space_loss_bwd3": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],

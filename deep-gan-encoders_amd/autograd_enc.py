@@ -124,16 +124,21 @@ def encoder_forward(E, img, noises=None, save=False):
             a2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H), C2, 3, in_scale=sc2, in_shift=sh2, noise=n2,
                             noise_w=blk.noise_weight_2.detach().reshape(-1), bias=blk.bias_2.detach().reshape(-1),
                             act=ops.ACT_LRELU)
+            m2 = None
             if has3:
-                x2 = ops.blend(a2, pool=True)
+                x2, m2 = ops.blend(a2, pool=True, mask=True) if save else (ops.blend(a2, pool=True), None)
                 xp = ops.blend(x, pool=True)
                 out = ops.conv2d(xp, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(),
                                  gain=0.889, addend=x2, add_scale=0.111, stats=nstats)
             else:
                 xp = ops.blend(x, pool=True, alpha=0.889)
-                out = ops.blend(a2, z=xp, pool=True, alpha=0.111, beta=1.0, stats=nstats.plain())
+                if save:
+                    out, m2 = ops.blend(a2, z=xp, pool=True, alpha=0.111, beta=1.0, stats=nstats.plain(), mask=True)
+                else:
+                    out = ops.blend(a2, z=xp, pool=True, alpha=0.111, beta=1.0, stats=nstats.plain())
             if save:
-                rec.update(n2=n2, a2=a2, xp=xp if has3 else None)
+                # a2 itself is not kept: its backward (lrelu derivative + pool adjoint) needs only the signs (1 bit per element)
+                rec.update(n2=n2, m2=m2, xp=xp if has3 else None)
         else:
             if has3:
                 y2 = ops.blend(x1, sc=sc2, sh=sh2)

@@ -87,7 +87,7 @@ def encoder_backward(E, saved, g_w):
                 raise RuntimeError("non-final encoder block without an output gradient")
             # planar reductions ([k, C]): every parameter gradient below is a contiguous view, no strided copies
             red2 = ops.zeros((3 if has3 else 2, C2), dev)     # third row: sum of g_out = conv_3.bias gradient / 0.889
-            g_pre2 = ops.act_bwd(g_out, rec["a2"], rec["n2"], pool=True, scale=0.111 * 0.25, red=red2, planar=True, defer=later)
+            g_pre2 = ops.act_bwd_mask(g_out, rec["m2"], rec["n2"], scale=0.111 * 0.25, red=red2, planar=True, defer=later)
             grads[pre + "bias_2"] = red2[0].reshape(1, C2, 1, 1)
             grads[pre + "noise_weight_2"] = red2[1].reshape(1, C2, 1, 1)
             gW2 = ops.zeros(tuple(blk.conv_2.weight.shape), dev)

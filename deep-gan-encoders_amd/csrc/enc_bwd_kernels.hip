@@ -382,6 +382,50 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ gup,
     if (red_out) block_chan_flush<EP, NS>(s, cpt, ppi, red_out + (size_t)b * C * NS, C, red);      // per-sample partial sums
 }
 
+// The pooled case from the sign mask of dge_blend_pool_mask: one thread = one 16-byte chunk of one POOLED pixel q = its four children.
+// g_pre[b, child, c] = scale * g_up[b,q,c] * (bit ? 1 : slope);  red as act_bwd_kernel (third column: sum of g_up).
+template <typename T, int NS>
+__global__ __launch_bounds__(256) void act_bwd_mask_kernel(const T* __restrict__ gup, const unsigned* __restrict__ mask,
+                                                            const float* __restrict__ noise, T* __restrict__ gpre,
+                                                            float* __restrict__ red_out, int H, int W, int C, float scale, float slope) {
+    constexpr int EP = Elem<T>::PER16;
+    __shared__ float red[256 * NS * EP];
+    const int b = blockIdx.y;
+    const int cpt = C / EP, ppi = 256 / cpt;
+    const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
+    const int UW = W / 2, UHW = (H / 2) * UW, HW = H * W;
+    float s[NS][EP];
+#pragma unroll
+    for (int k = 0; k < NS; k++)
+#pragma unroll
+        for (int e = 0; e < EP; e++) s[k][e] = 0.f;
+    for (int q0 = blockIdx.x * ppi; q0 < UHW; q0 += gridDim.x * ppi) {
+        const int q = q0 + slot;
+        if (slot < ppi && q < UHW) {
+            float g[EP];
+            unpack16(*(const uint4*)(gup + ((size_t)b * UHW + q) * C + chunk * EP), g, (T*)nullptr);
+            const unsigned m = mask[((size_t)b * UHW + q) * cpt + chunk];
+            const int oy = q / UW, ox = q - oy * UW;
+            const int p00 = (2 * oy) * W + 2 * ox;
+#pragma unroll
+            for (int e = 0; e < EP; e++) { if constexpr (NS == 3) s[2][e] += g[e]; g[e] *= scale; }
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) {
+                const int p = p00 + (c4 >> 1) * W + (c4 & 1);
+                const float nz = noise ? noise[(size_t)b * HW + p] : 0.f;
+                float o[EP];
+#pragma unroll
+                for (int e = 0; e < EP; e++) {
+                    o[e] = g[e] * (((m >> (c4 * EP + e)) & 1u) ? 1.f : slope);
+                    s[0][e] += o[e]; s[1][e] += o[e] * nz;
+                }
+                *(uint4*)(gpre + ((size_t)b * HW + p) * C + chunk * EP) = pack16(o, (T*)nullptr);
+            }
+        }
+    }
+    if (red_out) block_chan_flush<EP, NS>(s, cpt, ppi, red_out + (size_t)b * C * NS, C, red);
+}
+
 // ------------------------------------------------------------------ instance-norm + statistics backward
 // Coefficients of g_X = A*g_y + Bc*X + Cc for y = (X-mu)*r, with the extra gradients g_mu, g_sigma of
 // the (mean, std) outputs (E.py:51-53): see DESIGN.md.  dots[b,c] = (sum g_y*X, sum g_y) from the dgrad conv
@@ -758,6 +802,20 @@ extern "C" int dge_act_bwd(const void* gup, const void* a, const float* noise, v
     else { if (red_cols == 3) AB(float, 3); else AB(float, 2); }
 #undef AB
     DGE_LAUNCH_CHECK("act_bwd");
+    return 0;
+}
+
+extern "C" int dge_act_bwd_mask(const void* gup, const unsigned* mask, const float* noise, void* gpre, float* red, int red_cols, int B, int H,
+                                int W, int C, float scale, float slope, int dtype, hipStream_t s) {
+    const int ep = dtype == DGE_BF16 ? 8 : 4;
+    DGE_CHECK(CHAN_OK(C, ep) && H % 2 == 0 && W % 2 == 0 && mask, "act_bwd_mask: unsupported shape (C %d, %d x %d)", C, H, W);
+    DGE_CHECK(red_cols == 2 || red_cols == 3, "act_bwd_mask: red_cols must be 2 or 3 (got %d)", red_cols);
+    dim3 grid(dge_stream_grid(H * W / 4, 256 / (C / ep), B), B);
+#define AB(T, NS) hipLaunchKernelGGL((act_bwd_mask_kernel<T, NS>), grid, dim3(256), 0, s, (const T*)gup, mask, noise, (T*)gpre, red, H, W, C, scale, slope)
+    if (dtype == DGE_BF16) { if (red_cols == 3) AB(bf16_t, 3); else AB(bf16_t, 2); }
+    else { if (red_cols == 3) AB(float, 3); else AB(float, 2); }
+#undef AB
+    DGE_LAUNCH_CHECK("act_bwd_mask");
     return 0;
 }
 

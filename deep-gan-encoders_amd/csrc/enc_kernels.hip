@@ -70,7 +70,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ x, const T* __restrict__ z, T* __restrict__ y,
                                                      const float* __restrict__ sc, const float* __restrict__ sh,
                                                      float* __restrict__ stats, int OH, int OW, int C, int pool,
-                                                     float alpha, float beta) {
+                                                     float alpha, float beta, unsigned* __restrict__ mask) {
     constexpr int EP = Elem<T>::PER16;
     __shared__ float red[256 * 2 * EP];
     const int b = blockIdx.y;
@@ -99,6 +99,14 @@ __global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ x, con
                 unpack16(*(const uint4*)(base + (size_t)IW * C + C), f3, (T*)nullptr);
 #pragma unroll
                 for (int e = 0; e < EP; e++) f[e] = 0.25f * (f0[e] + f1[e] + f2[e] + f3[e]);
+                if (mask) {            // signs of the 4 x EP pooled inputs: all the activation backward needs of them (dge_act_bwd_mask)
+                    unsigned m = 0;
+#pragma unroll
+                    for (int e = 0; e < EP; e++)
+                        m |= (f0[e] > 0.f ? 1u : 0u) << e | (f1[e] > 0.f ? 1u : 0u) << (EP + e) | (f2[e] > 0.f ? 1u : 0u) << (2 * EP + e) |
+                             (f3[e] > 0.f ? 1u : 0u) << (3 * EP + e);
+                    mask[((size_t)b * OHW + p) * cpt + chunk] = m;
+                }
             } else {
                 unpack16(*(const uint4*)(xb + (size_t)p * C + chunk * EP), f, (T*)nullptr);
             }
@@ -282,18 +290,29 @@ extern "C" int dge_stats_finalize(const float* stats, float* musig, float* sc, f
     return dge_stats_finalize_slots(stats, 1, musig, sc, sh, B, C, npix, eps, s);
 }
 
-extern "C" int dge_blend(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B,
-                         int OH, int OW, int C, int pool, float alpha, float beta, int dtype, hipStream_t s) {
+static int blend_launch(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B,
+                        int OH, int OW, int C, int pool, float alpha, float beta, unsigned* mask, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "blend: unsupported channel count %d", C);
     const int ppi = 256 / (C / ep);
     dim3 grid(dge_stream_grid(OH * OW, ppi, B), B);
     if (dtype == DGE_BF16)
-        hipLaunchKernelGGL(blend_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)z, (bf16_t*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta);
+        hipLaunchKernelGGL(blend_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)z, (bf16_t*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta, mask);
     else
-        hipLaunchKernelGGL(blend_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)z, (float*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta);
+        hipLaunchKernelGGL(blend_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)z, (float*)y, sc, sh, stats, OH, OW, C, pool, alpha, beta, mask);
     DGE_LAUNCH_CHECK("blend");
     return 0;
+}
+extern "C" int dge_blend(const void* x, const void* z, void* y, const float* sc, const float* sh, float* stats, int B,
+                         int OH, int OW, int C, int pool, float alpha, float beta, int dtype, hipStream_t s) {
+    return blend_launch(x, z, y, sc, sh, stats, B, OH, OW, C, pool, alpha, beta, nullptr, dtype, s);
+}
+// the pooling blend, also leaving the SIGNS of its full-resolution input: mask [B, OH*OW, C/ep] words, bit q*ep + e = (x at the q-th
+// of the 2x2 children, channel e of the chunk) > 0.  The activation backward of that input reads 1 bit per element instead of the tensor.
+extern "C" int dge_blend_pool_mask(const void* x, const void* z, void* y, float* stats, unsigned* mask, int B, int OH, int OW, int C,
+                                   float alpha, float beta, int dtype, hipStream_t s) {
+    DGE_CHECK(mask, "blend_pool_mask: null mask");
+    return blend_launch(x, z, y, nullptr, nullptr, stats, B, OH, OW, C, 1, alpha, beta, mask, dtype, s);
 }
 
 extern "C" int dge_blur_noise_act(const void* x, const float* noise, const float* noise_w, const float* bias, void* y, float* stats,

@@ -431,10 +431,19 @@ def stats_finalize(stats, npix, eps=1e-8, musig_out=None):
     return musig, sc, sh
 
 
-def blend(x, z=None, sc=None, sh=None, pool=False, alpha=1.0, beta=0.0, stats=None):
+def blend(x, z=None, sc=None, sh=None, pool=False, alpha=1.0, beta=0.0, stats=None, mask=False):
+    """mask=True (pooling blend without sc / sh): also returns the sign mask of x for act_bwd_mask -> (y, mask)"""
     B, H, W, Cc = x.shape
     OH, OW = (H // 2, W // 2) if pool else (H, W)
     y = torch.empty((B, OH, OW, Cc), dtype=x.dtype, device=x.device)
+    if mask:
+        if not pool or sc is not None or sh is not None:
+            raise DgeError("blend: the sign mask is offered for the plain pooling blend")
+        ep = 8 if x.dtype == torch.bfloat16 else 4
+        m = torch.empty((B, OH * OW, Cc // ep), dtype=torch.int32, device=x.device)
+        check(lib().dge_blend_pool_mask(_p(x), _p(z), _p(y), _f32(stats), _p(m), B, OH, OW, Cc, float(alpha), float(beta), dtype_of(x),
+                                        _stream()), "dge_blend_pool_mask")
+        return y, m
     check(lib().dge_blend(_p(x), _p(z), _p(y), _f32(sc), _f32(sh), _f32(stats), B, OH, OW, Cc, 1 if pool else 0,
                           float(alpha), float(beta), dtype_of(x), _stream()), "dge_blend")
     return y
@@ -596,6 +605,20 @@ def act_bwd(gup, a, noise=None, pool=False, scale=1.0, red=None, slope=0.2, plan
     part = zeros((B, Cc, ncol), a.device) if red is not None else None
     check(lib().dge_act_bwd(_p(gup), _p(a), _f32(noise), _p(gpre), _f32(part), ncol, B, H, W, Cc,
                             1 if pool else 0, float(scale), float(slope), dtype_of(a), _stream()), "dge_act_bwd")
+    if red is not None:
+        _sum_planar(part, red, defer) if planar else _sum_over_batch(part, red)
+    return gpre
+
+
+def act_bwd_mask(gup, mask, noise, scale=1.0, red=None, slope=0.2, planar=False, defer=None):
+    """act_bwd(pool=True) from the sign mask of blend(..., mask=True): gup [B,H/2,W/2,C] -> g_pre [B,H,W,C]"""
+    B, UH, UW, Cc = gup.shape
+    H, W = 2 * UH, 2 * UW
+    gpre = torch.empty((B, H, W, Cc), dtype=gup.dtype, device=gup.device)
+    ncol = 2 if red is None else (red.shape[0] if planar else red.shape[-1])
+    part = zeros((B, Cc, ncol), gup.device) if red is not None else None
+    check(lib().dge_act_bwd_mask(_p(gup), _p(mask), _f32(noise), _p(gpre), _f32(part), ncol, B, H, W, Cc, float(scale), float(slope),
+                                 dtype_of(gup), _stream()), "dge_act_bwd_mask")
     if red is not None:
         _sum_planar(part, red, defer) if planar else _sum_over_batch(part, red)
     return gpre

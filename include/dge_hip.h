@@ -282,6 +282,13 @@ int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const fl
    bias gradient of a parallel 1x1 branch fed by the same gup, reference E.py conv_3) */
 int dge_act_bwd(const void* gup, const void* a, const float* noise, void* gpre, float* red, int red_cols, int B, int H, int W, int C,
                 int pool, float scale, float slope, int dtype, dge_stream_t stream);
+/* The pooled case without the activation tensor: dge_blend_pool_mask (the forward's avg-pool blend, model/E/E.py:76-84) leaves the
+ * signs of its input as mask [B, (H/2)*(W/2), C/ep] words (bit q*ep + e: child q of the 2x2 block, channel e of the 16-byte chunk);
+ * dge_act_bwd_mask = dge_act_bwd(pool = 1) reading that mask: 1 bit per element instead of the stored activation. */
+int dge_blend_pool_mask(const void* x, const void* z, void* y, float* stats, unsigned* mask, int B, int OH, int OW, int C, float alpha,
+                        float beta, int dtype, dge_stream_t stream);
+int dge_act_bwd_mask(const void* gup, const unsigned* mask, const float* noise, void* gpre, float* red, int red_cols, int B, int H, int W,
+                     int C, float scale, float slope, int dtype, dge_stream_t stream);
 /* FromRGB data gradient (model/utils/net.py:231-240 differentiated w.r.t. the image; embedding_img.py:88 feeds a generated,
  * gradient-carrying image into the encoder): gimg [B,3,HW] f32 = sum_c w[c][k] * gx[b,p,c] * lrelu'(x0[b,p,c]) */
 int dge_fromrgb_dgrad(const void* gx, const void* x0, const float* w, float* gimg, int B, int HW, int C, int dtype, dge_stream_t stream);
