@@ -46,6 +46,7 @@ static int env_int(const char* name, int dflt) { const char* e = getenv(name); r
 static void env_load() {
     g_env.force_stream = getenv("DGE_FORCE_STREAM") ? 1 : 0;
     g_env.no_stream = getenv("DGE_NO_STREAM") ? 1 : 0;
+    g_env.no_pw = getenv("DGE_NO_PW") ? 1 : 0;
     g_env.stream_nseg = env_int("DGE_STREAM_NSEG", 0);
     g_env.conv_dbg = env_int("DGE_CONV_DBG", 0);
     g_env.conv_bn = env_int("DGE_CONV_BN", 0);

@@ -232,6 +232,7 @@ __device__ __forceinline__ float2 sum_slot_pairs(const float* __restrict__ base,
 // path (~10 per conv launch, ~1300 launches per step); dge_env_reload() re-reads them (tests that toggle a switch mid-process).
 struct DgeEnv {
     int force_stream, no_stream, stream_nseg;            // DGE_FORCE_STREAM, DGE_NO_STREAM, DGE_STREAM_NSEG (0 = default)
+    int no_pw;                                           // DGE_NO_PW: 1x1 launches stay on conv_igemm
     int conv_dbg, conv_bn, conv_kc, conv_small, conv_nok4, conv_nok2;   // DGE_CONV_* (bn / kc 0 = default, small -1 = default)
     int torgb_thread, wgrad_th8, wgrad_groups, up_dbg;   // DGE_TORGB_THREAD, DGE_WGRAD_TH8, DGE_WGRAD_GROUPS (0 = default), DGE_UP_DBG
 };

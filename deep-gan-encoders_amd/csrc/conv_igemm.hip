@@ -15,6 +15,7 @@ int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s) {
         return dge_conv_small_launch(p, s);
     }
     if (dge_conv_stream_eligible(p, dtype, ksize)) return dge_conv_stream_launch(p, s);     // HBM-bound layers: conv_stream.hip
+    if (dge_conv_pw_eligible(p, dtype, ksize)) return dge_conv_pw_launch(p, s);             // narrow 1x1 layers: conv_pw.hip
     const int esize = dtype == DGE_BF16 ? 2 : 4;
     DGE_CHECK(ksize == 1 || ksize == 3, "conv: ksize %d unsupported", ksize);
     DGE_CHECK(p.Cin % (32 / esize) == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, 32 / esize);

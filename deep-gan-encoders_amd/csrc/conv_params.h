@@ -54,3 +54,6 @@ int dge_conv_stream_launch(const ConvParams& p, hipStream_t s);
 // conv_small.hip: the low-resolution 3x3 layers (whole-Cin halo tile resident in LDS, weights streamed straight into registers)
 bool dge_conv_small_shape_ok(int H, int W, int cin, int ntot, int ksize, int in_s2d, int in_up2, int dtype);
 int dge_conv_small_launch(const ConvParams& p, hipStream_t s);
+// conv_pw.hip: 1x1 convolution of the narrow high-resolution layers (encoder skip branch conv_3 and its data gradient), no LDS
+bool dge_conv_pw_eligible(const ConvParams& p, int dtype, int ksize);
+int dge_conv_pw_launch(const ConvParams& p, hipStream_t s);

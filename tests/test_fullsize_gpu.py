@@ -216,14 +216,25 @@ def test_encoder_conv_fullsize(cin, cout, R, B, stats, kernel):
 
 
 SKIP_CONVS = [
-    (16, 32, 512, 8, "conv_igemm<bf16,16,16,32,16,1,4,1>"),        # block 0 conv_3 (after the 2x2 average pool)
-    (32, 64, 256, 8, "conv_igemm<bf16,16,16,64,32,1,4,1>"),        # block 1 conv_3
-    (64, 128, 128, 8, "conv_igemm<bf16,16,16,128,32,1,2,2>"),      # block 2 conv_3
+    (16, 32, 512, 8, "conv_pw<bf16,16,32>"),        # block 0 conv_3 (after the 2x2 average pool): the LDS-free pointwise kernel
+    (32, 64, 256, 8, "conv_pw<bf16,32,64>"),        # block 1 conv_3
+    (64, 128, 128, 8, "conv_igemm<bf16,16,16,128,32,1,2,2>"),      # block 2 conv_3: back on the implicit-GEMM kernel
 ]
+
+
+def test_pointwise_kernel_ragged_shape(force_stream):
+    """csrc/conv_pw.hip on a shape whose pixel count is not a multiple of its 32-pixel groups (70 x 70, batch 3; below the
+    kernel's work threshold: DGE_FORCE_STREAM routes it there), every sample compared."""
+    _skip_conv_case(16, 32, 70, 3, "conv_pw<bf16,16,32>", samples=(0, 1, 2))
+    _skip_conv_case(64, 128, 34, 2, "conv_pw<bf16,64,128>", samples=(0, 1))
 
 
 @pytest.mark.parametrize("cin,cout,R,B,kernel", SKIP_CONVS)
 def test_encoder_skip_conv_fullsize(cin, cout, R, B, kernel):
+    _skip_conv_case(cin, cout, R, B, kernel)
+
+
+def _skip_conv_case(cin, cout, R, B, kernel, samples=None):
     """BEBlock.forward residual join (E.py:77-83): 1x1 conv + bias, 0.889 / 0.111 blend with the main branch in the epilogue,
     statistics of the blended result (post-addend) for the next block's instance norm."""
     from dge_amd import ops
@@ -237,7 +248,7 @@ def test_encoder_skip_conv_fullsize(cin, cout, R, B, kernel):
                    stats=st)
     assert _kernel() == kernel
     tot = st.buf.sum(0).cpu()
-    for b in SAMPLES(B):
+    for b in (samples if samples is not None else SAMPLES(B)):
         ref, rs, rq = CR.enc_skip_conv(_nchw(xp, b), w.cpu(), b3.cpu(), _nchw(x2, b))     # no prologue here: nothing to round
         assert _one_rounding(_nchw(y, b), ref) <= 0, b
         absum = ref.double().abs().sum((2, 3))[0]
@@ -253,7 +264,8 @@ DGRADS = [
     (64, 64, 512, 8, 3, True, "conv_stream<bf16,64,64,dot>"),         # generator layer14
     (64, 32, 512, 8, 3, False, "conv_stream<bf16,64,32,dot>"),        # encoder block 1 conv_2
     (128, 128, 256, 8, 3, True, "conv_igemm<bf16,16,16,128,32,3,2,2>"),    # generator layer12
-    (64, 32, 256, 8, 1, False, "conv_igemm<bf16,16,16,32,32,1,4,1>"),      # encoder block 1 conv_3 (1x1)
+    (64, 32, 256, 8, 1, False, "conv_pw<bf16,64,32>"),      # encoder block 1 conv_3 (1x1)
+    (32, 16, 512, 8, 1, False, "conv_pw<bf16,32,32>"),      # encoder block 0 conv_3 (1x1; N padded 16 -> 32)
     (512, 512, 16, 8, 3, True, "conv_small<bf16,8,8,64,512>"),             # generator layer4 (low-resolution kernel, dot statistics)
     (512, 512, 8, 8, 3, False, "conv_small<bf16,8,8,64,512>"),             # encoder block 7
     (512, 512, 4, 8, 3, True, "conv_small<bf16,8,8,64,512>"),              # generator layer0
