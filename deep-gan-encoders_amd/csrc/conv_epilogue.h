@@ -222,31 +222,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
                 }
             }
         }
-        if constexpr (PREP) if (prep && p.prep_stats) {
-            float* __restrict__ PST = p.prep_stats + (size_t)(vbid % p.stats_slots) * p.B * p.Cout * 2;
+        // Per-channel sums of the "post" side: after the butterflies every lane with the same chunk index holds the totals of its
+        // EP16 channels.  Lane (chq, e' = lane / CPR) keeps channel oc + e', so that ONE atomic instruction carries the 32
+        // channels of the tile (an instruction per channel with CPR active lanes is an L2 request each; at ~10 requests per ns on
+        // the whole device the 16 - 32 instructions per tile cost the data-gradient launches 25 - 100 us)
+        const int esel = (lane / CPR) % EP16;
+        auto lane_pick = [&](float (&v)[EP16]) {
+            float out = 0.f;
 #pragma unroll
             for (int e = 0; e < EP16; e++) {
 #pragma unroll
-                for (int msk = CPR; msk < 64; msk <<= 1) { pt0[e] += __shfl_xor(pt0[e], msk, 64); pt1[e] += __shfl_xor(pt1[e], msk, 64); }
-                if (lane < CPR && cvalid) {
-                    atomicAdd(PST + ((size_t)b * p.Cout + oc + e) * 2, pt0[e]);
-                    atomicAdd(PST + ((size_t)b * p.Cout + oc + e) * 2 + 1, pt1[e]);
-                }
+                for (int msk = CPR; msk < 64; msk <<= 1) v[e] += __shfl_xor(v[e], msk, 64);
+                if (esel == e) out = v[e];
+            }
+            return out;
+        };
+        if constexpr (PREP) if (prep && p.prep_stats) {
+            float* __restrict__ PST = p.prep_stats + (size_t)(vbid % p.stats_slots) * p.B * p.Cout * 2;
+            const float t0 = lane_pick(pt0), t1 = lane_pick(pt1);
+            if (lane < CPR * EP16 && cvalid) {
+                atomicAdd(PST + ((size_t)b * p.Cout + oc + esel) * 2, t0);
+                atomicAdd(PST + ((size_t)b * p.Cout + oc + esel) * 2 + 1, t1);
             }
         }
         if (post_stats) {          // lanes with equal chq hold partial sums of the same channels
+            if (det) {
 #pragma unroll
-            for (int e = 0; e < EP16; e++) {
+                for (int e = 0; e < EP16; e++) {
 #pragma unroll
-                for (int msk = CPR; msk < 64; msk <<= 1) { ps0[e] += __shfl_xor(ps0[e], msk, 64); ps1[e] += __shfl_xor(ps1[e], msk, 64); }
-                if (lane < CPR && cvalid) {
-                    if (det) {
+                    for (int msk = CPR; msk < 64; msk <<= 1) { ps0[e] += __shfl_xor(ps0[e], msk, 64); ps1[e] += __shfl_xor(ps1[e], msk, 64); }
+                    if (lane < CPR && cvalid) {
                         const int ee = (wn * C::WTN + j * 32 + chq * EP16 + e) * 2;
                         det_vec[ee] = ps0[e]; det_vec[ee + 1] = ps1[e];
-                    } else {
-                        atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2, ps0[e]);
-                        atomicAdd(STATS + ((size_t)b * p.Cout + oc + e) * 2 + 1, ps1[e]);
                     }
+                }
+            } else {
+                const float t0 = lane_pick(ps0), t1 = lane_pick(ps1);
+                if (lane < CPR * EP16 && cvalid) {
+                    atomicAdd(STATS + ((size_t)b * p.Cout + oc + esel) * 2, t0);
+                    atomicAdd(STATS + ((size_t)b * p.Cout + oc + esel) * 2 + 1, t1);
                 }
             }
         }
