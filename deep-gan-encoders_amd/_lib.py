@@ -137,6 +137,7 @@ SIGNATURES = {
     "dge_loss_reduce3": [_P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     "dge_crop_pool_multi": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dge_space_loss_bwd3": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P],
+    "dge_in_bwd_fromrgb": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dge_in_bwd_fused": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dge_sum_slots_planar_multi": [C.POINTER(SumPlanarEntry), _I, _P],
     "dge_heads_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],

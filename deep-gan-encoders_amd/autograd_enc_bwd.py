@@ -35,7 +35,7 @@ def encoder_backward(E, saved, g_w):
     L = E.layer_count
     B = g_w.shape[0]
     grads = {}
-    g_out = None
+    g_out = fr = None
     later = ops.DeferredSums()          # per-channel parameter-gradient reductions: one grouped launch (two with the DDP hook)
     post = []                           # what reads a deferred sum runs after the flush
 
@@ -119,7 +119,12 @@ def encoder_backward(E, saved, g_w):
         dots1 = ops.SlotStats(B, Cc, dev)
         g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
         coef1 = (dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
-        g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
+        if j == 0 and Cc <= 512:
+            # x is the FromRGB output: its gradient has one reader, the FromRGB parameter gradients - reduced in the same launch
+            fr = ops.in_bwd_fromrgb(g_y1, x, coef1, saved["img"].float(), extra=extra, extra_pool=extra_pool, extra_scale=extra_scale,
+                                    defer=later)
+        else:
+            g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
         if j == L // 2:
             # data-parallel runs: the gradients of blocks L-1 .. L/2 (the 512-channel blocks: > 90 % of the parameter bytes) are
             # complete here, while the high-resolution blocks still to come take most of the backward's time
@@ -127,7 +132,8 @@ def encoder_backward(E, saved, g_w):
             if hook is not None:
                 flush_sums()
                 hook(dict(grads))
-    fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float(), planar=True, defer=later)
+    if fr is None:
+        fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float(), planar=True, defer=later)
     flush_sums()
     C0 = E.startf
     grads["FromRGB.from_rgb.weight"] = fr[:3].t().reshape(C0, 3, 1, 1)

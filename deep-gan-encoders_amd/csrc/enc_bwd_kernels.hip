@@ -455,19 +455,23 @@ __global__ void in_bwd_coef_kernel(const float* __restrict__ dots, const float* 
 // g_pre = g_X * lrelu'(X) with the bias / noise-weight reductions as in act_bwd_kernel.
 // Sources of the coefficients when in_bwd computes them itself (dge_in_bwd_fused: no in_bwd_coef launch in front of it)
 struct InCoefSrc { const float* dots; const float* gms; const float* musig; const float* sc; const float* sh; int nslot, B; float inv_n; };
-template <typename T>
+// FR (the last launch of the encoder backward: X is the FromRGB output x0 = lrelu(W img + b), net.py:231-240): the result g_x0 is
+// not stored - its only reader was dge_fromrgb_bwd, which read x0 a second time - but reduced in place: g_pre = g_x0*lrelu'(x0),
+// fr_out[b][c][0..2] += sum g_pre*img[k], fr_out[b][c][3] += sum g_pre.
+template <typename T, bool FR>
 __global__ __launch_bounds__(256) void in_bwd_kernel(const T* __restrict__ gy, const T* __restrict__ X, const float* __restrict__ coef,
                                                       const T* __restrict__ extra, const float* __restrict__ noise,
                                                       T* __restrict__ gout, float* __restrict__ red_out, int H, int W, int C,
-                                                      int extra_pool, float extra_scale, int act, InCoefSrc cs) {
+                                                      int extra_pool, float extra_scale, int act, InCoefSrc cs,
+                                                      const float* __restrict__ img, float* __restrict__ fr_out) {
     constexpr int EP = Elem<T>::PER16;
-    __shared__ float red[256 * 2 * EP];
+    __shared__ float red[256 * (FR ? 4 : 2) * EP];
     __shared__ float lcoef[3 * 512];                    // fused form (C <= 512): this sample's coefficients, computed by the workgroup
     const int b = blockIdx.y;
     const int cpt = C / EP, ppi = 256 / cpt;
     const int chunk = threadIdx.x % cpt, slot = threadIdx.x / cpt;
     const int HW = H * W, UW = extra_pool ? W / 2 : W, UHW = extra_pool ? HW / 4 : HW;
-    float s[2][EP], A[EP], Bc[EP], Cc[EP];
+    float s[FR ? 4 : 2][EP], A[EP], Bc[EP], Cc[EP];
     if (!coef) {
         // the math of in_bwd_coef_kernel for the C channels of sample b (every workgroup of the sample repeats it: C <= 512 channels,
         // one thread each, slot copies summed with 8 loads in flight - cheaper than a launch of its own in front of this one)
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(256) void in_bwd_kernel(const T* __restrict__ gy, c
 #pragma unroll
     for (int e = 0; e < EP; e++) {
         s[0][e] = s[1][e] = 0.f;
+        if constexpr (FR) s[2][e] = s[3][e] = 0.f;
         if (coef) {
             const size_t ci = ((size_t)b * C + chunk * EP + e) * 3;
             A[e] = coef[ci]; Bc[e] = coef[ci + 1]; Cc[e] = coef[ci + 2];
@@ -512,6 +517,12 @@ __global__ __launch_bounds__(256) void in_bwd_kernel(const T* __restrict__ gy, c
         }
         float nzA = 0.f, nzB = 0.f;
         if (act && noise) { if (okA) nzA = noise[(size_t)b * HW + pA]; if (okB) nzB = noise[(size_t)b * HW + pB]; }
+        float imA[3] = {0.f, 0.f, 0.f}, imB[3] = {0.f, 0.f, 0.f};
+        if constexpr (FR) {
+            const float* ib = img + (size_t)b * 3 * HW;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { if (okA) imA[k] = ib[(size_t)k * HW + pA]; if (okB) imB[k] = ib[(size_t)k * HW + pB]; }
+        }
 #pragma unroll
         for (int h2 = 0; h2 < 2; h2++) {
             if (!(h2 ? okB : okA)) continue;
@@ -534,10 +545,20 @@ __global__ __launch_bounds__(256) void in_bwd_kernel(const T* __restrict__ gy, c
                     s[0][e] += g[e]; s[1][e] += g[e] * nz;
                 }
             }
-            *(uint4*)(gout + (h2 ? oB : oA)) = pack16(g, (T*)nullptr);
+            if constexpr (FR) {
+                const float* im = h2 ? imB : imA;
+#pragma unroll
+                for (int e = 0; e < EP; e++) {
+                    const float gp = g[e] * (xv[e] > 0.f ? 1.f : 0.2f);
+                    s[0][e] += gp * im[0]; s[1][e] += gp * im[1]; s[2][e] += gp * im[2]; s[3][e] += gp;
+                }
+            } else {
+                *(uint4*)(gout + (h2 ? oB : oA)) = pack16(g, (T*)nullptr);
+            }
         }
     }
-    if (red_out) block_chan_flush<EP, 2>(s, cpt, ppi, red_out + (size_t)b * C * 2, C, red);       // per-sample partial sums
+    if constexpr (FR) block_chan_flush<EP, 4>(s, cpt, ppi, fr_out + (size_t)b * C * 4, C, red);
+    else if (red_out) block_chan_flush<EP, 2>(s, cpt, ppi, red_out + (size_t)b * C * 2, C, red);       // per-sample partial sums
 }
 
 // per-channel sum over batch and pixels of an NHWC tensor: out[c] += scale * sum x[b,p,c]
@@ -832,12 +853,15 @@ extern "C" int dge_in_bwd_coef(const float* dots, const float* gms, const float*
 }
 
 static int in_bwd_launch(const void* gy, const void* x, const float* coef, const InCoefSrc& cs, const void* extra, const float* noise, void* gout,
-                         float* red, int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, hipStream_t s) {
+                         float* red, int B, int H, int W, int C, int extra_pool, float extra_scale, int act, int dtype, hipStream_t s,
+                         const float* img = nullptr, float* fr_out = nullptr) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(CHAN_OK(C, ep), "in_bwd: unsupported channel count %d", C);
     dim3 grid(dge_stream_grid(H * W, 256 / (C / ep), B), B);
-    if (dtype == DGE_BF16) hipLaunchKernelGGL(in_bwd_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)gy, (const bf16_t*)x, coef, (const bf16_t*)extra, noise, (bf16_t*)gout, red, H, W, C, extra_pool, extra_scale, act, cs);
-    else hipLaunchKernelGGL(in_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)gy, (const float*)x, coef, (const float*)extra, noise, (float*)gout, red, H, W, C, extra_pool, extra_scale, act, cs);
+#define DGE_IB(T, FR) hipLaunchKernelGGL((in_bwd_kernel<T, FR>), grid, dim3(256), 0, s, (const T*)gy, (const T*)x, coef, (const T*)extra, noise, (T*)gout, red, H, W, C, extra_pool, extra_scale, act, cs, img, fr_out)
+    if (img) { if (dtype == DGE_BF16) DGE_IB(bf16_t, true); else DGE_IB(float, true); }
+    else { if (dtype == DGE_BF16) DGE_IB(bf16_t, false); else DGE_IB(float, false); }
+#undef DGE_IB
     DGE_LAUNCH_CHECK("in_bwd");
     return 0;
 }
@@ -853,6 +877,15 @@ extern "C" int dge_in_bwd_fused(const void* gy, const void* x, const float* dots
     DGE_CHECK(C <= 512 && nslot >= 1 && musig && sc && sh && npix > 0, "in_bwd_fused: needs C <= 512, musig, sc, sh");
     InCoefSrc cs{dots, gms, musig, sc, sh, nslot, B, 1.0f / (float)npix};
     return in_bwd_launch(gy, x, nullptr, cs, extra, noise, gout, red, B, H, W, C, extra_pool, extra_scale, act, dtype, s);
+}
+
+// dge_in_bwd_fused (act = 0) + dge_fromrgb_bwd in one launch: x is the FromRGB output x0, the gradient w.r.t. x0 is reduced, not stored
+extern "C" int dge_in_bwd_fromrgb(const void* gy, const void* x0, const float* dots, int nslot, const float* gms, const float* musig,
+                                  const float* sc, const float* sh, int npix, const void* extra, const float* img, float* out4,
+                                  int B, int H, int W, int C, int extra_pool, float extra_scale, int dtype, hipStream_t s) {
+    DGE_CHECK(C <= 512 && nslot >= 1 && musig && sc && sh && npix > 0 && img && out4, "in_bwd_fromrgb: needs C <= 512, musig, sc, sh, img, out4");
+    InCoefSrc cs{dots, gms, musig, sc, sh, nslot, B, 1.0f / (float)npix};
+    return in_bwd_launch(gy, x0, nullptr, cs, extra, nullptr, nullptr, nullptr, B, H, W, C, extra_pool, extra_scale, 0, dtype, s, img, out4);
 }
 
 extern "C" int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, int dtype, hipStream_t s) {

@@ -659,6 +659,22 @@ def in_bwd(gy, x, coef, extra=None, extra_pool=False, extra_scale=1.0, noise=Non
     return gout
 
 
+def in_bwd_fromrgb(gy, x0, coef, img, extra=None, extra_pool=False, extra_scale=1.0, defer=None):
+    """Last step of the encoder backward: in_bwd (coefficients computed in the launch, `coef` = (dots, gms, musig, sc, sh, npix))
+    on the FromRGB output x0 with the FromRGB parameter gradients reduced from the result in registers -> [4, C] (planar: weight
+    gradient rows 0..2, bias gradient row 3).  The gradient w.r.t. x0 is never stored."""
+    B, H, W, Cc = x0.shape
+    dots, gms, musig, sc, sh, npix = coef
+    nslot = 1
+    if isinstance(dots, SlotStats):
+        nslot, dots = dots.nslot, dots.buf
+    part = zeros((B, Cc, 4), x0.device)
+    check(lib().dge_in_bwd_fromrgb(_p(gy), _p(x0), _f32(dots), nslot, _f32(gms), _f32(musig), _f32(sc), _f32(sh), int(npix), _p(extra),
+                                   _f32(img.contiguous()), _p(part), B, H, W, Cc, 1 if extra_pool else 0, float(extra_scale),
+                                   dtype_of(x0), _stream()), "dge_in_bwd_fromrgb")
+    return _sum_planar(part, torch.empty((4, Cc), dtype=torch.float32, device=x0.device), defer)
+
+
 def chan_sum(x, scale=1.0):
     B, H, W, Cc = x.shape
     part = zeros((B, Cc), x.device)

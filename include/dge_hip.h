@@ -315,6 +315,11 @@ int dge_chan_sum(const void* x, float* out, int B, int HW, int C, float scale, i
  * per-sample partial sums [B,C,4], pre-zeroed, summed over b by the caller */
 int dge_fromrgb_bwd(const void* gx, const void* x0, const float* img, float* out4, int B, int HW, int C, int dtype,
                     dge_stream_t stream);
+/* dge_in_bwd_fused (act = 0) followed by dge_fromrgb_bwd as ONE launch - the last step of the encoder backward (E.py:124 FromRGB,
+ * net.py:231-240): x0 is the FromRGB output, the gradient w.r.t. x0 is reduced into out4 [B,C,4] (pre-zeroed) and never stored */
+int dge_in_bwd_fromrgb(const void* gy, const void* x0, const float* dots, int nslot, const float* gms, const float* musig,
+                       const float* sc, const float* sh, int npix, const void* extra, const float* img, float* out4,
+                       int B, int H, int W, int C, int extra_pool, float extra_scale, int dtype, dge_stream_t stream);
 /* Forward of every inver_mod head of the encoder in one launch (E.py:51-53,64-66): w[b, gcol_l + o] = musig_l[b,:] . W_l[o,:] + bias_l[o]
  * over the same entry table as dge_heads_bwd (entries carry the bias pointer); w [B, ldw]. */
 int dge_heads_fwd(const void* dev_entries, int n, const float* musig_all, float* w, int ldw, int B, int O, dge_stream_t stream);

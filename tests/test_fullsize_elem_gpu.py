@@ -169,6 +169,44 @@ def test_instance_norm_backward_fullsize(C, R, B, mode):
         assert _red_err(red, tot, absum) < 1e-4
 
 
+@pytest.mark.parametrize("C,R,B", [(16, 1024, 8), (16, 70, 3)])
+def test_last_instance_norm_backward_with_fromrgb_gradients_fullsize(C, R, B):
+    """The last launch of the encoder backward (dge_in_bwd_fromrgb): block 0's instance-norm backward with the pooled
+    residual-branch gradient, its result g_x0 reduced in registers to the FromRGB parameter gradients (net.py:231-240) instead of
+    being stored.  Oracle: enc_in_bwd (f64) -> fromrgb_bwd on the UNROUNDED g_x0 (the two-launch path rounded it to bf16)."""
+    from dge_amd import ops
+    import torch.nn.functional as F
+    g = _gen(700 + R)
+    img = torch.randn(B, 3, R, R, device=DEV, generator=g)
+    w = torch.randn(C, 3, 1, 1, device=DEV, generator=g)
+    bias = 0.2 * torch.randn(C, device=DEV, generator=g)
+    st = torch.zeros(B, C, 2, device=DEV)
+    x0 = ops.fromrgb(img, w, bias, ops.BF16, st)
+    gy = _act(B, R, R, C, g)
+    gms = torch.randn(B, 2 * C, device=DEV, generator=g)
+    extra = _act(B, R // 2, R // 2, C, g)
+    musig, sc, sh = ops.stats_finalize(st, R * R)
+    gd, Xd = gy.double(), x0.double()
+    dots = torch.stack([(gd * Xd).sum((1, 2)), gd.sum((1, 2))], dim=-1).float().contiguous()
+    del gd, Xd
+    out = ops.in_bwd_fromrgb(gy, x0, (dots, gms, musig, sc, sh, R * R), img, extra=extra, extra_pool=True, extra_scale=0.25)   # [4, C]
+    # the two-launch path it replaces, for reference: same sums up to the bf16 rounding of g_x0
+    two = ops.fromrgb_bwd(ops.in_bwd(gy, x0, (dots, gms, musig, sc, sh, R * R), extra=extra, extra_pool=True, extra_scale=0.25), x0, img,
+                          planar=True)
+    tot, absum = torch.zeros(4, C, dtype=torch.float64), torch.zeros(4, C, dtype=torch.float64)
+    for b in range(B):
+        ib = img[b:b + 1].cpu()
+        gx0, _, _ = ER.enc_in_bwd(_nchw(x0, b), _nchw(gy, b), gms[b, :C].cpu(), gms[b, C:].cpu(), extra=_nchw(extra, b), extra_scale=0.25,
+                                  noise=None, act=False)
+        gW, gb = ER.fromrgb_bwd(_nchw(x0, b), gx0, ib)
+        gp = gx0.double() * torch.where(_nchw(x0, b) > 0, 1.0, 0.2).double()
+        tot += torch.cat([gW.t(), gb[None]])
+        absum += torch.cat([torch.stack([(gp * ib.double()[:, k:k + 1]).abs().sum((0, 2, 3)) for k in range(3)]), gp.abs().sum((0, 2, 3))[None]])
+    # f32 coefficients out of f32 sums over up to 10^6 pixels (1e-6 relative) times |X|, then f32 accumulation: 1e-4 of sum |terms|
+    assert _red_err(out, tot, absum) < 1e-4
+    assert _red_err(two, tot, absum) < 2e-3           # (what the bf16 rounding of the stored gradient cost the old path)
+
+
 @pytest.mark.parametrize("C,R,B,form", [(16, 1024, 8, "pool"), (32, 512, 8, "pool"), (512, 32, 8, "res_stats"), (512, 4, 8, "in_blend")])
 def test_blend_fullsize(C, R, B, form):
     """avg_pool2d / residual blend / instance-norm apply (model/E/E.py:75-78,84) - dge_blend, with the fused (sum, sumsq)"""
