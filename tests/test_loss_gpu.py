@@ -59,11 +59,13 @@ def test_ssim_known_answers():
     assert abs((1 - float(info[6])) - float(g["ssim_40x24"])) < 1e-5
 
 
-def test_tsa_loss_and_gradient_vs_oracle():
-    """loss_imgs + 5*loss_medium + 9*loss_small at 1024 (pool x4) against the oracle's autograd."""
+@pytest.mark.parametrize("B,H,W", [(1, 1024, 1024), (2, 44, 30)])
+def test_tsa_loss_and_gradient_vs_oracle(B, H, W):
+    """loss_imgs + 5*loss_medium + 9*loss_small at 1024 (pool x4: the 16-byte forms of the three merged-window kernels) and on a
+    small image whose width is not a multiple of 4 (their scalar forms), against the oracle's autograd."""
     from dge_amd import losses
-    a = R.randn("tsa.a", (1, 3, 1024, 1024), 3, 0.4)
-    b = (a * 0.8 + R.randn("tsa.b", (1, 3, 1024, 1024), 3, 0.2)).requires_grad_(True)
+    a = R.randn("tsa.a", (B, 3, H, W), 3, 0.4)
+    b = (a * 0.8 + R.randn("tsa.b", (B, 3, H, W), 3, 0.2)).requires_grad_(True)
     zero_lp = lambda x, y: torch.zeros(x.shape[0], 1, 1, 1)
     tot = 0
     for wgt, (x1, x2) in zip((1, 5, 9), zip([a, *O.attention_crops(a)], [b, *O.attention_crops(b)])):
