@@ -103,7 +103,22 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(!d->prep || !dge_get_deterministic(), "conv2d: the fused tail backward (prep) is not offered in deterministic mode; run dge_modconv_bwd_prep");
     DGE_CHECK(d->w_layout == 0 || d->w_layout == 1, "conv2d: bad w_layout %d", d->w_layout);
     p.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
+    p.rgb_w = d->rgb_out ? d->rgb_w : nullptr; p.rgb_style = d->rgb_style; p.rgb_bias = d->rgb_bias; p.rgb_out = d->rgb_out;
+    p.rgb_wscale = d->rgb_wscale; p.rgb_skip_y = (d->rgb_out && d->rgb_skip_y) ? 1 : 0;
+    if (d->rgb_out) {
+        DGE_CHECK(d->rgb_w && d->rgb_style && d->rgb_bias, "conv2d: rgb_out needs rgb_w, rgb_style, rgb_bias");
+        DGE_CHECK(dge_conv_rgb_ok(p, d->dtype, d->ksize), "conv2d: the fused toRGB is offered where dge_conv_rgb_supported() says so "
+                  "(bf16 3x3 32 -> 32 launches of the streaming kernel)");
+    }
     return dge_conv_launch(p, d->dtype, d->ksize, s);
+}
+
+// 1 when a plain generator-flavour launch (style scale, demodulation, shared noise plane, bias, activation) of this shape may carry
+// the fused toRGB epilogue (dge_conv_desc.rgb_*)
+extern "C" int dge_conv_rgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    ConvParams p = {};
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ntot_valid = Cout; p.Ntot = dge_packed_n(Cout);
+    return dge_conv_rgb_ok(p, dtype, ksize) ? 1 : 0;
 }
 
 // out[i] (+)= sum_s partial[s][i]   (combines the spread statistics copies of dge_conv2d)

@@ -43,6 +43,14 @@ struct ConvParams {
     float* prep_stats;        // [slots][B,Cout,2], pre-zeroed (same slot count as `stats`)
     int mask_relu;            // 1: result *= [dot_src > 0] (ReLU backward of the layer below), no dot statistics
     int in_t2d;               // 1: x is [B,H+1,W+1,Cin] (dge_fir_t2d); only the taps (dy,dx) in {1,2}^2 are computed
+    // toRGB of the result fused into the epilogue (conv_stream only; stylegan2_generator.py:515-522, :465-474): rgb_out[b][k][y][x] =
+    // rgb_bias[k] + sum_c rgb_w[k][c] * rgb_wscale * rgb_style[b][c] * y[b][y][x][c]  (the bf16-stored y, f32 weights as hi + lo bf16)
+    const float* rgb_w;       // [3][Cout] or null
+    const float* rgb_style;   // [B][Cout]
+    const float* rgb_bias;    // [3]
+    float* rgb_out;           // [B][3][H][W] f32
+    float rgb_wscale;
+    int rgb_skip_y;           // 1: y is not stored (its only reader was the toRGB)
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);
@@ -51,6 +59,7 @@ extern "C" int dge_conv_ntile(int ntot);
 // conv_stream.hip: the streaming kernel for the HBM-bound small-channel 3x3 layers
 bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize);
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s);
+bool dge_conv_rgb_ok(const ConvParams& p, int dtype, int ksize);
 // conv_small.hip: the low-resolution 3x3 layers (whole-Cin halo tile resident in LDS, weights streamed straight into registers)
 bool dge_conv_small_shape_ok(int H, int W, int cin, int ntot, int ksize, int in_s2d, int in_up2, int dtype);
 int dge_conv_small_launch(const ConvParams& p, hipStream_t s);

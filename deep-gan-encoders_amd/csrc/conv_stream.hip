@@ -107,7 +107,8 @@ template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigne
                      "buffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds" : : "v"(voff), "s"(m0v), "s"(rs), "v"(voff1) : "memory");
 }
 
-enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4 };
+enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5 };
+// FL_GEN_RGB:   FL_GEN + the toRGB of the result (ConvParams::rgb_*): two more MFMAs per row on the packed output registers
 // FL_GEN:       uniform noise weight (or none), no input shift, no statistics            (generator forward, LPIPS convs)
 // FL_ENC:       per-channel noise weight, folded instance-norm shift with border terms    (encoder forward) - superset of GEN
 // FL_ENC_STATS: + (sum, sum of squares) of the output per (sample, channel)
@@ -127,7 +128,8 @@ struct SC {
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
-    static constexpr bool PREP = FL == FL_DOT_PREP;
+    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB;
+    static_assert(!RGB || (COUT == 32 && TEAM == 1), "fused toRGB: one wave holds all 32 output channels of its pixels");
     static constexpr bool DOT = FL == FL_DOT || PREP, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS;
     static constexpr bool NOISE = !DOT || PREP;
 #ifndef DGE_SC_NR
@@ -161,7 +163,7 @@ struct SC {
     static constexpr int TBYTES = 32 * MTW * 16 * 4;
     static constexpr int DUMMY_OFF = T_OFF + TEAM * TBYTES;
     static constexpr int LDS_BYTES = DUMMY_OFF + (TEAM == 2 ? 1024 : 0);
-    static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + (PREP ? 16 : 0) + 36;
+    static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + (PREP ? 16 : 0) + (RGB ? 11 : 0) + 36;
     // (the 64-channel prep flavour holds 144 weight + 48 sum registers: at two waves per SIMD it spilled 360 B per lane)
     static constexpr int WPE = (PREP && CIN == 64) ? 1 : (NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2));
     static_assert(D <= NR - 3, "the slot of the row being fetched must be dead");
@@ -351,6 +353,30 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
         }
     const float nw_uniform = (!C::ENC && C::NOISE && p.noise) ? p.noise_w[0] * p.gain : 0.f;
     const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
+
+    // ---- fused toRGB: the packed bf16 output registers of a lane ARE the B operand of a K = 32 product over the output channels
+    //      (same permutation as the input fragments).  A rows 0..2 = bf16 hi part of the modulated f32 toRGB weights, rows 8..10 =
+    //      their lo part (hi + lo carries 16 mantissa bits): lane (pixel, kh = 0) finds row k in register k, row 8 + k in 4 + k.
+    uint4 rgbA[C::RGB ? 2 : 1];
+    float rgbb[3] = {0.f, 0.f, 0.f};
+    if constexpr (C::RGB) {
+        const int row = n31 & 7, part = n31 >> 3;                       // part 0: hi, 1: lo
+        const bool live = row < 3 && part < 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int c = 16 * ks + 8 * kh + e;
+                const float wv = live ? p.rgb_w[row * COUT + c] * p.rgb_wscale * p.rgb_style[b * COUT + c] : 0.f;
+                const float hi = __uint_as_float(__float_as_uint(wv) & 0xffff0000u);      // (truncated hi: the lo part takes the rest)
+                f[e] = part == 0 ? hi : wv - hi;
+            }
+            rgbA[ks] = pack16(f, (bf16_t*)nullptr);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) rgbb[k] = p.rgb_bias[k];
+    }
 
     // ---- B-fragment lane offsets: halo pixel n31 + dx, chunk (ks*2 + kh) ^ swizzle
     unsigned loff[3][C::KS];
@@ -546,6 +572,16 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             uint4 o0 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             uint4 o1 = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
             unsigned char* dst = yrow + yoff + mt * 64;
+            if constexpr (C::RGB) {
+                f32x16_t t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&rgbA[0], *(const bf16x8_t*)&o0, zero16, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&rgbA[1], *(const bf16x8_t*)&o1, t, 0, 0, 0);
+                if (kh == 0 && pv) {
+                    float* __restrict__ ro = p.rgb_out + ((size_t)b * 3 * p.H + gy) * p.W + gx;
+                    const size_t plane = (size_t)p.H * p.W;
+                    ro[0] = t[0] + t[4] + rgbb[0]; ro[plane] = t[1] + t[5] + rgbb[1]; ro[2 * plane] = t[2] + t[6] + rgbb[2];
+                }
+                if (p.rgb_skip_y) continue;
+            }
 #ifdef DGE_SC_NOSTORE
             if (o0.x != 0x12345u || o1.y != 0x54321u) continue;
 #endif
@@ -669,7 +705,7 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     const int njobs = p.B * nstrips * nseg;
     const int nwg = (njobs + C::TPW - 1) / C::TPW;
     const int jobs_per_xcd = (nwg + 7) / 8;                        // workgroups per XCD
-    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : "dot_prep")));
+    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : "gen_rgb"))));
     dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
     hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM * C::TPW), C::LDS_BYTES * C::TPW, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
@@ -686,6 +722,11 @@ int launch_flavour(const ConvParams& p, hipStream_t s) {
         return launch_stream<CIN, COUT, FL_DOT>(p, s);
     }
     const bool enc = p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0);
+    if (p.rgb_out) {
+        if constexpr (CIN == 32 && COUT == 32) { if (!enc) return launch_stream<CIN, COUT, FL_GEN_RGB>(p, s); }
+        dge_set_error("conv_stream: the fused toRGB is built for the generator flavour of 32 -> 32 only");
+        return -1;
+    }
     if constexpr (CIN == 64) {       // the encoder flavours of the 64-channel input do not fit the register file next to 144 weight registers
         if (enc) { dge_set_error("conv_stream: encoder flavour with Cin = 64 is not built"); return -1; }
     } else {
@@ -720,6 +761,12 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     if (p.noise && p.noise_w == nullptr) return false;
     if (dge_env().no_stream) return false;
     return true;
+}
+
+// The fused toRGB epilogue (ConvParams::rgb_*) exists in the streaming kernel only, for the 32 -> 32 generator flavour
+bool dge_conv_rgb_ok(const ConvParams& p, int dtype, int ksize) {
+    return p.Cin == 32 && p.Cout == 32 && !p.dot_src && !p.stats && !p.in_shift && !(p.noise && p.noise_w_stride != 0) &&
+           dge_conv_stream_eligible(p, dtype, ksize);
 }
 
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s) {

@@ -601,6 +601,38 @@ extern "C" int dge_torgb(const void* x, const float* wrgb, const float* style, c
     return 0;
 }
 
+// img += up2(prev): four consecutive output pixels of a row per thread (they read prev columns x/2-1 .. x/2+2 of two prev rows)
+__global__ __launch_bounds__(256) void rgb_upsample_add_kernel(float* __restrict__ img, const float* __restrict__ prev, int H, int W) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x >= W) return;
+    const int y = blockIdx.y, bc = blockIdx.z;
+    const int h2 = H >> 1, w2 = W >> 1;
+    const float* pp = prev + (size_t)bc * h2 * w2;
+    const int my = y >> 1, mx = x >> 1;
+    const int ya = (y & 1) ? my : my - 1, yb = ya + 1;
+    const float wya = (y & 1) ? 0.75f : 0.25f, wyb = 1.f - wya;
+    float v[4];                       // vertical blend of prev columns mx-1 .. mx+2
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int xq = mx - 1 + j;
+        const bool xin = xq >= 0 && xq < w2;
+        const float pa = (xin && ya >= 0) ? pp[(size_t)ya * w2 + xq] : 0.f, pb = (xin && yb < h2) ? pp[(size_t)yb * w2 + xq] : 0.f;
+        v[j] = wya * pa + wyb * pb;
+    }
+    float4* ip = (float4*)(img + ((size_t)bc * H + y) * W + x);
+    float4 o = *ip;
+    // even output x: .25*p[m-1] + .75*p[m];  odd: .75*p[m] + .25*p[m+1]
+    o.x += 0.25f * v[0] + 0.75f * v[1]; o.y += 0.75f * v[1] + 0.25f * v[2];
+    o.z += 0.25f * v[1] + 0.75f * v[2]; o.w += 0.75f * v[2] + 0.25f * v[3];
+    *ip = o;
+}
+extern "C" int dge_rgb_upsample_add(float* img, const float* prev, int BC, int H, int W, hipStream_t s) {
+    DGE_CHECK(img && prev && BC > 0 && H > 0 && W % 4 == 0 && H % 2 == 0 && H <= 65535 && BC <= 65535, "rgb_upsample_add: needs W %% 4 == 0, even H");
+    hipLaunchKernelGGL(rgb_upsample_add_kernel, dim3((W / 4 + 255) / 256, H, BC), dim3(256), 0, s, img, prev, H, W);
+    DGE_LAUNCH_CHECK("rgb_upsample_add");
+    return 0;
+}
+
 extern "C" int dge_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int src_B, int dtype, hipStream_t s) {
     const long n = (long)B * C * HW;
     if (dtype == DGE_BF16)

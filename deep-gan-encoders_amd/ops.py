@@ -306,11 +306,14 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None, in_t2d=False):
+           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None, in_t2d=False, rgb=None):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout].
     `prep`: dict(gain, noise [1|B,OH,OW] or None, ns (device scalar) or None, stats=SlotStats(B, cout)) - the fused tail backward of
     the layer that produced `dot_src` (dge_conv_desc.prep): y is then g_z and prep['stats'] receives (sum g_z*(z - ns*noise), sum g_z).
-    `relu_mask`: stored activation a = relu(pre) of the layer below: the result is multiplied by [a > 0] (dge_conv_desc.mask_relu)."""
+    `relu_mask`: stored activation a = relu(pre) of the layer below: the result is multiplied by [a > 0] (dge_conv_desc.mask_relu).
+    `rgb`: dict(w [3,cout] f32, style [B,cout], bias [3], wscale, out [B,3,H,W] f32, skip_y=False) - the toRGB of the result written
+    by the same launch (dge_conv_desc.rgb_*, where conv_rgb_supported() says so); with skip_y the activation itself is not stored
+    and None is returned."""
     B, H, W, Cin = x.shape
     if in_s2d:            # x is the fine grid [B,2H,2W,C]; logical input is [B,H,W,4C]
         H, W, Cin = H // 2, W // 2, Cin * 4
@@ -355,6 +358,9 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         d.prep_noise, d.prep_ns = _f32(pn), _f32(prep.get("ns") if pn is not None else None)
         d.prep_noise_batch = 1 if pn is None else pn.shape[0]
         d.prep_stats = _f32(prep["stats"].alloc(nslot))
+    if rgb is not None:
+        d.rgb_w, d.rgb_style, d.rgb_bias, d.rgb_out = _f32(rgb["w"]), _f32(rgb["style"]), _f32(rgb["bias"]), _f32(rgb["out"])
+        d.rgb_wscale, d.rgb_skip_y = float(rgb["wscale"]), 1 if rgb.get("skip_y") else 0
     d.noise_batch = 1 if noise is None else noise.shape[0]
     d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
     d.act, d.bias_scale, d.gain, d.add_scale, d.dtype = act, bias_scale, gain, add_scale, dt
@@ -380,6 +386,8 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")
     if partial is not None and not lazy:
         check(lib().dge_sum_slots(_p(partial), _p(stats), nslot, stats.numel(), 1, _stream()), "dge_sum_slots")
+    if rgb is not None and rgb.get("skip_y"):
+        return None
     return out
 
 
@@ -673,6 +681,17 @@ def in_bwd_fromrgb(gy, x0, coef, img, extra=None, extra_pool=False, extra_scale=
                                    _f32(img.contiguous()), _p(part), B, H, W, Cc, 1 if extra_pool else 0, float(extra_scale),
                                    dtype_of(x0), _stream()), "dge_in_bwd_fromrgb")
     return _sum_planar(part, torch.empty((4, Cc), dtype=torch.float32, device=x0.device), defer)
+
+
+def conv_rgb_supported(B, H, W, cin, cout, ksize, dtype):
+    return bool(lib().dge_conv_rgb_supported(B, H, W, cin, cout, ksize, dtype))
+
+
+def rgb_upsample_add(img, prev):
+    """img [B,3,H,W] += up2(prev [B,3,H/2,W/2]) in place (the skip connection of SynthesisModule.forward :517-522)"""
+    B, Cc, H, W = img.shape
+    check(lib().dge_rgb_upsample_add(_p(img), _f32(prev), B * Cc, H, W, _stream()), "dge_rgb_upsample_add")
+    return img
 
 
 def chan_sum(x, scale=1.0):

@@ -175,16 +175,18 @@ class ModulateConvBlock(nn.Module):
             self._cache["wu"] = c
         return c[1]
 
-    def conv(self, x, s, d, noise, dt):
-        """The modulated conv proper (:898-921) on NHWC activations: shared-weight form with s / d as prologue / epilogue scales."""
+    def conv(self, x, s, d, noise, dt, rgb=None):
+        """The modulated conv proper (:898-921) on NHWC activations: shared-weight form with s / d as prologue / epilogue scales.
+        `rgb`: fused toRGB of the result (ops.conv2d), stride-1 layers only."""
         nw = self.noise_strength.detach().reshape(1) if noise is not None else None
         wu = self._prepared_up(dt)
         if wu is not None:
+            assert rgb is None
             return ops.upconv_fir(x, wu, self.out_c, in_scale=s, out_scale=d, bias=self.bias, bias_scale=self.bscale,
                                   noise=noise, noise_w=nw, act=self.act, gain=self.gain)
         packed, _ = self._prepared(dt)
         return ops.conv2d(x, packed, self.out_c, 3, up=self.up, in_scale=s, out_scale=d, bias=self.bias,
-                          bias_scale=self.bscale, noise=noise, noise_w=nw, act=self.act, gain=self.gain)
+                          bias_scale=self.bscale, noise=noise, noise_w=nw, act=self.act, gain=self.gain, rgb=rgb)
 
     def styles(self, w):
         """style s[b,i] and demodulation d[b,o] for latent rows w [B, 512] (any row stride)."""

@@ -98,6 +98,16 @@ typedef struct dge_conv_desc {
      * [B,H+1,W+1,Cin] with Cin = 4*Cout_up, weights DGE_PACK_UPT2D_DGRAD; the launch computes y[m] = sum over the taps
      * (dy,dx) in {1,2}^2 of x[m + (dy-1,dx-1)] * W[tap] (4 of 9 taps: 16 tap-units per pixel against the 36 of in_s2d). */
     int in_t2d;               /* 0 / 1 */
+    /* toRGB of the result fused into the epilogue (SynthesisModule.forward :515-522, ModulateConvBlock k = 1 :465-474), offered where
+     * dge_conv_rgb_supported() says so: rgb_out[b][k][y][x] = rgb_bias[k] + sum_c rgb_w[k][c]*rgb_wscale*rgb_style[b][c] * y[b][y][x][c]
+     * (y as stored, i.e. rounded to dtype); the 2x-upsampled previous image is added by dge_rgb_upsample_add.  rgb_skip_y = 1: y
+     * itself is not stored (inference: the toRGB is its only reader). */
+    const float* rgb_w;       /* [3][Cout] f32 or NULL */
+    const float* rgb_style;   /* [B][Cout] */
+    const float* rgb_bias;    /* [3] */
+    float* rgb_out;           /* [B][3][H][W] f32, NULL = no fused toRGB */
+    float rgb_wscale;
+    int rgb_skip_y;
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
@@ -165,6 +175,11 @@ int dge_truncation(const float* w, const float* w_avg, float* wp, int B, int L, 
 int dge_torgb(const void* x, const float* wrgb, const float* style, const float* bias, const float* prev, float* img,
               int B, int H, int W, int cin, float wscale, int dtype, dge_stream_t stream);
 
+int dge_conv_rgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
+/* img[b][c][y][x] += up2(prev)[b][c][y][x]: the skip connection of SynthesisModule.forward :517-522 (UpsamplingLayer :603-615:
+ * zero-insert, pad (2,1), 4x4 FIR == per-axis taps {.25,.75} / {.75,.25}) for an image whose toRGB term is already in img
+ * (dge_conv_desc.rgb_out).  img [B,3,H,W] f32, prev [B,3,H/2,W/2] f32. */
+int dge_rgb_upsample_add(float* img, const float* prev, int BC, int H, int W, dge_stream_t stream);
 int dge_nchw_to_nhwc(const float* src, void* dst, int B, int C, int HW, int src_B, int dtype, dge_stream_t stream);
 int dge_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtype, dge_stream_t stream);
 

@@ -120,6 +120,58 @@ def test_generator_stride1_layer_fullsize(cin, cout, R, B, kernel):
         assert e < 6e-3, (b, e)            # measured 2.0e-3 .. 3.2e-3
 
 
+def _fused_torgb_case(R, W, B):
+    from dge_amd import ops
+    cin = cout = 32
+    g = _gen(1500 + R + W)
+    x = _act(B, R, W, cin, g)
+    w = _wgt(cout, cin, 3, g)
+    wscale = 1.0 / math.sqrt(9 * cin)
+    s = 1.0 + 0.3 * torch.randn(B, cin, device=DEV, generator=g)
+    d = 0.5 + torch.rand(B, cout, device=DEV, generator=g)
+    noise = torch.randn(1, R, W, device=DEV, generator=g)
+    ns = torch.tensor([0.37], device=DEV)
+    bias = 0.2 * torch.randn(cout, device=DEV, generator=g)
+    wrgb = torch.randn(3, cout, device=DEV, generator=g)
+    srgb = 1.0 + 0.3 * torch.randn(B, cout, device=DEV, generator=g)
+    brgb = 0.1 * torch.randn(3, device=DEV, generator=g)
+    prev = torch.randn(B, 3, R // 2, W // 2, device=DEV, generator=g)
+    rws = 1.0 / math.sqrt(cout)
+    assert ops.conv_rgb_supported(B, R, W, cin, cout, 3, ops.BF16)
+    wp = ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, wscale)
+    args = dict(in_scale=s, out_scale=d, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=math.sqrt(2.0))
+    y0 = ops.conv2d(x, wp, cout, 3, **args)
+    assert _kernel() == "conv_stream<bf16,32,32,gen>"
+    img1 = torch.full((B, 3, R, W), float("nan"), device=DEV)
+    y1 = ops.conv2d(x, wp, cout, 3, rgb=dict(w=wrgb, style=srgb, bias=brgb, wscale=rws, out=img1), **args)
+    assert _kernel() == "conv_stream<bf16,32,32,gen_rgb>"
+    assert torch.equal(y0, y1)                                   # the activation itself is the plain launch's, bit for bit
+    img2 = torch.full((B, 3, R, W), float("nan"), device=DEV)
+    assert ops.conv2d(x, wp, cout, 3, rgb=dict(w=wrgb, style=srgb, bias=brgb, wscale=rws, out=img2, skip_y=True), **args) is None
+    assert torch.equal(img1, img2)
+    for b in (range(B) if R < 256 else SAMPLES(B)):
+        # f64 toRGB of the STORED activation (stylegan2_generator.py:465-474, :515-516): the kernel multiplies bf16 activations by
+        # weights carried as hi + lo bf16 (2^-17 relative) and accumulates in f32
+        wm = (wrgb[:, :].double() * rws * srgb[b].double()[None, :]).cpu()
+        ref = torch.einsum("kc,hwc->khw", wm, y0[b].double().cpu()) + brgb.double().cpu()[:, None, None]
+        err = ((img1[b].double().cpu() - ref).abs().max() / ref.abs().max()).item()
+        assert err < 2e-5, (b, err)
+    # the skip connection added afterwards == the one-pass toRGB kernel with `prev`
+    want = ops.torgb(y0, wrgb, srgb, brgb, prev, rws)
+    got = ops.rgb_upsample_add(img1.clone(), prev)
+    assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
+
+
+def test_fused_torgb_of_the_last_layer_fullsize():
+    """Layer 16 of the 1024^2 generator with its toRGB in the conv epilogue (dge_conv_desc.rgb_*) and the skip image added by
+    dge_rgb_upsample_add (stylegan2_generator.py:515-522)."""
+    _fused_torgb_case(1024, 1024, 8)
+
+
+def test_fused_torgb_ragged_shape(force_stream):
+    _fused_torgb_case(136, 132, 2)
+
+
 UP_LAYERS = [
     (64, 32, 512, 8, "upconv_fir<bf16>"),                          # layer15 (-> 1024^2)
     (128, 64, 256, 8, "upconv_fir<bf16>"),                         # layer13
