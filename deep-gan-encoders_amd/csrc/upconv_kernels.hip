@@ -425,6 +425,12 @@ __global__ void upconv_pack_kernel(const float* __restrict__ w, T* __restrict__ 
     }
 }
 
+// upconv_stream.hip: the streaming form for the 64 -> 32 layer at the top of the generator
+bool dge_upconv_stream_ok(int B, int H, int W, int Cin, int Cout, int dtype);
+int dge_upconv_stream_launch(const void* x, const void* w_packed, void* y, const float* in_scale, const float* out_scale, const float* noise,
+                             int noise_bstride, const float* noise_w, const float* bias, float bias_scale, float gain, int act,
+                             int B, int H, int W, hipStream_t s);
+
 extern "C" int dge_upconv_supported(int Cin, int Cout, int dtype) {
     const int kc = dtype == DGE_BF16 ? 32 : 16;
     return (Cin % kc == 0 && Cout % 32 == 0) ? 1 : 0;
@@ -446,6 +452,8 @@ extern "C" int dge_upconv_fir(const void* x, const void* w_packed, void* y, cons
     DGE_CHECK(dge_upconv_supported(Cin, Cout, dtype), "upconv_fir: Cin=%d must be a multiple of the 64-byte K chunk and Cout=%d of 32", Cin, Cout);
     DGE_CHECK(gain > 0.f, "upconv_fir: the gain is folded into scale / noise / bias and must be positive");
     DGE_CHECK(!noise || noise_w, "upconv_fir: noise needs its weight");
+    if ((!noise || noise_w_stride == 0) && dge_upconv_stream_ok(B, H, W, Cin, Cout, dtype))
+        return dge_upconv_stream_launch(x, w_packed, y, in_scale, out_scale, noise, noise_bstride, noise_w, bias, bias_scale, gain, act, B, H, W, s);
     UpParams p;
     p.x = x; p.w = w_packed; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.noise = noise; p.noise_w = noise_w; p.bias = bias;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;

@@ -173,7 +173,7 @@ def test_fused_torgb_ragged_shape(force_stream):
 
 
 UP_LAYERS = [
-    (64, 32, 512, 8, "upconv_fir<bf16>"),                          # layer15 (-> 1024^2)
+    (64, 32, 512, 8, "upconv_stream<bf16,64,32>"),                 # layer15 (-> 1024^2): the streaming form (csrc/upconv_stream.hip)
     (128, 64, 256, 8, "upconv_fir<bf16>"),                         # layer13
     (512, 512, 32, 8, "upconv_fir<bf16>"),                         # layer7
     (512, 512, 16, 8, "upconv_fir<bf16>"),                         # layer5 (-> 32^2: smallest phase-form layer)
@@ -182,18 +182,28 @@ UP_LAYERS = [
 ]
 
 
+def test_streaming_up_layer_ragged_shape(force_stream):
+    """csrc/upconv_stream.hip on a shape that cuts its strips (60 output columns) and row segments unevenly, every sample compared."""
+    _up_layer_case(64, 32, 70, 2, "upconv_stream<bf16,64,32>", Win=66, samples=(0, 1))
+
+
 @pytest.mark.parametrize("cin,cout,Rin,B,kernel", UP_LAYERS)
 def test_generator_up_layer_fullsize(cin, cout, Rin, B, kernel):
+    _up_layer_case(cin, cout, Rin, B, kernel)
+
+
+def _up_layer_case(cin, cout, Rin, B, kernel, Win=None, samples=None):
     """ModulateConvBlock.forward, scale_factor 2 (:879-896 conv_transpose2d + FIR, :908-921), through the dispatch the
     generator itself uses (phase form when supported and the output resolution is >= 32, else the folded form)."""
     from dge_amd import ops
     g = _gen(2000 + cin + Rin)
-    x = _act(B, Rin, Rin, cin, g)
+    Win = Rin if Win is None else Win
+    x = _act(B, Rin, Win, cin, g)
     w = _wgt(cout, cin, 3, g)
     wscale = 1.0 / math.sqrt(9 * cin)
     s = 1.0 + 0.3 * torch.randn(B, cin, device=DEV, generator=g)
     d = 0.5 + torch.rand(B, cout, device=DEV, generator=g)
-    noise = torch.randn(1, 2 * Rin, 2 * Rin, device=DEV, generator=g)
+    noise = torch.randn(1, 2 * Rin, 2 * Win, device=DEV, generator=g)
     ns = torch.tensor([0.37], device=DEV)
     bias = 0.2 * torch.randn(cout, device=DEV, generator=g)
     args = dict(in_scale=s, out_scale=d, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=math.sqrt(2.0))
@@ -205,7 +215,7 @@ def test_generator_up_layer_fullsize(cin, cout, Rin, B, kernel):
     assert _kernel() == kernel
     # phase form: the packed units are w*wscale in bf16; folded form: K (x) W summed in f32, then rounded - both within the bound
     wq = CR.bf16_round(w.cpu() * wscale)
-    for b in SAMPLES(B):
+    for b in (samples if samples is not None else SAMPLES(B)):
         a = (_nchw(x, b), wq, s[b:b + 1].cpu(), d[b:b + 1].cpu(), noise.cpu(), 0.37, bias.cpu(), 1.0, 1.0)
         # one rounding + 4e-3 of the max: the phase form keeps the transposed-conv result t in LDS as bf16 for the FIR, the
         # folded form rounds the phase kernels FIR (x) W to bf16 as packed weights - one storage rounding more than the oracle
