@@ -289,7 +289,7 @@ def main():
             traffic, tsrc = tj["traffic_bytes_per_launch"], "offline PMC (tools/pmc_traffic.sh, separate rocprofv3 --pmc passes over this command), profiles/" + tname
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + upconv_fir_kernel (all conv launches of a step: dge_conv2d, dge_upconv_fir)",
+                           "kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + upconv_fir_kernel + upconv_stream_kernel (all conv launches of a step: dge_conv2d, dge_upconv_fir)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,
                            "algorithmic_bytes_per_launch": ab / max(nlaunch, 1),

@@ -380,7 +380,9 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         else:
             macs = float(ksize * ksize) * Cin * cout * H * W
         # algorithmic bytes: every operand tensor crosses HBM once (input, output, optional addend / dot_src, packed weights)
-        abytes = sum(t.numel() * t.element_size() for t in (x, out, addend, dot_src, w_packed) if t is not None)
+        skip_y = rgb is not None and rgb.get("skip_y")
+        abytes = sum(t.numel() * t.element_size() for t in (x, None if skip_y else out, addend, dot_src, w_packed,
+                                                            rgb["out"] if rgb is not None else None) if t is not None)
         PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, ksize, up, in_s2d), abytes))
     else:
         check(lib().dge_conv2d(C.byref(d), _stream()), "dge_conv2d")

@@ -20,7 +20,7 @@ mkdir -p $R/gpurun_out
 python - "$R" "$TAG" <<'PY'
 import csv, glob, json, sys, collections
 R, TAG = sys.argv[1], sys.argv[2]
-FAMILY = ("conv_igemm_kernel", "conv_stream_kernel", "conv_small_kernel", "upconv_fir_kernel")
+FAMILY = ("conv_igemm_kernel", "conv_stream_kernel", "conv_small_kernel", "conv_pw_kernel", "upconv_fir_kernel", "upconv_stream_kernel")
 tot = {}
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -38,7 +38,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 nl = tot["FETCH_SIZE"][0]
 fetch = 2.0 * tot["FETCH_SIZE"][1] * 1024 / nl        # KB -> bytes, x2 gfx950 correction
 write = tot["WRITE_SIZE"][1] * 1024 / tot["WRITE_SIZE"][0]
-out = {"kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + upconv_fir_kernel", "launches_profiled": nl, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+out = {"kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + upconv_fir_kernel + upconv_stream_kernel", "launches_profiled": nl, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
        "traffic_bytes_per_launch": fetch + write, "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as reported",
        "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-synthesis"}
 json.dump(out, open(f"{R}/gpurun_out/{TAG}_conv_traffic.json", "w"), indent=1)
