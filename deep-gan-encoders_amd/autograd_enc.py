@@ -121,12 +121,20 @@ def encoder_forward(E, img, noises=None, save=False):
         nstats = zeros(C2) if not last else None
         if not last:
             n2 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
-            a2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H), C2, 3, in_scale=sc2, in_shift=sh2, noise=n2,
-                            noise_w=blk.noise_weight_2.detach().reshape(-1), bias=blk.bias_2.detach().reshape(-1),
-                            act=ops.ACT_LRELU)
+            c2args = dict(in_scale=sc2, in_shift=sh2, noise=n2, noise_w=blk.noise_weight_2.detach().reshape(-1),
+                          bias=blk.bias_2.detach().reshape(-1), act=ops.ACT_LRELU)
             m2 = None
+            # the first blocks: conv_2 stores the 2x2 average pool of its result (and the signs for the backward) itself - the
+            # full-resolution activation (537 MB at block 0) is neither written nor read back by a pooling pass
+            pooled = has3 and ops.conv_pool_supported(B, H, H, Cc, C2, 3, dt)
+            if pooled:
+                r2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H), C2, 3, pool_out=True, pool_mask=save, **c2args)
+                x2, m2 = r2 if save else (r2, None)
+            else:
+                a2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H), C2, 3, **c2args)
             if has3:
-                x2, m2 = ops.blend(a2, pool=True, mask=True) if save else (ops.blend(a2, pool=True), None)
+                if not pooled:
+                    x2, m2 = ops.blend(a2, pool=True, mask=True) if save else (ops.blend(a2, pool=True), None)
                 xp = ops.blend(x, pool=True)
                 out = ops.conv2d(xp, _packed(cache, blk.conv_3, dt, ops.PACK_FWD), C2, 1, bias=blk.conv_3.bias.detach(),
                                  gain=0.889, addend=x2, add_scale=0.111, stats=nstats)

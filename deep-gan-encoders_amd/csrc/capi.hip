@@ -105,12 +105,25 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.stats_slots = d->stats_slots > 0 ? d->stats_slots : 1;
     p.rgb_w = d->rgb_out ? d->rgb_w : nullptr; p.rgb_style = d->rgb_style; p.rgb_bias = d->rgb_bias; p.rgb_out = d->rgb_out;
     p.rgb_wscale = d->rgb_wscale; p.rgb_skip_y = (d->rgb_out && d->rgb_skip_y) ? 1 : 0;
+    p.pool_out = d->pool_out ? 1 : 0; p.pool_mask = d->pool_out ? (unsigned*)d->pool_mask : nullptr;
+    if (d->pool_out)
+        DGE_CHECK(!d->up && dge_conv_pool_ok(p, d->dtype, d->ksize), "conv2d: the pooled epilogue is offered where dge_conv_pool_supported() "
+                  "says so (conv_2 of the first encoder blocks on the streaming kernel)");
     if (d->rgb_out) {
         DGE_CHECK(d->rgb_w && d->rgb_style && d->rgb_bias, "conv2d: rgb_out needs rgb_w, rgb_style, rgb_bias");
         DGE_CHECK(dge_conv_rgb_ok(p, d->dtype, d->ksize), "conv2d: the fused toRGB is offered where dge_conv_rgb_supported() says so "
                   "(bf16 3x3 32 -> 32 launches of the streaming kernel)");
     }
     return dge_conv_launch(p, d->dtype, d->ksize, s);
+}
+
+// 1 when an encoder-flavour launch (instance-norm affine, per-sample noise, bias, lrelu; no statistics) of this shape may store the
+// 2x2 average pool of its result instead of the result (dge_conv_desc.pool_out)
+extern "C" int dge_conv_pool_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    ConvParams p = {};
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ntot_valid = Cout; p.Ntot = dge_packed_n(Cout);
+    p.in_shift = (const float*)16; p.noise_w_stride = 1;       // (the encoder flavour's work threshold)
+    return dge_conv_pool_ok(p, dtype, ksize) ? 1 : 0;
 }
 
 // 1 when a plain generator-flavour launch (style scale, demodulation, shared noise plane, bias, activation) of this shape may carry

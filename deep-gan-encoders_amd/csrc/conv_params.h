@@ -51,6 +51,10 @@ struct ConvParams {
     float* rgb_out;           // [B][3][H][W] f32
     float rgb_wscale;
     int rgb_skip_y;           // 1: y is not stored (its only reader was the toRGB)
+    // 2x2 average pool of the result taken in the epilogue (conv_stream only; model/E/E.py:75-76): y is [B,H/2,W/2,Cout]; pool_mask
+    // (optional) receives the signs of the full-resolution values, [B, H/2*W/2, Cout/8] words (dge_blend_pool_mask's layout)
+    int pool_out;
+    unsigned* pool_mask;
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);
@@ -60,6 +64,7 @@ extern "C" int dge_conv_ntile(int ntot);
 bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize);
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s);
 bool dge_conv_rgb_ok(const ConvParams& p, int dtype, int ksize);
+bool dge_conv_pool_ok(const ConvParams& p, int dtype, int ksize);
 // conv_small.hip: the low-resolution 3x3 layers (whole-Cin halo tile resident in LDS, weights streamed straight into registers)
 bool dge_conv_small_shape_ok(int H, int W, int cin, int ntot, int ksize, int in_s2d, int in_up2, int dtype);
 int dge_conv_small_launch(const ConvParams& p, hipStream_t s);

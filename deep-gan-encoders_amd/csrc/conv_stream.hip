@@ -107,7 +107,9 @@ template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigne
                      "buffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds" : : "v"(voff), "s"(m0v), "s"(rs), "v"(voff1) : "memory");
 }
 
-enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5 };
+enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5, FL_ENC_POOL = 6 };
+// FL_ENC_POOL:  FL_ENC with the 2x2 average pool of the result (BEBlock: downscale2d after conv_2, model/E/E.py:75-76) taken in the
+//               epilogue: the full-resolution activation is never stored - only its pooled value and, for the backward, the signs
 // FL_GEN_RGB:   FL_GEN + the toRGB of the result (ConvParams::rgb_*): two more MFMAs per row on the packed output registers
 // FL_GEN:       uniform noise weight (or none), no input shift, no statistics            (generator forward, LPIPS convs)
 // FL_ENC:       per-channel noise weight, folded instance-norm shift with border terms    (encoder forward) - superset of GEN
@@ -128,9 +130,9 @@ struct SC {
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
-    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB;
+    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL;
     static_assert(!RGB || (COUT == 32 && TEAM == 1), "fused toRGB: one wave holds all 32 output channels of its pixels");
-    static constexpr bool DOT = FL == FL_DOT || PREP, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS;
+    static constexpr bool DOT = FL == FL_DOT || PREP, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS || POOL;
     static constexpr bool NOISE = !DOT || PREP;
 #ifndef DGE_SC_NR
 #define DGE_SC_NR 6
@@ -163,7 +165,7 @@ struct SC {
     static constexpr int TBYTES = 32 * MTW * 16 * 4;
     static constexpr int DUMMY_OFF = T_OFF + TEAM * TBYTES;
     static constexpr int LDS_BYTES = DUMMY_OFF + (TEAM == 2 ? 1024 : 0);
-    static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + (PREP ? 16 : 0) + (RGB ? 11 : 0) + 36;
+    static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + (PREP ? 16 : 0) + (RGB ? 11 : 0) + (POOL ? 20 * MTW : 0) + 36;
     // (the 64-channel prep flavour holds 144 weight + 48 sum registers: at two waves per SIMD it spilled 360 B per lane)
     static constexpr int WPE = (PREP && CIN == 64) ? 1 : (NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2));
     static_assert(D <= NR - 3, "the slot of the row being fetched must be dead");
@@ -416,6 +418,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 #pragma unroll
         for (int r = 0; r < 16; r++) s2[r] = 0.f;
     }
+    // pooled flavour: the even row of the current row pair (activated values and their sign bytes), this lane's pixel
+    float prow[C::POOL ? C::MTW : 1][C::POOL ? 16 : 1];
+    unsigned psign[C::POOL ? C::MTW : 1];
     // prep: x = lrelu(z)*gain of the layer below -> g_z = g * gain * lrelu'(x), z = x / (gain * lrelu'(x))
     const float pg_pos = p.prep_gain, pg_neg = 0.2f * p.prep_gain, pz_pos = 1.f / p.prep_gain, pz_neg = 1.f / (0.2f * p.prep_gain);
     const float pns = (C::PREP && p.prep_noise && p.prep_ns) ? p.prep_ns[0] : 0.f;
@@ -569,6 +574,44 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                     for (int r = 0; r < NREG; r++) { s0[mt][r] += v[r]; s1[mt][r] = fmaf(v[r], v[r], s1[mt][r]); }
                 }
             }
+            if constexpr (C::POOL) {
+                // sign bytes of the two channel runs (bit e = channel e of the run is positive: all the activation backward needs)
+                unsigned sb = 0;
+#pragma unroll
+                for (int r = 0; r < NREG; r++) sb |= (v[r] > 0.f ? 1u : 0u) << r;
+                if ((gy & 1) == 0) {                                   // wave-uniform: the segment starts on an even row
+#pragma unroll
+                    for (int r = 0; r < NREG; r++) prow[mt][r] = v[r];
+                    psign[mt] = sb;
+                    continue;
+                }
+                // odd row: this pixel's column sum, plus the neighbour column's (lanes 2j / 2j+1: quad_perm [1,0,3,2])
+#pragma unroll
+                for (int r = 0; r < NREG; r++) {
+                    const float cs = prow[mt][r] + v[r];
+                    v[r] = 0.25f * (cs + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(unsigned, cs), 0xB1, 0xf, 0xf, true)));
+                }
+                if (p.pool_mask) {
+                    // mask word of a pooled pixel and 8-channel chunk: byte q = position (2oy, 2ox), (2oy, 2ox+1), (2oy+1, 2ox), (2oy+1, 2ox+1)
+                    // (the layout of dge_blend_pool_mask / dge_act_bwd_mask)
+                    const unsigned own = (psign[mt] & 0xffffu) | (sb << 16);       // runs: [7:0], [15:8] even row | [23:16], [31:24] odd row
+                    const unsigned nbr = __builtin_amdgcn_mov_dpp(own, 0xB1, 0xf, 0xf, true);
+                    if ((n31 & 1) == 0 && pv) {
+                        const int OWp = p.W >> 1, cpt = COUT / 8;
+                        unsigned* __restrict__ mrow = p.pool_mask + (((size_t)b * (p.H >> 1) + (gy >> 1)) * OWp + (gx >> 1)) * cpt + (wave * C::MTW + mt) * 4 + kh;
+                        mrow[0] = (own & 0xffu) | ((nbr & 0xffu) << 8) | (((own >> 16) & 0xffu) << 16) | (((nbr >> 16) & 0xffu) << 24);
+                        if constexpr (NREG == 16)
+                            mrow[2] = ((own >> 8) & 0xffu) | (((nbr >> 8) & 0xffu) << 8) | (((own >> 24) & 0xffu) << 16) | (((nbr >> 24) & 0xffu) << 24);
+                    }
+                }
+                if ((n31 & 1) == 0 && pv) {
+                    unsigned char* dstp = (unsigned char*)p.y + (((size_t)b * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * C::CPB +
+                                          (unsigned)(wave * C::MTW * 64) + kh * 16 + mt * 64;
+                    *(uint4*)dstp = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+                    if constexpr (NREG == 16) *(uint4*)(dstp + 32) = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
+                }
+                continue;
+            }
             uint4 o0 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             uint4 o1 = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
             unsigned char* dst = yrow + yoff + mt * 64;
@@ -701,11 +744,12 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     if (nseg > maxseg) nseg = maxseg;
     if (nseg < 1) nseg = 1;
     int seg_rows = (p.H + nseg - 1) / nseg;
+    if (C::POOL) seg_rows += seg_rows & 1;                       // row pairs stay inside a segment
     nseg = (p.H + seg_rows - 1) / seg_rows;
     const int njobs = p.B * nstrips * nseg;
     const int nwg = (njobs + C::TPW - 1) / C::TPW;
     const int jobs_per_xcd = (nwg + 7) / 8;                        // workgroups per XCD
-    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : "gen_rgb"))));
+    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : (FL == FL_GEN_RGB ? "gen_rgb" : "enc_pool")))));
     dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
     hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM * C::TPW), C::LDS_BYTES * C::TPW, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
@@ -725,6 +769,11 @@ int launch_flavour(const ConvParams& p, hipStream_t s) {
     if (p.rgb_out) {
         if constexpr (CIN == 32 && COUT == 32) { if (!enc) return launch_stream<CIN, COUT, FL_GEN_RGB>(p, s); }
         dge_set_error("conv_stream: the fused toRGB is built for the generator flavour of 32 -> 32 only");
+        return -1;
+    }
+    if (p.pool_out) {
+        if constexpr ((CIN == 16 && COUT == 32) || (CIN == 32 && COUT == 64)) { if (!p.stats) return launch_stream<CIN, COUT, FL_ENC_POOL>(p, s); }
+        dge_set_error("conv_stream: the pooled epilogue is built for the encoder's 16 -> 32 and 32 -> 64 layers without statistics");
         return -1;
     }
     if constexpr (CIN == 64) {       // the encoder flavours of the 64-channel input do not fit the register file next to 144 weight registers
@@ -761,6 +810,12 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     if (p.noise && p.noise_w == nullptr) return false;
     if (dge_env().no_stream) return false;
     return true;
+}
+
+// The pooled epilogue (ConvParams::pool_out) exists in the streaming kernel only, for conv_2 of the first two encoder blocks
+bool dge_conv_pool_ok(const ConvParams& p, int dtype, int ksize) {
+    return ((p.Cin == 16 && p.Cout == 32) || (p.Cin == 32 && p.Cout == 64)) && !p.dot_src && !p.stats && !p.rgb_out && p.H % 2 == 0 && p.W % 2 == 0 &&
+           dge_conv_stream_eligible(p, dtype, ksize);
 }
 
 // The fused toRGB epilogue (ConvParams::rgb_*) exists in the streaming kernel only, for the 32 -> 32 generator flavour

@@ -306,14 +306,16 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None, in_t2d=False, rgb=None):
+           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None, in_t2d=False, rgb=None, pool_out=False, pool_mask=False):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout].
     `prep`: dict(gain, noise [1|B,OH,OW] or None, ns (device scalar) or None, stats=SlotStats(B, cout)) - the fused tail backward of
     the layer that produced `dot_src` (dge_conv_desc.prep): y is then g_z and prep['stats'] receives (sum g_z*(z - ns*noise), sum g_z).
     `relu_mask`: stored activation a = relu(pre) of the layer below: the result is multiplied by [a > 0] (dge_conv_desc.mask_relu).
     `rgb`: dict(w [3,cout] f32, style [B,cout], bias [3], wscale, out [B,3,H,W] f32, skip_y=False) - the toRGB of the result written
     by the same launch (dge_conv_desc.rgb_*, where conv_rgb_supported() says so); with skip_y the activation itself is not stored
-    and None is returned."""
+    and None is returned.
+    `pool_out`: the launch stores the 2x2 average pool of its result, [B,OH/2,OW/2,cout] (dge_conv_desc.pool_out, where
+    conv_pool_supported() says so); with pool_mask the signs of the full-resolution values come back too: returns (y, mask)."""
     B, H, W, Cin = x.shape
     if in_s2d:            # x is the fine grid [B,2H,2W,C]; logical input is [B,H,W,4C]
         H, W, Cin = H // 2, W // 2, Cin * 4
@@ -323,9 +325,17 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         H, W = H - 1, W - 1
     dt = dtype_of(x)
     OH, OW = (2 * H, 2 * W) if up else (H, W)
+    mask = None
+    if pool_out:
+        if out is not None or up:
+            raise DgeError("conv2d: pool_out allocates its own result and excludes up")
+        out = torch.empty((B, OH // 2, OW // 2, cout), dtype=x.dtype, device=x.device)
+        if pool_mask:
+            mask = torch.empty((B, (OH // 2) * (OW // 2), cout // 8), dtype=torch.int32, device=x.device)
     if out is None:
         out = torch.empty((B, OH, OW, cout), dtype=x.dtype, device=x.device)
     d = ConvDesc()
+    d.pool_out, d.pool_mask = 1 if pool_out else 0, _p(mask)
     if relu_mask is not None:
         if dot_src is not None or prep is not None:
             raise DgeError("conv2d: relu_mask excludes dot_src / prep")
@@ -390,6 +400,8 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         check(lib().dge_sum_slots(_p(partial), _p(stats), nslot, stats.numel(), 1, _stream()), "dge_sum_slots")
     if rgb is not None and rgb.get("skip_y"):
         return None
+    if pool_out and pool_mask:
+        return out, mask
     return out
 
 
@@ -683,6 +695,10 @@ def in_bwd_fromrgb(gy, x0, coef, img, extra=None, extra_pool=False, extra_scale=
                                    _f32(img.contiguous()), _p(part), B, H, W, Cc, 1 if extra_pool else 0, float(extra_scale),
                                    dtype_of(x0), _stream()), "dge_in_bwd_fromrgb")
     return _sum_planar(part, torch.empty((4, Cc), dtype=torch.float32, device=x0.device), defer)
+
+
+def conv_pool_supported(B, H, W, cin, cout, ksize, dtype):
+    return bool(lib().dge_conv_pool_supported(B, H, W, cin, cout, ksize, dtype))
 
 
 def conv_rgb_supported(B, H, W, cin, cout, ksize, dtype):

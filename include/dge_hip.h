@@ -108,6 +108,12 @@ typedef struct dge_conv_desc {
     float* rgb_out;           /* [B][3][H][W] f32, NULL = no fused toRGB */
     float rgb_wscale;
     int rgb_skip_y;
+    /* 2x2 average pool of the result taken in the epilogue (BEBlock: downscale2d after conv_2, model/E/E.py:75-76), offered where
+     * dge_conv_pool_supported() says so: y is [B,H/2,W/2,Cout] (the mean of the four f32 results, rounded once); pool_mask (or NULL)
+     * receives the signs of the four full-resolution values in dge_blend_pool_mask's layout ([B, H/2*W/2, Cout/8] words, byte q =
+     * position (2oy, 2ox), (2oy, 2ox+1), (2oy+1, 2ox), (2oy+1, 2ox+1), bit e = channel e of the 8-channel chunk). */
+    int pool_out;             /* 0 / 1 */
+    void* pool_mask;
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
@@ -176,6 +182,7 @@ int dge_torgb(const void* x, const float* wrgb, const float* style, const float*
               int B, int H, int W, int cin, float wscale, int dtype, dge_stream_t stream);
 
 int dge_conv_rgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
+int dge_conv_pool_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 /* img[b][c][y][x] += up2(prev)[b][c][y][x]: the skip connection of SynthesisModule.forward :517-522 (UpsamplingLayer :603-615:
  * zero-insert, pad (2,1), 4x4 FIR == per-axis taps {.25,.75} / {.75,.25}) for an image whose toRGB term is already in img
  * (dge_conv_desc.rgb_out).  img [B,3,H,W] f32, prev [B,3,H/2,W/2] f32. */

@@ -277,6 +277,49 @@ def test_encoder_conv_fullsize(cin, cout, R, B, stats, kernel):
         assert e < 7.5e-3, (b, e)          # measured 2.9e-3 .. 3.7e-3
 
 
+def _pooled_conv_case(cin, cout, R, B, W=None, samples=None):
+    """BEBlock conv_2 with the downscale2d of its result in the epilogue (E.py:68-76; dge_conv_desc.pool_out): pooled value from
+    the f32 results (one rounding of the oracle's avg_pool2d), sign mask bit-identical to the one the pooling pass
+    (dge_blend_pool_mask) takes from the stored activation."""
+    from dge_amd import ops
+    import torch.nn.functional as F
+    W = R if W is None else W
+    g = _gen(3500 + cin + cout + R + W)
+    x = _act(B, R, W, cin, g)
+    w = (_wgt(cout, cin, 3, g) * (1.0 / math.sqrt(9 * cin))).to(torch.bfloat16).float()
+    sc = 0.5 + torch.rand(B, cin, device=DEV, generator=g)
+    sh = 0.3 * torch.randn(B, cin, device=DEV, generator=g)
+    noise = torch.randn(B, R, W, device=DEV, generator=g)
+    nw = 0.1 * torch.randn(cout, device=DEV, generator=g)
+    bias = 0.1 * torch.randn(cout, device=DEV, generator=g)
+    args = dict(in_scale=sc, in_shift=sh, noise=noise, noise_w=nw, bias=bias, act=ops.ACT_LRELU)
+    wp = ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, 1.0)
+    assert ops.conv_pool_supported(B, R, W, cin, cout, 3, ops.BF16)
+    y, mask = ops.conv2d(x, wp, cout, 3, pool_out=True, pool_mask=True, **args)
+    assert _kernel() == f"conv_stream<bf16,{cin},{cout},enc_pool>"
+    assert ops.conv2d(x, wp, cout, 3, pool_out=True, **args).equal(y)              # (without the mask: same values)
+    a2 = ops.conv2d(x, wp, cout, 3, **args)
+    y_two, mask_two = ops.blend(a2, pool=True, mask=True)
+    # a sign can only differ where the f32 value rounds to a bf16 zero: never for normal numbers
+    assert (mask != mask_two).sum().item() == 0
+    for b in (samples if samples is not None else SAMPLES(B)):
+        a = (_nchw(x, b), w.cpu(), sc[b:b + 1].cpu(), sh[b:b + 1].cpu(), noise[b:b + 1].cpu(), nw.cpu(), bias.cpu())
+        ref = F.avg_pool2d(CR.enc_conv_folded(*a, q=CR.bf16_round)[0], 2)
+        assert _one_rounding(_nchw(y, b), ref) <= 0, b
+        e = _relmax(_nchw(y, b), F.avg_pool2d(CR.enc_conv(*a)[0], 2))
+        assert e < 7.5e-3, (b, e)
+
+
+@pytest.mark.parametrize("cin,cout,R,B", [(16, 32, 1024, 8), (32, 64, 512, 8)])
+def test_encoder_conv_with_pooled_epilogue_fullsize(cin, cout, R, B):
+    _pooled_conv_case(cin, cout, R, B)
+
+
+def test_encoder_conv_with_pooled_epilogue_ragged_shape(force_stream):
+    _pooled_conv_case(16, 32, 134, 2, W=140, samples=(0, 1))
+    _pooled_conv_case(32, 64, 130, 2, W=132, samples=(0, 1))
+
+
 SKIP_CONVS = [
     (16, 32, 512, 8, "conv_pw<bf16,16,32>"),        # block 0 conv_3 (after the 2x2 average pool): the LDS-free pointwise kernel
     (32, 64, 256, 8, "conv_pw<bf16,32,64>"),        # block 1 conv_3
