@@ -141,11 +141,13 @@ static int launch_pw(const ConvParams& p, hipStream_t s) {
     const int nsub = 4 / nmt;
     const int HW = p.H * p.W, ngroups = (HW + 31) / 32;
     auto kern = conv_pw_kernel<CIN>;
-    static int cap = 0;                                                 // resident workgroups of this instantiation on the device
+    static int caps[16] = {0};                                          // resident workgroups of this instantiation, per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& cap = caps[dev >= 0 && dev < 16 ? dev : 0];
     if (!cap) {
-        int occ = 0, dev = 0, ncu = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        int occ = 0, ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, 0) != hipSuccess || occ < 1) occ = 1;
         cap = occ * ncu;
     }

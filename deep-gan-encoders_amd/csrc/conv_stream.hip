@@ -727,12 +727,14 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     using C = SC<CIN, COUT, FL>;
     ConvParams p = p0;
     auto kern = conv_stream_kernel<CIN, COUT, FL>;
-    static int cap = 0;                                          // resident workgroups of this instantiation on the device
+    static int caps[16] = {0};                                   // resident workgroups of this instantiation, per device (so is the attribute)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& cap = caps[dev >= 0 && dev < 16 ? dev : 0];
     if (!cap) {
-        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES * C::TPW);
-        int occ = 0, dev = 0, ncu = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES * C::TPW);
+        int occ = 0, ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 64 * C::TEAM * C::TPW, C::LDS_BYTES * C::TPW) != hipSuccess || occ < 1) occ = 1;
         cap = occ * ncu * C::TPW;
     }

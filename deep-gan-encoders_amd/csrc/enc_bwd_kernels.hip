@@ -399,20 +399,40 @@ __global__ __launch_bounds__(256) void act_bwd_mask_kernel(const T* __restrict__
     for (int k = 0; k < NS; k++)
 #pragma unroll
         for (int e = 0; e < EP; e++) s[k][e] = 0.f;
-    for (int q0 = blockIdx.x * ppi; q0 < UHW; q0 += gridDim.x * ppi) {
-        const int q = q0 + slot;
-        if (slot < ppi && q < UHW) {
+    // two pooled pixels per thread and iteration, every load of both issued before the arithmetic (more bytes in flight per wave)
+    const int stride = gridDim.x * ppi;
+    for (int q0 = blockIdx.x * ppi; q0 < UHW; q0 += 2 * stride) {
+        const int qq[2] = {q0 + slot, q0 + slot + stride};
+        bool ok[2]; uint4 gv[2]; unsigned mv[2]; int p00[2]; float nzv[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            ok[h] = slot < ppi && qq[h] < UHW;
+            gv[h] = make_uint4(0, 0, 0, 0); mv[h] = 0; p00[h] = 0;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; c4++) nzv[h][c4] = 0.f;
+            if (ok[h]) {
+                gv[h] = *(const uint4*)(gup + ((size_t)b * UHW + qq[h]) * C + chunk * EP);
+                mv[h] = mask[((size_t)b * UHW + qq[h]) * cpt + chunk];
+                const int oy = qq[h] / UW, ox = qq[h] - oy * UW;
+                p00[h] = (2 * oy) * W + 2 * ox;
+                if (noise) {
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; c4++) nzv[h][c4] = noise[(size_t)b * HW + p00[h] + (c4 >> 1) * W + (c4 & 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (!ok[h]) continue;
             float g[EP];
-            unpack16(*(const uint4*)(gup + ((size_t)b * UHW + q) * C + chunk * EP), g, (T*)nullptr);
-            const unsigned m = mask[((size_t)b * UHW + q) * cpt + chunk];
-            const int oy = q / UW, ox = q - oy * UW;
-            const int p00 = (2 * oy) * W + 2 * ox;
+            unpack16(gv[h], g, (T*)nullptr);
+            const unsigned m = mv[h];
 #pragma unroll
             for (int e = 0; e < EP; e++) { if constexpr (NS == 3) s[2][e] += g[e]; g[e] *= scale; }
 #pragma unroll
             for (int c4 = 0; c4 < 4; c4++) {
-                const int p = p00 + (c4 >> 1) * W + (c4 & 1);
-                const float nz = noise ? noise[(size_t)b * HW + p] : 0.f;
+                const int p = p00[h] + (c4 >> 1) * W + (c4 & 1);
+                const float nz = nzv[h][c4];
                 float o[EP];
 #pragma unroll
                 for (int e = 0; e < EP; e++) {

@@ -340,12 +340,14 @@ int dge_upconv_stream_launch(const void* x, const void* w_packed, void* y, const
     p.dbg = dge_env().up_dbg;
     p.x = x; p.w = w_packed; p.y = y; p.in_scale = in_scale; p.out_scale = out_scale; p.noise = noise; p.noise_w = noise_w; p.bias = bias;
     p.B = B; p.H = H; p.W = W; p.noise_bstride = noise_bstride; p.act = act; p.bias_scale = bias_scale; p.gain = gain;
-    static int cap = 0;
+    static int caps[16] = {0};                                   // resident teams, per device (the attribute is per device too)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& cap = caps[dev >= 0 && dev < 16 ? dev : 0];
     if (!cap) {
-        hipFuncSetAttribute((const void*)upconv_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        int occ = 0, dev = 0, ncu = 256;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipFuncSetAttribute((const void*)upconv_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        int occ = 0, ncu = 256;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)upconv_stream_kernel, 128, LDS_BYTES) != hipSuccess || occ < 1) occ = 1;
         cap = occ * ncu;
     }
