@@ -93,16 +93,17 @@ def synthesis_run(mod, wp, randomize_noise=False, save=False):
             noise = ops.randn((x.shape[0], L.res, L.res), x.device)
         else:
             noise = L.noise.reshape(1, L.res, L.res)
-        # the last layer's toRGB rides in its conv epilogue where the streaming kernel offers it (1024^2: the 537 MB activation is
-        # not read back by a toRGB pass, and not even written when nothing else reads it); the skip image is added afterwards
-        fuse_rgb = (i == nl - 2 and i % 2 == 0 and image is not None and not L.up and L.bias is not None and
+        # the toRGB of the top layers rides in their conv epilogue where the streaming kernel offers it (512^2 / 1024^2: the activation
+        # is not read back by a toRGB pass, and the last one is not even written when nothing else reads it); the skip image is
+        # added afterwards
+        fuse_rgb = (i % 2 == 0 and image is not None and not L.up and L.bias is not None and
                     ops.conv_rgb_supported(B, L.res, L.res, L.in_c, L.out_c, 3, dt))
         rgb = None
         if fuse_rgb:
             O_ = getattr(mod, f"output{i // 2}")
             srgb = s_of(nl - 1 + i // 2, O_.in_c)
             rgb = dict(w=O_.weight.detach().reshape(3, -1), style=srgb, bias=O_.bias.detach(), wscale=O_.wscale,
-                       out=torch.empty((B, 3, L.res, L.res), dtype=torch.float32, device=x.device), skip_y=not save)
+                       out=torch.empty((B, 3, L.res, L.res), dtype=torch.float32, device=x.device), skip_y=(not save) and i == nl - 2)
         y = L.conv(x, s, d, noise, dt, rgb=rgb)
         results[f"style{i:02d}"] = s
         if save:

@@ -131,7 +131,7 @@ struct SC {
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
     static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL;
-    static_assert(!RGB || (COUT == 32 && TEAM == 1), "fused toRGB: one wave holds all 32 output channels of its pixels");
+    static_assert(!RGB || COUT == 32 || (COUT == 64 && TEAM == 2), "fused toRGB: 32 output channels per wave, one wave or a 2-wave team per pixel");
     static constexpr bool DOT = FL == FL_DOT || PREP, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS || POOL;
     static constexpr bool NOISE = !DOT || PREP;
 #ifndef DGE_SC_NR
@@ -164,7 +164,8 @@ struct SC {
     static constexpr int T_OFF = D_OFF + TEAM * DRING;                           // per wave: T table [32*MTW][12] f32 + epilogue constants [3][32*MTW]
     static constexpr int TBYTES = 32 * MTW * 16 * 4;
     static constexpr int DUMMY_OFF = T_OFF + TEAM * TBYTES;
-    static constexpr int LDS_BYTES = DUMMY_OFF + (TEAM == 2 ? 1024 : 0);
+    static constexpr int RGBX_OFF = DUMMY_OFF + (TEAM == 2 ? 1024 : 0);             // fused toRGB of a team: wave 1's partial sums, [2 row parities][3][32] f32
+    static constexpr int LDS_BYTES = RGBX_OFF + (RGB && TEAM == 2 ? 1024 : 0);
     static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + (PREP ? 16 : 0) + (RGB ? 11 : 0) + (POOL ? 20 * MTW : 0) + 36;
     // (the 64-channel prep flavour holds 144 weight + 48 sum registers: at two waves per SIMD it spilled 360 B per lane)
     static constexpr int WPE = (PREP && CIN == 64) ? 1 : (NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2));
@@ -369,7 +370,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             float f[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const int c = 16 * ks + 8 * kh + e;
+                const int c = wave * 32 + 16 * ks + 8 * kh + e;
                 const float wv = live ? p.rgb_w[row * COUT + c] * p.rgb_wscale * p.rgb_style[b * COUT + c] : 0.f;
                 const float hi = __uint_as_float(__float_as_uint(wv) & 0xffff0000u);      // (truncated hi: the lo part takes the rest)
                 f[e] = part == 0 ? hi : wv - hi;
@@ -377,8 +378,21 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             rgbA[ks] = pack16(f, (bf16_t*)nullptr);
         }
 #pragma unroll
-        for (int k = 0; k < 3; k++) rgbb[k] = p.rgb_bias[k];
+        for (int k = 0; k < 3; k++) rgbb[k] = wave == 0 ? p.rgb_bias[k] : 0.f;
     }
+    // 2-wave team: wave 1 leaves its partial sums of row s in LDS, wave 0 keeps its own and stores the sum one step later (after
+    // the team barrier of step s + 1)
+    float rgbh[3] = {0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) float* lds_wfp;
+    auto rgb_flush = [&](int srow) {
+        if (kh == 0 && x0 + n31 < p.W) {
+            const unsigned a = lds0 + C::RGBX_OFF + (unsigned)(srow & 1) * 384 + n31 * 4;
+            float* __restrict__ ro = p.rgb_out + ((size_t)b * 3 * p.H + (r0 + srow)) * p.W + x0 + n31;
+            const size_t plane = (size_t)p.H * p.W;
+#pragma unroll
+            for (int k = 0; k < 3; k++) ro[k * plane] = rgbh[k] + *(const __attribute__((address_space(3))) float*)(a + k * 128);
+        }
+    };
 
     // ---- B-fragment lane offsets: halo pixel n31 + dx, chunk (ks*2 + kh) ^ swizzle
     unsigned loff[3][C::KS];
@@ -446,7 +460,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 #else
         asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
 #endif
+        if constexpr (C::RGB && C::TEAM == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave 1's partial sums of row s-1 are in LDS)
         if constexpr (C::TEAM == 2) __builtin_amdgcn_s_barrier();     // the partner's pieces landed; it finished step s-1
+        if constexpr (C::RGB && C::TEAM == 2) { if (wave == 0 && s > 0) rgb_flush(s - 1); }
         DGE_T(1);
         if constexpr (C::NOISE && I == 0) issue_noise(s + C::NR, npar ^ 1024u);   // the next period's rows into the other buffer
         issue(s + 2 + C::D, (I + 2 + C::D) % C::NR, (I + C::D) % C::DR);
@@ -618,7 +634,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             if constexpr (C::RGB) {
                 f32x16_t t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&rgbA[0], *(const bf16x8_t*)&o0, zero16, 0, 0, 0);
                 t = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&rgbA[1], *(const bf16x8_t*)&o1, t, 0, 0, 0);
-                if (kh == 0 && pv) {
+                if constexpr (C::TEAM == 2) {
+                    if (wave == 0) { rgbh[0] = t[0] + t[4] + rgbb[0]; rgbh[1] = t[1] + t[5] + rgbb[1]; rgbh[2] = t[2] + t[6] + rgbb[2]; }
+                    else if (kh == 0) {
+                        const unsigned a = lds0 + C::RGBX_OFF + (unsigned)(s & 1) * 384 + n31 * 4;
+                        *(lds_wfp)(a) = t[0] + t[4]; *(lds_wfp)(a + 128) = t[1] + t[5]; *(lds_wfp)(a + 256) = t[2] + t[6];
+                    }
+                } else if (kh == 0 && pv) {
                     float* __restrict__ ro = p.rgb_out + ((size_t)b * 3 * p.H + gy) * p.W + gx;
                     const size_t plane = (size_t)p.H * p.W;
                     ro[0] = t[0] + t[4] + rgbb[0]; ro[plane] = t[1] + t[5] + rgbb[1]; ro[2 * plane] = t[2] + t[6] + rgbb[2];
@@ -667,6 +689,11 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 else done = true;
             }
         });
+    }
+    if constexpr (C::RGB && C::TEAM == 2) {          // the last row's toRGB
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave == 0 && rows > 0) rgb_flush(rows - 1);
     }
     // no DMA may land after the wave has given its LDS back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -769,8 +796,8 @@ int launch_flavour(const ConvParams& p, hipStream_t s) {
     }
     const bool enc = p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0);
     if (p.rgb_out) {
-        if constexpr (CIN == 32 && COUT == 32) { if (!enc) return launch_stream<CIN, COUT, FL_GEN_RGB>(p, s); }
-        dge_set_error("conv_stream: the fused toRGB is built for the generator flavour of 32 -> 32 only");
+        if constexpr ((CIN == 32 && COUT == 32) || (CIN == 64 && COUT == 64)) { if (!enc) return launch_stream<CIN, COUT, FL_GEN_RGB>(p, s); }
+        dge_set_error("conv_stream: the fused toRGB is built for the generator flavour of 32 -> 32 and 64 -> 64 only");
         return -1;
     }
     if (p.pool_out) {
@@ -820,9 +847,9 @@ bool dge_conv_pool_ok(const ConvParams& p, int dtype, int ksize) {
            dge_conv_stream_eligible(p, dtype, ksize);
 }
 
-// The fused toRGB epilogue (ConvParams::rgb_*) exists in the streaming kernel only, for the 32 -> 32 generator flavour
+// The fused toRGB epilogue (ConvParams::rgb_*) exists in the streaming kernel only, for the 32 -> 32 and 64 -> 64 generator flavours
 bool dge_conv_rgb_ok(const ConvParams& p, int dtype, int ksize) {
-    return p.Cin == 32 && p.Cout == 32 && !p.dot_src && !p.stats && !p.in_shift && !(p.noise && p.noise_w_stride != 0) &&
+    return ((p.Cin == 32 && p.Cout == 32) || (p.Cin == 64 && p.Cout == 64)) && !p.dot_src && !p.stats && !p.in_shift && !(p.noise && p.noise_w_stride != 0) &&
            dge_conv_stream_eligible(p, dtype, ksize);
 }
 

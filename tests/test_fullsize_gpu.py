@@ -120,9 +120,9 @@ def test_generator_stride1_layer_fullsize(cin, cout, R, B, kernel):
         assert e < 6e-3, (b, e)            # measured 2.0e-3 .. 3.2e-3
 
 
-def _fused_torgb_case(R, W, B):
+def _fused_torgb_case(R, W, B, cin=32):
     from dge_amd import ops
-    cin = cout = 32
+    cout = cin
     g = _gen(1500 + R + W)
     x = _act(B, R, W, cin, g)
     w = _wgt(cout, cin, 3, g)
@@ -141,10 +141,10 @@ def _fused_torgb_case(R, W, B):
     wp = ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, wscale)
     args = dict(in_scale=s, out_scale=d, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=math.sqrt(2.0))
     y0 = ops.conv2d(x, wp, cout, 3, **args)
-    assert _kernel() == "conv_stream<bf16,32,32,gen>"
+    assert _kernel() == f"conv_stream<bf16,{cin},{cout},gen>"
     img1 = torch.full((B, 3, R, W), float("nan"), device=DEV)
     y1 = ops.conv2d(x, wp, cout, 3, rgb=dict(w=wrgb, style=srgb, bias=brgb, wscale=rws, out=img1), **args)
-    assert _kernel() == "conv_stream<bf16,32,32,gen_rgb>"
+    assert _kernel() == f"conv_stream<bf16,{cin},{cout},gen_rgb>"
     assert torch.equal(y0, y1)                                   # the activation itself is the plain launch's, bit for bit
     img2 = torch.full((B, 3, R, W), float("nan"), device=DEV)
     assert ops.conv2d(x, wp, cout, 3, rgb=dict(w=wrgb, style=srgb, bias=brgb, wscale=rws, out=img2, skip_y=True), **args) is None
@@ -162,14 +162,16 @@ def _fused_torgb_case(R, W, B):
     assert ((got - want).abs().max() / want.abs().max()).item() < 2e-5
 
 
-def test_fused_torgb_of_the_last_layer_fullsize():
-    """Layer 16 of the 1024^2 generator with its toRGB in the conv epilogue (dge_conv_desc.rgb_*) and the skip image added by
-    dge_rgb_upsample_add (stylegan2_generator.py:515-522)."""
-    _fused_torgb_case(1024, 1024, 8)
+@pytest.mark.parametrize("cin,R", [(32, 1024), (64, 512)])
+def test_fused_torgb_of_the_top_layers_fullsize(cin, R):
+    """Layers 16 / 14 of the 1024^2 generator with their toRGB in the conv epilogue (dge_conv_desc.rgb_*; 64 channels: the 2-wave
+    team adds its halves through LDS) and the skip image added by dge_rgb_upsample_add (stylegan2_generator.py:515-522)."""
+    _fused_torgb_case(R, R, 8, cin)
 
 
 def test_fused_torgb_ragged_shape(force_stream):
     _fused_torgb_case(136, 132, 2)
+    _fused_torgb_case(130, 140, 2, 64)
 
 
 UP_LAYERS = [
