@@ -74,8 +74,73 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
 
 static constexpr int cmin(int a, int b) { return a < b ? a : b; }
-template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN>
+// ---- transposed-accumulator epilogue (kernel MODE bit 5).  MFMA C layout with the weights as A operand: lane (pixel = lane & 31,
+// kh = lane >> 5) holds rows 8j + 4kh + i in register 4j + i; with the weight rows permuted by tr_chan_of_row, registers 0-7 are
+// channels 8kh .. 8kh+7 and registers 8-15 channels 16+8kh .. 16+8kh+7 of the 32-channel tile (conv_stream.hip uses the same map).
+__device__ __forceinline__ int tr_chan_of_row(int m) {
+    const int j = m >> 3, k = (m >> 2) & 1, i = m & 3;
+    return 16 * (j >> 1) + 8 * k + 4 * (j & 1) + i;
+}
+// Stages: demodulation scale, noise, bias, activation, gain (model/stylegan2_generator.py:908-921; LPIPS conv + ReLU) - the
+// forward menu of conv_epilogue MODE 0 without statistics and without the depth-to-space store.
+template <typename T, class C, int TH, int TW, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_tr(const ConvParams& p, f32x16_t (&acc)[C::MT][C::NT], const float* ldsN,
+                                                 int b, int x0, int y0, int bn0, int wave, int lane) {
+    static_assert(sizeof(T) == 2, "bf16 storage");
+    const int wm = wave / WN, wn = wave % WN;
+    const int px = lane & 31, kh = lane >> 5;
+    const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
+    T* __restrict__ Yb = (T*)p.y + (size_t)b * p.H * p.W * p.Cout;           // in-image offsets fit 32 bits
+    StaticFor<C::NT>::run([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int n0 = bn0 + wn * C::WTN + j * 32;
+        if (n0 >= p.Ntot_valid) return;                                        // wave-uniform
+        float osc[16], bia[16], nw[16];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int c0 = n0 + 16 * h + 8 * kh;
+            const bool cv = c0 < p.Cout;                                       // Cout is a multiple of 8: a run is valid or empty
+#pragma unroll
+            for (int e4 = 0; e4 < 2; e4++) {
+                float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.out_scale && cv) s4 = *(const float4*)(p.out_scale + (size_t)b * p.Cout + c0 + e4 * 4);
+                if (p.bias && cv) b4 = *(const float4*)(p.bias + c0 + e4 * 4);
+                const int r = 8 * h + 4 * e4;
+                osc[r] = s4.x * p.gain; osc[r + 1] = s4.y * p.gain; osc[r + 2] = s4.z * p.gain; osc[r + 3] = s4.w * p.gain;
+                const float bg = p.bias_scale * p.gain;
+                bia[r] = b4.x * bg; bia[r + 1] = b4.y * bg; bia[r + 2] = b4.z * bg; bia[r + 3] = b4.w * bg;
+#pragma unroll
+                for (int e = 0; e < 4; e++) nw[r + e] = (p.noise && cv) ? p.noise_w[(c0 + e4 * 4 + e) * p.noise_w_stride] * p.gain : 0.f;
+            }
+        }
+        StaticFor<C::MT>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const int m = wm * C::WTM + i * 32 + px;
+            const int gy = y0 + m / TW, gx = x0 + m % TW;
+            const float nz = p.noise ? ldsN[m] : 0.f;
+            const f32x16_t a = acc[i][j];
+            float v0[8], v1[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float u0 = fmaf(a[r], osc[r], fmaf(nw[r], nz, bia[r]));
+                const float u1 = fmaf(a[8 + r], osc[8 + r], fmaf(nw[8 + r], nz, bia[8 + r]));
+                v0[r] = fmaxf(u0, u0 * slope); v1[r] = fmaxf(u1, u1 * slope);
+            }
+            if ((gy < p.H) & (gx < p.W)) {
+                T* yp = Yb + (gy * p.W + gx) * p.Cout + n0 + 8 * kh;
+                if (n0 + 8 * kh < p.Cout) *(uint4*)yp = pack16(v0, (T*)nullptr);
+                if (n0 + 16 + 8 * kh < p.Cout) *(uint4*)(yp + 16) = pack16(v1, (T*)nullptr);
+            }
+        });
+    });
+}
+
+// OPT bit 1 (N1): single-phase noise tile - the launch is not in up mode (lets the 32 x 16 pixel tile keep two workgroups per CU).
+// (A double-buffered halo tile - OPT bit 0 in the round-3 experiments: next chunk's tile written during the current chunk, no
+//  boundary barrier - measured +-2 % on every deep-K 64-wide launch and was removed: DESIGN 6e.)
+template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN, int OPT = 0>
 struct ConvCfg {
+    static constexpr int N1 = (OPT >> 1) & 1;                // single-phase noise tile (launch is not in up mode)
     static constexpr int BM = TH * TW;
     static constexpr int WTM = BM / WM, WTN = BN / WN;
     static constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -93,15 +158,16 @@ struct ConvCfg {
     static constexpr int E_BYTES = 4 * 32 * ESTR;
     // noise values of the tile (x4 phases in up mode; up mode has N = 4*Cout >= 64, so 32-wide N tiles never see it and
     // keep 3 KB: that puts the 16x16x32 configuration under the 3-workgroups-per-CU LDS line)
-    static constexpr int N_BYTES = (BN >= 64 ? 4 : 1) * BM * 4;
+    static constexpr int N_BYTES = ((BN >= 64 && !N1) ? 4 : 1) * BM * 4;
+    static constexpr int A_BUFS = 1;
     // weight-stage ring.  Large pixel tiles: 4 deep (DMA issued 3 stages ahead) when two workgroups still fit a CU, else
     // 2 deep.  Small pixel tiles serve the low-resolution layers, whose grids do not fill the chip and whose stages are
     // short (6-12 MFMAs per wave): there the serial K loop is bound by the L2 latency of the weight stream, so the ring
     // takes the whole LDS (one workgroup per CU) and runs up to 5 stages ahead.
-    static constexpr int NBUF_SMALL = cmin(6, cmax(2, (150 * 1024 - A_BYTES - N_BYTES) / B_BYTES));
-    static constexpr int NBUF = (BM <= 128) ? NBUF_SMALL : ((A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2);
+    static constexpr int NBUF_SMALL = cmin(6, cmax(2, (150 * 1024 - A_BUFS * A_BYTES - N_BYTES) / B_BYTES));
+    static constexpr int NBUF = (BM <= 128) ? NBUF_SMALL : ((A_BUFS * A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2);
     static constexpr int DPW = B_PIECES / 4;                   // DMA instructions every wave issues per stage (floor)
-    static constexpr int LDS_BYTES = cmax(A_BYTES + NBUF * B_BYTES, E_BYTES) + N_BYTES;
+    static constexpr int LDS_BYTES = cmax(A_BUFS * A_BYTES + NBUF * B_BYTES, E_BYTES) + N_BYTES;
     static constexpr int NA_ITEMS = HH * HW * CH, NA_PER = (NA_ITEMS + 255) / 256;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(MT >= 1 && NT >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
@@ -114,16 +180,21 @@ struct ConvCfg {
 };
 
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)) void conv_igemm_kernel(ConvParams p) {
-    using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>;
+__global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN, (MODE >> 3) & 3>::MINW)) void conv_igemm_kernel(ConvParams p) {
+    using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN, (MODE >> 3) & 3>;
     // MODE: bits 0-1 = epilogue mode (conv_epilogue.h); bit 2 = in_t2d (phase-form adjoint of the up layer: compile time, because a
-    // run-time choice between two unrolled step sequences in the main loop doubled its code and spilled the accumulators)
+    // run-time choice between two unrolled step sequences in the main loop doubled its code and spilled the accumulators);
+    // bits 3-4 = ConvCfg OPT
     constexpr bool T2D = (MODE & 4) != 0;
+    // bit 5 = transposed accumulators (TR): the WEIGHT fragment is the MFMA A operand, its rows permuted (tr_chan_of_row) so that
+    // a lane ends up with two runs of 8 consecutive channels of ONE pixel - the result leaves as 16-byte stores straight from
+    // the registers (conv_epilogue_tr: no LDS transpose).  Offered for the plain forward epilogue (mode 0, no statistics, no up).
+    constexpr bool TR = (MODE & 32) != 0;
     constexpr int EMODE = MODE & 3;
     constexpr int EP16 = Elem<T>::PER16;
     __shared__ __attribute__((aligned(256))) unsigned char lds[C::LDS_BYTES];
     unsigned char* ldsA = lds;                         // halo tile of the current K chunk
-    unsigned char* ldsB = lds + C::A_BYTES;            // 2 weight stages
+    unsigned char* ldsB = lds + C::A_BUFS * C::A_BYTES;   // weight stages
     float* ldsN = (float*)(lds + C::LDS_BYTES - C::N_BYTES);   // noise tile, lives until the epilogue
     const unsigned ldsB_off = lds_offset_of(ldsB);
 
@@ -166,7 +237,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     int bbase[C::NT], bsw[C::NT];           // weight row byte offset and its chunk swizzle
 #pragma unroll
     for (int j = 0; j < C::NT; j++) {
-        const int n = wn * C::WTN + j * 32 + (lane & 31);
+        const int n = wn * C::WTN + j * 32 + (TR ? tr_chan_of_row(lane & 31) : (lane & 31));
         bbase[j] = n * C::KCB; bsw[j] = (n / C::RP) % C::CH;
     }
 
@@ -231,7 +302,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
         });
     };
     // ---- registers -> LDS with the fused per-(b,c) affine (inside the image only)
-    auto store_a = [&]() {
+    auto store_a = [&](int abuf) {
+        unsigned char* __restrict__ dstA = ldsA + abuf * C::A_BYTES;
         StaticFor<C::NA_PER>::run([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const int idx = tid + i * 256;
@@ -250,7 +322,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                     }
                     v = pack16(f, (T*)nullptr);
                 }
-                *(uint4*)(ldsA + hy * C::RPITCH + hx * C::PSTR + achunk * 16) = v;
+                *(uint4*)(dstA + hy * C::RPITCH + hx * C::PSTR + achunk * 16) = v;
             }
         });
     };
@@ -303,7 +375,7 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
             ldsN[idx] = (gy < p.H && gx < p.W) ? nz_src[(size_t)b * nz_bs + (size_t)oy * OWn + ox] : 0.f;
         }
     }
-    store_a();
+    store_a(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the untracked weight DMAs
     __syncthreads();
 
@@ -344,7 +416,10 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
 #pragma unroll
                         for (int i = 0; i < C::MT; i++)
 #pragma unroll
-                            for (int j = 0; j < C::NT; j++) Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                            for (int j = 0; j < C::NT; j++) {
+                                if constexpr (TR) Mma<T>::run(bf[q & 1][j], af[q & 1][i], acc[i][j]);
+                                else Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                            }
                     });
                 } else if constexpr (row > 0) {
                     // in_t2d: kernel row 0 and tap 0 of the other rows hold zero weights (DGE_PACK_UPT2D_DGRAD) and are skipped:
@@ -356,7 +431,10 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
 #pragma unroll
                         for (int i = 0; i < C::MT; i++)
 #pragma unroll
-                            for (int j = 0; j < C::NT; j++) Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                            for (int j = 0; j < C::NT; j++) {
+                                if constexpr (TR) Mma<T>::run(bf[q & 1][j], af[q & 1][i], acc[i][j]);
+                                else Mma<T>::run(af[q & 1][i], bf[q & 1][j], acc[i][j]);
+                            }
                     });
                 }
             }
@@ -373,8 +451,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
                 else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * C::DPW) : "memory");
             }
             __syncthreads();                                       // ... for every wave: stage closed
-            if (row == KS - 1 && !LAST) {                          // chunk boundary: replace the halo tile
-                store_a();
+            if (row == KS - 1 && !LAST) {                  // chunk boundary: replace the halo tile
+                store_a(0);
                 __syncthreads();
             }
         });
@@ -385,7 +463,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN>::MINW)
     }
     // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
     // LDS is re-used as the transpose buffer from here (all reads done: barrier above); the noise tile at its end stays valid
-    conv_epilogue<T, C, TH, TW, BN, WM, WN, 256, EMODE>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
+    if constexpr (TR) conv_epilogue_tr<T, C, TH, TW, BN, WM, WN>(p, acc, ldsN, b, x0, y0, bn0, wave, lane);
+    else conv_epilogue<T, C, TH, TW, BN, WM, WN, 256, EMODE>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
 }
 
 // ------------------------------------------------------------------------- dispatch
@@ -397,11 +476,14 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     p.tiles_y = (p.H + TH - 1) / TH;
     const int ntiles = (p.Ntot + BN - 1) / BN;
     const long grid = (long)p.tiles_x * p.tiles_y * p.B * ntiles;
-    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s%s", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN,
-                    p.in_t2d ? "+t2d" : "", p.prep ? "+prep" : "");
+
     // epilogue mode (conv_epilogue.h): 0 plain, 1 addend / dot_src with prefetch, 2 = 1 + fused tail backward (3x3 only).
     // The f32 parity path has no prefetch, so its mode 1 is its mode 0 with the stages enabled: it always takes >= 1.
     const bool da = p.addend || p.dot_src;
+    // transposed accumulators + direct stores (conv_epilogue_tr): the plain forward epilogue on the 16 x 16 / 32 x 16 pixel tiles
+    const bool tr = sizeof(T) == 2 && !da && !p.prep && !p.stats && !p.up && !p.in_t2d && !(p.dbg & 64);
+    dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s%s%s", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN,
+                    p.in_t2d ? "+t2d" : "", p.prep ? "+prep" : "", (tr && KS == 3 && TW == 16 && (TH == 16 || TH == 32)) ? "+tr" : "");
     DGE_CHECK(!p.prep || (KS == 3 && p.dot_src), "conv: prep is offered for 3x3 data-gradient launches only");
 #define DGE_GO(MODE) hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN, MODE>), dim3((unsigned)grid), dim3(256), 0, s, p)
     if constexpr (KS == 3) {
@@ -410,7 +492,16 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
             else DGE_CHECK(false, "conv: in_t2d needs N >= 64 and a grid of at least 16 x 16");
         }
         else if (p.prep) DGE_GO(2);
+        else if constexpr (sizeof(T) == 2 && TH == 32 && TW == 16 && BN == 64) {
+            if (da) DGE_GO(17); else if (tr) DGE_GO(48); else DGE_GO(16);      // (offered without up mode only: single-phase noise tile)
+        }
+        else if constexpr (sizeof(T) == 2 && TH == 16 && TW == 16 && BN == 64) {
+            if (da) DGE_GO(1);
+            else if (tr) DGE_GO(32);
+            else DGE_GO(0);
+        }
         else if (da || sizeof(T) == 4) DGE_GO(1);
+        else if constexpr (sizeof(T) == 2 && TH == 16 && TW == 16) { if (tr) DGE_GO(32); else DGE_GO(0); }
         else DGE_GO(0);
     } else {
         if (da || sizeof(T) == 4) DGE_GO(1);
@@ -455,6 +546,11 @@ static int launch_t(const ConvParams& p, hipStream_t s) {
         if (kc == K0) GO(8, 16, 32, K0, 4, 1); GO(8, 16, 32, K1, 4, 1);
     }
     if (bn == 128) { if (kc == K0) GO(16, 16, 128, K0, 2, 2); GO(16, 16, 128, K1, 2, 2); }
+    if constexpr (E == 2 && KS == 3) {
+        // 64-wide N tile on 32 x 16 pixels: each wave holds 128 pixels x 64 channels (6 fragment reads per 8 MFMAs instead of 4 per 4)
+        if (bn == 64 && kc == K0 && !p.up && !p.in_t2d && !p.prep && (dge_env().conv_dbg & 128) &&
+            (long)((p.H + 31) / 32) * ((p.W + 15) / 16) * p.B * (p.Ntot / 64) >= 1024) GO(32, 16, 64, K0, 4, 1);
+    }
     if (bn == 64)  { if (kc == K0) GO(16, 16, 64, K0, 4, 1);  GO(16, 16, 64, K1, 4, 1); }
     if (kc == K0) GO(16, 16, 32, K0, 4, 1); GO(16, 16, 32, K1, 4, 1);
 #undef GO

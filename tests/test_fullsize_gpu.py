@@ -78,10 +78,10 @@ SAMPLES = lambda B: sorted({0, B - 1})
 G_LAYERS = [
     (32, 32, 1024, 8, "conv_stream<bf16,32,32,gen>"),       # layer16: the streaming kernel of the HBM-bound layers
     (64, 64, 512, 8, "conv_stream<bf16,64,64,gen>"),        # layer14
-    (128, 128, 256, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),     # layer12: the 128-wide N tile
-    (256, 256, 128, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),     # layer10
-    (512, 512, 64, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),      # layer8
-    (512, 512, 32, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>"),       # layer6
+    (128, 128, 256, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>+tr"),  # layer12: the 128-wide N tile; +tr = transposed accumulators,
+    (256, 256, 128, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>+tr"),  # layer10   direct stores (conv_epilogue_tr)
+    (512, 512, 64, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>+tr"),   # layer8
+    (512, 512, 32, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>+tr"),    # layer6
     (512, 512, 16, 8, "conv_small<bf16,8,8,64,512>"),              # layer4: the low-resolution kernel (csrc/conv_small.hip)
     (512, 512, 8, 8, "conv_small<bf16,8,8,64,512>"),               # layer2
     (512, 512, 4, 8, "conv_small<bf16,8,8,64,512>"),               # layer0 (one 8x8 tile per sample, a quarter of it image)
@@ -235,7 +235,7 @@ ENC_CONVS = [
     (32, 32, 512, 8, True, "conv_stream<bf16,32,32,enc_stats>"),      # block 1 conv_1
     (32, 64, 512, 8, False, "conv_stream<bf16,32,64,enc>"),     # block 1 conv_2
     (64, 64, 256, 8, True, "conv_igemm<bf16,16,16,64,32,3,4,1>"),      # block 2 conv_1 (encoder flavours stop at Cin = 32: registers)
-    (64, 128, 256, 8, False, "conv_igemm<bf16,16,16,128,32,3,2,2>"),   # block 2 conv_2: back on the implicit-GEMM kernel
+    (64, 128, 256, 8, False, "conv_igemm<bf16,16,16,128,32,3,2,2>+tr"),   # block 2 conv_2: back on the implicit-GEMM kernel (no statistics: direct stores)
     (512, 512, 8, 8, True, "conv_small<bf16,8,8,64,512>"),             # block 7 conv_1
     (512, 512, 16, 8, True, "conv_small<bf16,8,8,64,512>"),            # block 6 conv_1 (four tiles per sample)
 ]
@@ -632,6 +632,37 @@ def test_low_resolution_kernel_ragged_shapes(H, W, B):
         assert _one_rounding(_nchw(y, b), ref) <= 0, b
         refg = CR.conv_dgrad(_nchw(gy, b), w.cpu()) + _nchw(add, b)
         assert _one_rounding(_nchw(gx, b), refg) <= 0, b
+
+
+@pytest.mark.parametrize("H,W,B,cin,cout", [(150, 141, 2, 64, 136), (120, 130, 3, 128, 72), (200, 170, 2, 32, 24), (100, 90, 2, 256, 256)])
+def test_transposed_accumulator_epilogue_ragged_shapes(H, W, B, cin, cout):
+    """conv_igemm with the weights as the MFMA A operand and direct 16-byte stores (conv_epilogue_tr, kernel MODE bit 5) on
+    geometry where the 16 x 16 tiles hang over both image edges and the last N tile is partly empty (channel tails of 8),
+    on the 128-, 64- and 32-wide N tiles: the modulated forward conv (stylegan2_generator.py:855-922: style, demodulation,
+    noise, bias, lrelu * sqrt(2)) and the VGG conv + ReLU of LPIPS; every sample and pixel compared."""
+    from dge_amd import ops
+    import torch.nn.functional as F
+    g = _gen(7700 + H * 13 + W + cout)
+    x = _act(B, H, W, cin, g)
+    w = _wgt(cout, cin, 3, g)
+    wscale = 1.0 / math.sqrt(9 * cin)
+    s = 1.0 + 0.3 * torch.randn(B, cin, device=DEV, generator=g)
+    d = 0.5 + torch.rand(B, cout, device=DEV, generator=g)
+    noise = torch.randn(1, H, W, device=DEV, generator=g)
+    ns = torch.tensor([0.37], device=DEV)
+    bias = 0.2 * torch.randn(cout, device=DEV, generator=g)
+    wp = ops.pack_conv_weight(w, ops.PACK_FWD, ops.BF16, wscale)
+    y = ops.conv2d(x, wp, cout, 3, in_scale=s, out_scale=d, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU,
+                   gain=math.sqrt(2.0))
+    assert _kernel().startswith("conv_igemm<bf16,16,16,") and _kernel().endswith("+tr"), _kernel()
+    y2 = ops.conv2d(x, wp, cout, 3, bias=bias, act=ops.ACT_RELU)
+    assert _kernel().endswith("+tr"), _kernel()
+    wq = CR.bf16_round(w.cpu() * wscale)
+    for b in range(B):
+        a = (_nchw(x, b), wq, s[b:b + 1].cpu(), d[b:b + 1].cpu(), noise.cpu(), 0.37, bias.cpu(), 1.0, 1.0)
+        assert _one_rounding(_nchw(y, b), CR.modconv(*a, q=CR.bf16_round)) <= 0, b
+        ref = F.relu(F.conv2d(_nchw(x, b), wq, bias.cpu(), padding=1))
+        assert _one_rounding(_nchw(y2, b), ref) <= 0, b
 
 
 PREP_CASES = [
