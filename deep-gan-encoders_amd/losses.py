@@ -1,6 +1,9 @@
 """space_loss (reference training_utils.py:54-99) and the three-scale image loss of
 E_align_s2.py:185-203 on the HIP kernels, as autograd Functions whose forward also produces the
 analytic gradient w.r.t. the second argument (the only one that carries grad in E_align)."""
+import contextlib
+import os
+
 import torch
 
 from . import ops
@@ -105,6 +108,19 @@ def _space_loss_windows(a, b, wins, image_space, lpips_model, weights, g_outs, a
     return [_window_finish(a, b, st, image_space, weights[i], g_outs[i], accumulate, world) for i, st in enumerate(sts)]
 
 
+_WINDOW_STREAMS = os.environ.get("DGE_WINDOW_STREAMS", "1") != "0"
+_SIDE = {}
+
+
+def _side_streams(dev, n):
+    """n side streams of the device, created once (stream creation inside a step would be a host synchronisation)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    have = _SIDE.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[:n]
+
+
 def _space_loss_windows3(a, b, wins, lpips_model, weights, g, need, gb=None):
     """The three nested attention windows of image_loss_tsa with every image pass merged (dge_loss_reduce3, dge_crop_pool_multi,
     dge_space_loss_bwd3): `g` (or None) is WRITTEN with the weighted sum of the windows' gradients; need[i] False leaves window i
@@ -132,22 +148,46 @@ def _space_loss_windows3(a, b, wins, lpips_model, weights, g, need, gb=None):
     k2 = (C.c_int * (2 * nw))(*(ks * 2))
     check(L.dge_crop_pool_multi(srcs, dsts, w2, k2, 2 * nw, B * Cc, H, W, _stream()), "dge_crop_pool_multi")
     sts = []
+    # The windows are independent from here to the join below, and their LPIPS launches are small (conv3 - conv5 on 16^2 .. 64^2
+    # features: 256 - 1152 workgroups, one or two per CU, each a serial weight stream): on one stream they run one after the
+    # other on a half-empty chip.  Each window gets its own stream (forked off the caller's, joined before the results are
+    # read); the first call stays on one stream (it fills the LPIPS weight-pack cache), so does the deterministic mode (its
+    # slot workspace belongs to one stream at a time).
+    main = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+    # (the stream switches cost ~1 ms of host time per step: taken where the GPU work hides them - >= 4 Mpixel per call - or
+    #  where the host is out of the picture, i.e. while a hipGraph is being captured)
+    fork = (main is not None and lpips_model is not None and nw > 1 and _WINDOW_STREAMS and not ops.is_deterministic()
+            and getattr(lpips_model, "_streams_warm", False)
+            and (B * H * W >= (4 << 20) or torch.cuda.is_current_stream_capturing()))
+    side = _side_streams(dev, nw - 1) if fork else []
     for i, win in enumerate(wins):
         y0, x0, h, w = win
         ap, bp, k = aps[i], bps[i], ks[i]
         hp, wp = h // k, w // k
         ng = g is not None and need[i]
-        dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if ng else None
-        check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(pack[i, 8:40]), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
-        st = dict(win=win, pk=pack[i], k=k, npool=float(B * Cc * hp * wp) * world, n=float(B * Cc * h * w) * world, ap=ap, bp=bp,
-                  dmap=dmap, g_lp=None, lp=None, ng=ng)
-        if lpips_model is not None:
-            lp, st["g_lp"] = lpips_model.value_and_grad(ap, bp, need_grad=ng)
-            if world > 1:
-                check(L.dge_axpy_scalar(_p(lp), None, _p(pack[i, 40:41]), 1, 1.0 / world, 0, _stream()), "dge_axpy_scalar")
-                lp = pack[i, 40:41]
-            st["lp"] = lp
+        strm = side[i - 1] if (fork and i > 0) else None
+        if strm is not None:
+            strm.wait_stream(main)
+        with (torch.cuda.stream(strm) if strm is not None else contextlib.nullcontext()):
+            dmap = torch.empty((3, B, Cc, hp, wp), dtype=torch.float32, device=dev) if ng else None
+            check(L.dge_ssim_fwd(_p(ap), _p(bp), _p(pack[i, 8:40]), _p(dmap), B * Cc, hp, wp, _stream()), "dge_ssim_fwd")
+            st = dict(win=win, pk=pack[i], k=k, npool=float(B * Cc * hp * wp) * world, n=float(B * Cc * h * w) * world, ap=ap, bp=bp,
+                      dmap=dmap, g_lp=None, lp=None, ng=ng)
+            if lpips_model is not None:
+                lp, st["g_lp"] = lpips_model.value_and_grad(ap, bp, need_grad=ng)
+                if world > 1:
+                    check(L.dge_axpy_scalar(_p(lp), None, _p(pack[i, 40:41]), 1, 1.0 / world, 0, _stream()), "dge_axpy_scalar")
+                    lp = pack[i, 40:41]
+                st["lp"] = lp
+        if strm is not None:            # results allocated on the side stream are read (and freed) under the caller's stream
+            for t in (dmap, st["g_lp"], st["lp"]):
+                if t is not None:
+                    t.record_stream(main)
         sts.append(st)
+    for strm in side:
+        main.wait_stream(strm)
+    if lpips_model is not None:
+        lpips_model._streams_warm = True
     if gb is not None:
         gb.reduce(pack)
     outs, gps = [], []
