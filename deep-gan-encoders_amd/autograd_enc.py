@@ -10,11 +10,54 @@ def _ver(w):
     return (w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
 
 
+def _is_bwd_mode(mode):
+    return (mode & 0xff) in (ops.PACK_DGRAD, ops.PACK_UPFOLD_DGRAD, ops.PACK_SG1_UP_DGRAD, ops.PACK_UPT2D_DGRAD)
+
+
+def _stale(cache, only_bwd=False):
+    return [(k, e) for k, e in cache.items() if isinstance(k, tuple) and len(k) == 3 and isinstance(e, list) and _ver(e[2]) != e[0]
+            and (not only_bwd or _is_bwd_mode(k[1]))]
+
+
+def _refresh(cache, stale, which):
+    """One launch for all of `stale`; a descriptor table (device scratch) per kind of refresh, so that the two alternating sets of
+    a step (everything / data-gradient copies only) each find their table already uploaded (a hipGraph capture cannot upload)."""
+    key = ("_pack_scratch", which)
+    cache[key] = ops.pack_conv_weights_multi([(e[2].detach(), k[1], k[2], 1.0, e[1]) for k, e in stale], cache.get(key))
+    for k, e in stale:
+        e[0] = _ver(e[2])
+
+
+def refresh_packs(module):
+    """Refreshes every stale packed copy of the module's conv weights now (on the current stream): EAlignStep runs this beside the
+    generator's first pass at the start of an iteration instead of in front of the encoder's first conv."""
+    cache = module.__dict__.get("_pack_cache")
+    if cache:
+        stale = _stale(cache)
+        if stale:
+            _refresh(cache, stale, "all")
+
+
+def prime_pack_tables(module):
+    """EAlignStep.capture, between the eager warm-up and the capture: uploads the descriptor table of the all-copies refresh (a
+    capture cannot upload; a single warm-up iteration has only used the data-gradient table) and leaves every copy marked stale,
+    so that the captured iteration re-packs exactly as a steady-state iteration does."""
+    cache = module.__dict__.get("_pack_cache")
+    if cache:
+        stale = _stale(cache)
+        if stale:
+            _refresh(cache, stale, "all")
+            for _, e in stale:
+                e[0] = None
+
+
 def _packed(cache, conv, dtype, mode, hw=None):
     """Packed copy of a conv weight, rebuilt when the parameter was updated in place.  An optimizer step makes EVERY copy of
-    the module stale at once: the first stale hit refreshes all of them in one launch (ops.pack_conv_weights_multi) - in
-    place, the consumers of the old values are earlier on the same stream.  `hw`: resolution the conv runs at (the
-    low-resolution blocks keep their copies in fragment order for csrc/conv_small.hip)."""
+    the module stale at once: the first stale hit of a FORWARD copy refreshes all of them in one launch
+    (ops.pack_conv_weights_multi) - in place, the consumers of the old values are earlier on the same stream; the first stale
+    hit of a data-gradient copy (the second backward of an E_align step, after the first optimizer step) refreshes the
+    data-gradient copies only - the forward copies would be stale again before their next use.  `hw`: resolution the conv runs
+    at (the low-resolution blocks keep their copies in fragment order for csrc/conv_small.hip)."""
     w = conv.weight
     if hw is not None:
         mode = ops.pack_mode_for(w, mode, hw, hw, dtype)
@@ -26,11 +69,8 @@ def _packed(cache, conv, dtype, mode, hw=None):
     if hit is None:
         cache[key] = [ver, ops.pack_conv_weight(w, mode, dtype, 1.0), w]
         return cache[key][1]
-    stale = [(k, e) for k, e in cache.items() if isinstance(k, tuple) and len(k) == 3 and isinstance(e, list) and _ver(e[2]) != e[0]]
-    cache["_pack_scratch"] = ops.pack_conv_weights_multi([(e[2].detach(), k[1], k[2], 1.0, e[1]) for k, e in stale],
-                                                         cache.get("_pack_scratch"))
-    for k, e in stale:
-        e[0] = _ver(e[2])
+    bwd = _is_bwd_mode(mode)
+    _refresh(cache, _stale(cache, only_bwd=bwd), "bwd" if bwd else "all")
     return cache[key][1]
 
 

@@ -290,6 +290,8 @@ class EAlignStep:
                 self._graph_inputs(self._g_iter); self._g_iter += 1
                 self.step(0, z=self._g_z)
         torch.cuda.current_stream().wait_stream(side)
+        from .autograd_enc import prime_pack_tables
+        prime_pack_tables(self.E)
         self._graph = torch.cuda.CUDAGraph()
         self._graph_inputs(self._g_iter); self._g_iter += 1
         with torch.cuda.graph(self._graph):
@@ -352,8 +354,22 @@ class EAlignStep:
             zg = self.gen.draw(iteration, B * self.world, self.dev) if big else torch.randn(B * self.world, self.z_dim)
             z = zg[self.rank * B:(self.rank + 1) * B]
         z = self._upload(z)
+        # the re-pack of the encoder's conv weights (stale since the last optimizer step) beside the generator's first pass:
+        # an HBM-bound copy next to small-grid low-resolution layers; joined in front of the encoder
+        pack_side = None
+        if (self.dev.type == "cuda" and not ops.is_deterministic() and E.__dict__.get("_pack_cache")
+                and (B * imgs_px(G) >= (4 << 20) or torch.cuda.is_current_stream_capturing())):
+            from .autograd_enc import refresh_packs
+            if getattr(self, "_pack_stream", None) is None:
+                self._pack_stream = torch.cuda.Stream(device=self.dev)
+            pack_side, main = self._pack_stream, torch.cuda.current_stream(self.dev)
+            pack_side.wait_stream(main)
+            with torch.cuda.stream(pack_side):
+                refresh_packs(E)
         with torch.no_grad():
             imgs1, w1 = self.gen.sample(z, gen_noises[0])
+        if pack_side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(pack_side)
         if noises is None and self.reference_noise:
             from .autograd_enc import draw_noises
             noises = [n.to(self.dev) for n in draw_noises(E, B, imgs1.shape[2], "cpu")]
@@ -387,6 +403,12 @@ class EAlignStep:
         self.last = dict(imgs1=imgs1, imgs2=det(imgs2), w1=det(w1), w2=det(w2), const2=det(const2), loss_tsa=loss_tsa.detach(),
                          info_img=info_img, loss_w=loss_w.detach(), info_w=info_w)
         return self.last
+
+
+def imgs_px(G):
+    """pixels of one generated image (resolution attribute of the generator families; 0 when unknown)"""
+    r = getattr(G, "resolution", None) or getattr(G, "img_size", None) or 0
+    return int(r) * int(r)
 
 
 def build_models(img_size=1024, start_features=16, compute_dtype="bf16", device="cuda", lpips=True, seed=0,

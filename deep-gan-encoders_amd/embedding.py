@@ -60,6 +60,8 @@ class EmbedStep:
                 self._graph_inputs()
                 self.step(self._g_imgs1, noises)
         torch.cuda.current_stream().wait_stream(side)
+        from .autograd_enc import prime_pack_tables
+        prime_pack_tables(self.E)             # (the all-copies descriptor table must be on the device before the capture)
         self._graph = torch.cuda.CUDAGraph()
         self._graph_inputs()
         with torch.cuda.graph(self._graph):
