@@ -11,6 +11,8 @@ images reproduce a single-process run at batch N*B.
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -357,7 +359,7 @@ class EAlignStep:
         # the re-pack of the encoder's conv weights (stale since the last optimizer step) beside the generator's first pass:
         # an HBM-bound copy next to small-grid low-resolution layers; joined in front of the encoder
         pack_side = None
-        if (self.dev.type == "cuda" and not ops.is_deterministic() and E.__dict__.get("_pack_cache")
+        if (self.dev.type == "cuda" and _SIDE_STREAMS and not ops.is_deterministic() and E.__dict__.get("_pack_cache")
                 and (B * imgs_px(G) >= (4 << 20) or torch.cuda.is_current_stream_capturing())):
             from .autograd_enc import refresh_packs
             if getattr(self, "_pack_stream", None) is None:
@@ -403,6 +405,9 @@ class EAlignStep:
         self.last = dict(imgs1=imgs1, imgs2=det(imgs2), w1=det(w1), w2=det(w2), const2=det(const2), loss_tsa=loss_tsa.detach(),
                          info_img=info_img, loss_w=loss_w.detach(), info_w=info_w)
         return self.last
+
+
+_SIDE_STREAMS = os.environ.get("DGE_SIDE_STREAMS", "1") != "0"
 
 
 def imgs_px(G):

@@ -108,7 +108,8 @@ def _space_loss_windows(a, b, wins, image_space, lpips_model, weights, g_outs, a
     return [_window_finish(a, b, st, image_space, weights[i], g_outs[i], accumulate, world) for i, st in enumerate(sts)]
 
 
-_WINDOW_STREAMS = os.environ.get("DGE_WINDOW_STREAMS", "1") != "0"
+# DGE_SIDE_STREAMS=0: everything on the caller's stream (PMC counter collection serialises kernels; profiles of single stages)
+_WINDOW_STREAMS = os.environ.get("DGE_WINDOW_STREAMS", "1") != "0" and os.environ.get("DGE_SIDE_STREAMS", "1") != "0"
 _SIDE = {}
 
 
@@ -179,8 +180,16 @@ def _space_loss_windows3(a, b, wins, lpips_model, weights, g, need, gb=None):
                     check(L.dge_axpy_scalar(_p(lp), None, _p(pack[i, 40:41]), 1, 1.0 / world, 0, _stream()), "dge_axpy_scalar")
                     lp = pack[i, 40:41]
                 st["lp"] = lp
+            # the window's pooled-image gradient (SSIM + LPIPS; neither needs the global sums) in the window's stream too
+            st["gp"] = None
+            if ng:
+                gp = torch.empty_like(bp)
+                check(L.dge_ssim_bwd(_p(ap), _p(bp), _p(dmap), _p(gp), B * Cc, hp, wp, -1.0 / st["npool"], 0, _stream()), "dge_ssim_bwd")
+                if st["g_lp"] is not None:
+                    check(L.dge_axpy_scalar(_p(st["g_lp"]), None, _p(gp), gp.numel(), 2.0 / world, 1, _stream()), "dge_axpy_scalar")
+                st["gp"] = gp
         if strm is not None:            # results allocated on the side stream are read (and freed) under the caller's stream
-            for t in (dmap, st["g_lp"], st["lp"]):
+            for t in (dmap, st["g_lp"], st["lp"], st["gp"]):
                 if t is not None:
                     t.record_stream(main)
         sts.append(st)
@@ -192,15 +201,7 @@ def _space_loss_windows3(a, b, wins, lpips_model, weights, g, need, gb=None):
         gb.reduce(pack)
     outs, gps = [], []
     for i, st in enumerate(sts):
-        gp = None
-        if st["ng"]:
-            bp = st["bp"]
-            gp = torch.empty_like(bp)
-            check(L.dge_ssim_bwd(_p(st["ap"]), _p(bp), _p(st["dmap"]), _p(gp), B * Cc, bp.shape[2], bp.shape[3], -1.0 / st["npool"], 0,
-                                 _stream()), "dge_ssim_bwd")
-            if st["g_lp"] is not None:
-                check(L.dge_axpy_scalar(_p(st["g_lp"]), None, _p(gp), gp.numel(), 2.0 / world, 1, _stream()), "dge_axpy_scalar")
-        gps.append(gp)
+        gps.append(st["gp"])
         out8 = torch.empty(8, dtype=torch.float32, device=dev)
         check(L.dge_space_loss_finalize(_p(pack[i, 0:8]), _p(pack[i, 8:40]), _p(st["lp"]), _p(out8), st["n"], st["npool"], 1, _stream()),
               "dge_space_loss_finalize")

@@ -8,6 +8,9 @@
 # TCC_EA0_WRREQ x 64 B gives 537 MB, profiles/r02_conv_stream_pmc_32x32_1024.txt).
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
+# one stream: counter collection serialises kernels (a step with its side streams did not finish under --pmc), and the stage
+# tables want every launch at its isolated duration
+export DGE_SIDE_STREAMS=0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-synthesis --no-extras"
 for c in FETCH_SIZE WRITE_SIZE; do

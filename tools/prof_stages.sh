@@ -1,6 +1,9 @@
 #!/bin/bash
 # per-stage kernel tables of the headline step:  tools/prof_stages.sh <out-name>  -> gpurun_out/<out-name>.txt
 cd /tmp && export TMPDIR=/tmp
+# one stream: counter collection serialises kernels (a step with its side streams did not finish under --pmc), and the stage
+# tables want every launch at its isolated duration
+export DGE_SIDE_STREAMS=0
 R=${GRAFT_REPO_ROOT:-/root/repo}
 name=$1
 rm -rf /tmp/prof_$name
