@@ -141,6 +141,7 @@ __device__ __forceinline__ void conv_epilogue_tr(const ConvParams& p, f32x16_t (
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN, int OPT = 0>
 struct ConvCfg {
     static constexpr int N1 = (OPT >> 1) & 1;                // single-phase noise tile (launch is not in up mode)
+    static constexpr int NB2 = (OPT >> 2) & 1;               // weight ring 2 deep: with N1 the 64-wide tile fits three workgroups per CU
     static constexpr int BM = TH * TW;
     static constexpr int WTM = BM / WM, WTN = BN / WN;
     static constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -165,7 +166,7 @@ struct ConvCfg {
     // short (6-12 MFMAs per wave): there the serial K loop is bound by the L2 latency of the weight stream, so the ring
     // takes the whole LDS (one workgroup per CU) and runs up to 5 stages ahead.
     static constexpr int NBUF_SMALL = cmin(6, cmax(2, (150 * 1024 - A_BUFS * A_BYTES - N_BYTES) / B_BYTES));
-    static constexpr int NBUF = (BM <= 128) ? NBUF_SMALL : ((A_BUFS * A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2);
+    static constexpr int NBUF = NB2 ? 2 : ((BM <= 128) ? NBUF_SMALL : ((A_BUFS * A_BYTES + 4 * B_BYTES + N_BYTES <= 80 * 1024) ? 4 : 2));
     static constexpr int DPW = B_PIECES / 4;                   // DMA instructions every wave issues per stage (floor)
     static constexpr int LDS_BYTES = cmax(A_BUFS * A_BYTES + NBUF * B_BYTES, E_BYTES) + N_BYTES;
     static constexpr int NA_ITEMS = HH * HW * CH, NA_PER = (NA_ITEMS + 255) / 256;
@@ -180,8 +181,8 @@ struct ConvCfg {
 };
 
 template <typename T, int TH, int TW, int BN, int KC, int KS, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN, (MODE >> 3) & 3>::MINW)) void conv_igemm_kernel(ConvParams p) {
-    using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN, (MODE >> 3) & 3>;
+__global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN, ((MODE >> 3) & 3) | (((MODE >> 6) & 1) << 2)>::MINW)) void conv_igemm_kernel(ConvParams p) {
+    using C = ConvCfg<T, TH, TW, BN, KC, KS, WM, WN, ((MODE >> 3) & 3) | (((MODE >> 6) & 1) << 2)>;
     // MODE: bits 0-1 = epilogue mode (conv_epilogue.h); bit 2 = in_t2d (phase-form adjoint of the up layer: compile time, because a
     // run-time choice between two unrolled step sequences in the main loop doubled its code and spilled the accumulators);
     // bits 3-4 = ConvCfg OPT
@@ -496,7 +497,14 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
             if (da) DGE_GO(17); else if (tr) DGE_GO(48); else DGE_GO(16);      // (offered without up mode only: single-phase noise tile)
         }
         else if constexpr (sizeof(T) == 2 && TH == 16 && TW == 16 && BN == 64) {
-            if (da) DGE_GO(1);
+            // Three workgroups per CU (single-phase noise tile + 2-deep weight ring: 52 KB of LDS, 156 VGPRs) for the forward
+            // epilogues, where that saves a round of workgroups (LPIPS conv3 / conv4 on the crops: 576 - 768 tiles are two rounds
+            // of 512 slots but one of 768; measured 256->256 @48^2 59.9 -> 54.4 us, 128->64 @256^2 89.7 -> 82.0 us).  Grids that
+            // fit either way keep the 4-deep ring (512->512 @32^2: 81.9 vs 84.8 us); the data-gradient epilogues need 193
+            // registers (spilled at three waves per SIMD: 621 -> 713 us on the layer-15 adjoint) and stay at two.
+            const bool w3 = !p.up && !da && !(p.dbg & 256) && (grid + 767) / 768 < (grid + 511) / 512;
+            if (w3) { if (tr) DGE_GO(112); else DGE_GO(80); }
+            else if (da) DGE_GO(1);
             else if (tr) DGE_GO(32);
             else DGE_GO(0);
         }
