@@ -70,6 +70,8 @@ __device__ __forceinline__ unsigned lds_offset_of(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
 
+extern "C" int dge_get_deterministic(void);        // capi.hip
+
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int rup(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -132,6 +134,120 @@ __device__ __forceinline__ void conv_epilogue_tr(const ConvParams& p, f32x16_t (
                 if (n0 + 16 + 8 * kh < p.Cout) *(uint4*)(yp + 16) = pack16(v1, (T*)nullptr);
             }
         });
+    });
+}
+
+// ---- transposed-accumulator epilogue of the data-gradient launches (kernel MODE 33 = bit 5 + epilogue mode 1): residual addend,
+// dot products against dot_src (sum f*d, sum f per (sample, channel); the per-channel scale is applied after them, as in
+// conv_epilogue), ReLU backward of the layer below (mask_relu), statistics of results that include the addend.  A lane owns two
+// runs of 8 channels of one pixel, so addend / dot_src arrive as the same 16-byte vectors the result leaves in, requested one
+// tile ahead; the 2 x 16 per-lane sums are reduced over the 32 pixel lanes by halving (16 cross-lane moves per sum instead of
+// 80) and leave as ONE atomic instruction per sum and N tile.  Launches with bias / noise / activation / up / prep / the
+// deterministic mode keep conv_epilogue.
+__device__ __forceinline__ float tr_lane_reduce16(float (&v)[16], int lane) {
+    // v[q] summed over the 32 lanes of a half wave; returns the total of value q = 8 b4 + 4 b3 + 2 b2 + b1 (b = bits of lane & 31)
+    const bool b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    float w[8], x[4], y[2];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const float snd = b4 ? v[q] : v[q + 8]; w[q] = (b4 ? v[q + 8] : v[q]) + __shfl_xor(snd, 16, 64); }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const float snd = b3 ? w[q] : w[q + 4]; x[q] = (b3 ? w[q + 4] : w[q]) + __shfl_xor(snd, 8, 64); }
+#pragma unroll
+    for (int q = 0; q < 2; q++) { const float snd = b2 ? x[q] : x[q + 2]; y[q] = (b2 ? x[q + 2] : x[q]) + __shfl_xor(snd, 4, 64); }
+    const float snd = b1 ? y[0] : y[1];
+    float z = (b1 ? y[1] : y[0]) + __shfl_xor(snd, 2, 64);
+    z += __shfl_xor(z, 1, 64);
+    return z;
+}
+template <typename T, class C, int TH, int TW, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_tr_da(const ConvParams& p, f32x16_t (&acc)[C::MT][C::NT], int b, int x0, int y0, int bn0,
+                                                    int vbid, int wave, int lane) {
+    static_assert(sizeof(T) == 2, "bf16 storage");
+    const int wm = wave / WN, wn = wave % WN;
+    const int px = lane & 31, kh = lane >> 5;
+    T* __restrict__ Yb = (T*)p.y + (size_t)b * p.H * p.W * p.Cout;           // in-image offsets fit 32 bits
+    const T* __restrict__ ADDb = p.addend ? (const T*)p.addend + (size_t)b * p.H * p.W * p.Cout : nullptr;
+    const T* __restrict__ DOTb = p.dot_src ? (const T*)p.dot_src + (size_t)b * p.H * p.W * p.Cout : nullptr;
+    const bool dot = DOTb != nullptr, add = ADDb != nullptr;
+    const bool stats = p.stats != nullptr;
+    float* __restrict__ STATS = stats ? p.stats + (size_t)(vbid % p.stats_slots) * p.B * p.Cout * 2 : nullptr;
+    constexpr int NTILE = C::MT * C::NT;
+    uint4 pd[2][2], pa[2][2];
+    auto tile_off = [&](int i, int j, bool& ok) {
+        const int m = wm * C::WTM + i * 32 + px;
+        const int gy = y0 + m / TW, gx = x0 + m % TW;
+        ok = (gy < p.H) & (gx < p.W);
+        return (gy * p.W + gx) * p.Cout + bn0 + wn * C::WTN + j * 32 + 8 * kh;
+    };
+    auto issue = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int j = t / C::MT, i = t % C::MT;
+        bool ok;
+        const int off = tile_off(i, j, ok);
+        const int c0 = bn0 + wn * C::WTN + j * 32 + 8 * kh;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            pd[t & 1][h] = make_uint4(0, 0, 0, 0); pa[t & 1][h] = make_uint4(0, 0, 0, 0);
+            if (ok && c0 + 16 * h < p.Cout) {
+                if (dot) pd[t & 1][h] = *(const uint4*)(DOTb + off + 16 * h);
+                if (add) pa[t & 1][h] = *(const uint4*)(ADDb + off + 16 * h);
+            }
+        }
+    };
+    issue(std::integral_constant<int, 0>{});
+    StaticFor<C::NT>::run([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int n0 = bn0 + wn * C::WTN + j * 32;
+        float sc[16], ps0[16], ps1[16];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int c0 = n0 + 16 * h + 8 * kh;
+            const bool cv = c0 < p.Cout && n0 < p.Ntot_valid;
+#pragma unroll
+            for (int e4 = 0; e4 < 2; e4++) {
+                float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (p.out_scale && cv) s4 = *(const float4*)(p.out_scale + (size_t)b * p.Cout + c0 + e4 * 4);
+                const int r = 8 * h + 4 * e4;
+                sc[r] = s4.x; sc[r + 1] = s4.y; sc[r + 2] = s4.z; sc[r + 3] = s4.w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ps0[r] = 0.f; ps1[r] = 0.f; }
+        StaticFor<C::MT>::run([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int t = j * C::MT + i;
+            if constexpr (t + 1 < NTILE) issue(std::integral_constant<int, t + 1>{});
+            bool ok;
+            const int off = tile_off(i, j, ok);
+            const f32x16_t a = acc[i][j];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float f[8], d[8], ad[8];
+                unpack16(pd[t & 1][h], d, (T*)nullptr);
+                unpack16(pa[t & 1][h], ad, (T*)nullptr);
+                const bool rv = ok && (n0 + 16 * h + 8 * kh < p.Cout) && (n0 < p.Ntot_valid);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float v = rv ? a[8 * h + e] * p.gain : 0.f;
+                    if (dot) { ps0[8 * h + e] = fmaf(v, d[e], ps0[8 * h + e]); ps1[8 * h + e] += v; }
+                    v *= sc[8 * h + e];
+                    if (add) v = fmaf(p.add_scale, ad[e], v);
+                    if (dot && p.mask_relu) v = d[e] > 0.f ? v : 0.f;
+                    if (!dot && stats && rv) { ps0[8 * h + e] += v; ps1[8 * h + e] = fmaf(v, v, ps1[8 * h + e]); }
+                    f[e] = v;
+                }
+                if (rv) *(uint4*)(Yb + off + 16 * h) = pack16(f, (T*)nullptr);
+            }
+        });
+        if (stats) {
+            const float t0 = tr_lane_reduce16(ps0, lane), t1 = tr_lane_reduce16(ps1, lane);
+            const int q = (lane >> 1) & 15;                                   // value index this lane's totals belong to
+            const int c = n0 + 16 * (q >> 3) + 8 * kh + (q & 7);
+            if (!(lane & 1) && c < p.Cout && n0 < p.Ntot_valid) {
+                atomicAdd(STATS + ((size_t)b * p.Cout + c) * 2, t0);
+                atomicAdd(STATS + ((size_t)b * p.Cout + c) * 2 + 1, t1);
+            }
+        }
     });
 }
 
@@ -464,7 +580,8 @@ __global__ __launch_bounds__(256, (ConvCfg<T, TH, TW, BN, KC, KS, WM, WN, ((MODE
     }
     // ---------------------------------------------------------------- epilogue (conv_epilogue.h)
     // LDS is re-used as the transpose buffer from here (all reads done: barrier above); the noise tile at its end stays valid
-    if constexpr (TR) conv_epilogue_tr<T, C, TH, TW, BN, WM, WN>(p, acc, ldsN, b, x0, y0, bn0, wave, lane);
+    if constexpr (TR && EMODE == 1) conv_epilogue_tr_da<T, C, TH, TW, BN, WM, WN>(p, acc, b, x0, y0, bn0, vbid, wave, lane);
+    else if constexpr (TR) conv_epilogue_tr<T, C, TH, TW, BN, WM, WN>(p, acc, ldsN, b, x0, y0, bn0, wave, lane);
     else conv_epilogue<T, C, TH, TW, BN, WM, WN, 256, EMODE>(p, acc, lds, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i, wave, lane, tid, true);
 }
 
@@ -483,8 +600,11 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
     const bool da = p.addend || p.dot_src;
     // transposed accumulators + direct stores (conv_epilogue_tr): the plain forward epilogue on the 16 x 16 / 32 x 16 pixel tiles
     const bool tr = sizeof(T) == 2 && !da && !p.prep && !p.stats && !p.up && !p.in_t2d && !(p.dbg & 64);
+    // ... and the data-gradient epilogue in the same layout (conv_epilogue_tr_da), 64-wide tiles
+    const bool tr_da = sizeof(T) == 2 && da && !p.prep && !p.up && !p.in_t2d && !p.bias && !p.noise && p.act == DGE_ACT_NONE &&
+                       !dge_get_deterministic() && !(p.dbg & 512);
     dge_note_kernel("conv_igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s%s%s", sizeof(T) == 2 ? "bf16" : "f32", TH, TW, BN, KC, KS, WM, WN,
-                    p.in_t2d ? "+t2d" : "", p.prep ? "+prep" : "", (tr && KS == 3 && TW == 16 && (TH == 16 || TH == 32)) ? "+tr" : "");
+                    p.in_t2d ? "+t2d" : "", p.prep ? "+prep" : "", ((tr && KS == 3 && TW == 16 && (TH == 16 || TH == 32)) || (tr_da && KS == 3 && TH == 16 && TW == 16 && BN == 64)) ? "+tr" : "");
     DGE_CHECK(!p.prep || (KS == 3 && p.dot_src), "conv: prep is offered for 3x3 data-gradient launches only");
 #define DGE_GO(MODE) hipLaunchKernelGGL((conv_igemm_kernel<T, TH, TW, BN, KC, KS, WM, WN, MODE>), dim3((unsigned)grid), dim3(256), 0, s, p)
     if constexpr (KS == 3) {
@@ -504,6 +624,7 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
             // registers (spilled at three waves per SIMD: 621 -> 713 us on the layer-15 adjoint) and stay at two.
             const bool w3 = !p.up && !da && !(p.dbg & 256) && (grid + 767) / 768 < (grid + 511) / 512;
             if (w3) { if (tr) DGE_GO(112); else DGE_GO(80); }
+            else if (tr_da) DGE_GO(33);
             else if (da) DGE_GO(1);
             else if (tr) DGE_GO(32);
             else DGE_GO(0);

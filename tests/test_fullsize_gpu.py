@@ -408,7 +408,7 @@ def test_data_gradient_fullsize(cof, cif, R, B, k, oscale, kernel):
 
 
 UP_DGRADS = [
-    (64, 32, 512, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>"),        # layer15: gradient [B,1024,1024,32] -> [B,512,512,64]
+    (64, 32, 512, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>+tr"),     # layer15 (data-gradient epilogue on transposed accumulators): gradient [B,1024,1024,32] -> [B,512,512,64]
     (128, 64, 256, 8, "conv_igemm<bf16,16,16,128,32,3,2,2>"),      # layer13
     # phase form (dge_fir_t2d + in_t2d: FIR^T to the t grid, then 4 of 9 taps) - what the synthesis backward runs from 32^2 up
     (64, 32, 512, 8, "conv_igemm<bf16,16,16,64,32,3,4,1>+t2d"),    # layer15
@@ -663,6 +663,39 @@ def test_transposed_accumulator_epilogue_ragged_shapes(H, W, B, cin, cout):
         assert _one_rounding(_nchw(y, b), CR.modconv(*a, q=CR.bf16_round)) <= 0, b
         ref = F.relu(F.conv2d(_nchw(x, b), wq, bias.cpu(), padding=1))
         assert _one_rounding(_nchw(y2, b), ref) <= 0, b
+
+
+@pytest.mark.parametrize("H,W,B,cg,cx", [(120, 130, 3, 128, 72), (100, 90, 3, 256, 136), (150, 141, 4, 64, 40)])
+def test_transposed_accumulator_data_gradient_ragged_shapes(H, W, B, cg, cx):
+    """conv_epilogue_tr_da (kernel MODE 33: data-gradient epilogue on transposed accumulators, 64-wide N tiles) on geometry where the
+    tiles hang over both image edges and the last N tile is partly empty: (a) the generator's chain form - per-channel scale after
+    the dot products, residual addend, sums (f*dot_src, f) per (sample, channel) into statistics slots (stylegan2_generator.py:
+    855-922 differentiated); (b) the LPIPS form - tap-gradient addend + ReLU backward of the layer below (mask_relu).  Every sample
+    and pixel compared with the exact adjoint of the conv."""
+    from dge_amd import ops
+    g = _gen(8800 + H + W + cx)
+    gy = _act(B, H, W, cg, g)
+    xin = _act(B, H, W, cx, g)
+    add = _act(B, H, W, cx, g)
+    w = (_wgt(cg, cx, 3, g) / math.sqrt(9 * cx)).to(torch.bfloat16).float()        # forward weight [Cout = cg, Cin = cx]
+    wd = ops.pack_conv_weight(w, ops.PACK_DGRAD, ops.BF16, 1.0)
+    s = 1.0 + 0.3 * torch.randn(B, cx, device=DEV, generator=g)
+    dots = ops.SlotStats(B, cx, DEV)
+    ya = ops.conv2d(gy, wd, cx, 3, out_scale=s, addend=add, add_scale=1.0, stats=dots, dot_src=xin)
+    assert _kernel() == "conv_igemm<bf16,16,16,64,32,3,4,1>+tr", _kernel()
+    yb = ops.conv2d(gy, wd, cx, 3, addend=add, relu_mask=xin)
+    assert _kernel() == "conv_igemm<bf16,16,16,64,32,3,4,1>+tr", _kernel()
+    tot = dots.buf.sum(0).cpu().double()
+    for b in range(B):
+        raw = CR.conv_dgrad(_nchw(gy, b), w.cpu())
+        ref = raw * s[b].cpu()[None, :, None, None] + _nchw(add, b)
+        assert _one_rounding(_nchw(ya, b), ref) <= 0, b
+        xb = _nchw(xin, b).double()
+        rd = raw.double()
+        assert _stat_close(tot[b, :, 0], (rd * xb).sum((2, 3))[0], (rd * xb).abs().sum((2, 3))[0]) < 1e-5
+        assert _stat_close(tot[b, :, 1], rd.sum((2, 3))[0], rd.abs().sum((2, 3))[0]) < 1e-5
+        refb = (raw + _nchw(add, b)) * (_nchw(xin, b) > 0)
+        assert _one_rounding(_nchw(yb, b), refb) <= 0, b
 
 
 PREP_CASES = [
