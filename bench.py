@@ -287,7 +287,7 @@ def main():
         # HBM bytes per launch from the PMC counters: collected offline by tools/pmc_traffic.sh (separate rocprofv3 --pmc
         # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
         traffic, tsrc = None, None
-        tname = next((t for t in ("r03_conv_traffic_v6.json", "r03_conv_traffic_v5.json", "r03_conv_traffic_v3.json", "r03_conv_traffic_v2.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r01_conv_traffic.json")
+        tname = next((t for t in ("r03_conv_traffic_v6.json", "r03_conv_traffic_v3.json", "r03_conv_traffic_v2.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r01_conv_traffic.json")
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and a.mtype == 2 and a.img_size == 1024 and a.batch == 8 and a.dtype == "bf16":
             with open(tpath) as f:

@@ -22,6 +22,10 @@ extern "C" int dge_version(void) { return 100; }
 static std::vector<void (*)(const DgeDet*)>& det_setters() { static std::vector<void (*)(const DgeDet*)> v; return v; }
 void dge_det_register(void (*setter)(const DgeDet*)) { det_setters().push_back(setter); }
 static DgeDet g_det_host = {0, nullptr, nullptr, 0, 0};
+int dge_det_upload_failed = 0;
+bool dge_det_fits(long long ndomains, long long nslots, long long L) {
+    return !g_det_host.enabled || (ndomains * nslots * L <= g_det_host.ws_floats && ndomains <= (long long)g_det_host.ncounters);
+}
 extern "C" int dge_set_deterministic(int on) {
     if (on && !g_det_host.ws) {
         const long long nf = 32LL << 20;                 // 32 Mi floats = 128 MiB (largest need measured: 4.7 Mi, the weight-gradient slabs)
@@ -34,8 +38,9 @@ extern "C" int dge_set_deterministic(int on) {
     }
     g_det_host.enabled = on ? 1 : 0;
     DGE_CHECK(hipDeviceSynchronize() == hipSuccess, "set_deterministic: device synchronisation failed");   // no launch straddles the switch
+    dge_det_upload_failed = 0;
     for (auto f : det_setters()) f(&g_det_host);
-    DGE_CHECK(hipDeviceSynchronize() == hipSuccess, "set_deterministic: state upload failed");
+    DGE_CHECK(hipDeviceSynchronize() == hipSuccess && !dge_det_upload_failed, "set_deterministic: state upload failed");
     return 0;
 }
 extern "C" int dge_get_deterministic(void) { return g_det_host.enabled; }

@@ -94,8 +94,12 @@ struct DgeDet {
 };
 static __device__ DgeDet g_det = {0, nullptr, nullptr, 0, 0};
 void dge_det_register(void (*setter)(const DgeDet*));
+extern int dge_det_upload_failed;                 // capi.hip: set by a translation unit whose copy of the state could not be uploaded
+// host-side capacity check of a deterministic-mode launch (ndomains x nslots vectors of L floats, one counter per domain):
+// launchers refuse instead of letting det_slot() trap on the device.  True when the mode is off.
+bool dge_det_fits(long long ndomains, long long nslots, long long L);
 static void dge_det_set_this_tu(const DgeDet* v) {
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_det), v, sizeof(DgeDet), 0, hipMemcpyHostToDevice);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_det), v, sizeof(DgeDet), 0, hipMemcpyHostToDevice) != hipSuccess) dge_det_upload_failed = 1;
 }
 namespace { struct DgeDetReg { DgeDetReg() { dge_det_register(&dge_det_set_this_tu); } }; static DgeDetReg dge_det_reg_instance; }
 

@@ -597,6 +597,10 @@ static int launch_cfg(const ConvParams& p0, hipStream_t s) {
 
     // epilogue mode (conv_epilogue.h): 0 plain, 1 addend / dot_src with prefetch, 2 = 1 + fused tail backward (3x3 only).
     // The f32 parity path has no prefetch, so its mode 1 is its mode 0 with the stages enabled: it always takes >= 1.
+    if (p.stats && !p.up)          // deterministic mode: (sample, N tile) domains x (pixel tile, wave row) slots x (sum, sum2) per channel
+        DGE_CHECK(dge_det_fits((long long)p.B * ntiles, (long long)p.tiles_x * p.tiles_y * WM, BN * 2),
+                  "conv: the deterministic-mode workspace is too small for this launch (%d x %d x %d floats); reduce the batch", p.B * ntiles,
+                  p.tiles_x * p.tiles_y * WM, BN * 2);
     const bool da = p.addend || p.dot_src;
     // transposed accumulators + direct stores (conv_epilogue_tr): the plain forward epilogue on the 16 x 16 / 32 x 16 pixel tiles
     const bool tr = sizeof(T) == 2 && !da && !p.prep && !p.stats && !p.up && !p.in_t2d && !(p.dbg & 64);

@@ -218,6 +218,9 @@ int dge_conv_small_launch(const ConvParams& p0, hipStream_t s) {
     p.tiles_y = (p.H + TH - 1) / TH;
     const long grid = (long)p.tiles_x * p.tiles_y * p.B * (p.Ntot / BN);
     DGE_CHECK(grid > 0 && grid < (1L << 31), "conv_small: bad grid");
+    if (p.stats && !p.up)
+        DGE_CHECK(dge_det_fits((long long)p.B * (p.Ntot / BN), (long long)p.tiles_x * p.tiles_y * 2, BN * 2),
+                  "conv_small: the deterministic-mode workspace is too small for this launch");
     dge_note_kernel("conv_small<bf16,8,8,64,%d>%s", p.Cin, p.prep ? "+prep" : "");
     const int mode = p.prep ? 2 : ((p.addend || p.dot_src) ? 1 : 0);      // epilogue mode (conv_epilogue.h)
 #define DGE_GO(KQ, MODE) hipLaunchKernelGGL((conv_small_kernel<KQ, MODE>), dim3((unsigned)grid), dim3(512), 0, s, p)
