@@ -634,7 +634,8 @@ def test_low_resolution_kernel_ragged_shapes(H, W, B):
         assert _one_rounding(_nchw(gx, b), refg) <= 0, b
 
 
-@pytest.mark.parametrize("H,W,B,cin,cout", [(150, 141, 2, 64, 136), (120, 130, 3, 128, 72), (200, 170, 2, 32, 24), (100, 90, 2, 256, 256)])
+@pytest.mark.parametrize("H,W,B,cin,cout", [(150, 141, 2, 64, 136), (120, 130, 3, 128, 72), (200, 170, 2, 32, 24), (100, 90, 2, 256, 256),
+                                            (100, 90, 4, 48, 72)])      # (Cin = 48: the 16-element K chunk instantiations)
 def test_transposed_accumulator_epilogue_ragged_shapes(H, W, B, cin, cout):
     """conv_igemm with the weights as the MFMA A operand and direct 16-byte stores (conv_epilogue_tr, kernel MODE bit 5) on
     geometry where the 16 x 16 tiles hang over both image edges and the last N tile is partly empty (channel tails of 8),
@@ -655,6 +656,7 @@ def test_transposed_accumulator_epilogue_ragged_shapes(H, W, B, cin, cout):
     y = ops.conv2d(x, wp, cout, 3, in_scale=s, out_scale=d, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU,
                    gain=math.sqrt(2.0))
     assert _kernel().startswith("conv_igemm<bf16,16,16,") and _kernel().endswith("+tr"), _kernel()
+    assert ("3,4,1>" in _kernel() or "3,2,2>" in _kernel()) and (",16,3," in _kernel()) == (cin % 32 != 0), _kernel()
     y2 = ops.conv2d(x, wp, cout, 3, bias=bias, act=ops.ACT_RELU)
     assert _kernel().endswith("+tr"), _kernel()
     wq = CR.bf16_round(w.cpu() * wscale)
@@ -665,7 +667,7 @@ def test_transposed_accumulator_epilogue_ragged_shapes(H, W, B, cin, cout):
         assert _one_rounding(_nchw(y2, b), ref) <= 0, b
 
 
-@pytest.mark.parametrize("H,W,B,cg,cx", [(120, 130, 3, 128, 72), (100, 90, 3, 256, 136), (150, 141, 4, 64, 40)])
+@pytest.mark.parametrize("H,W,B,cg,cx", [(120, 130, 3, 128, 72), (100, 90, 3, 256, 136), (150, 141, 4, 64, 40), (100, 90, 4, 48, 72)])
 def test_transposed_accumulator_data_gradient_ragged_shapes(H, W, B, cg, cx):
     """conv_epilogue_tr_da (kernel MODE 33: data-gradient epilogue on transposed accumulators, 64-wide N tiles) on geometry where the
     tiles hang over both image edges and the last N tile is partly empty: (a) the generator's chain form - per-channel scale after
@@ -681,10 +683,11 @@ def test_transposed_accumulator_data_gradient_ragged_shapes(H, W, B, cg, cx):
     wd = ops.pack_conv_weight(w, ops.PACK_DGRAD, ops.BF16, 1.0)
     s = 1.0 + 0.3 * torch.randn(B, cx, device=DEV, generator=g)
     dots = ops.SlotStats(B, cx, DEV)
+    kname = "conv_igemm<bf16,16,16,64,%d,3,4,1>+tr" % (32 if cg % 32 == 0 else 16)
     ya = ops.conv2d(gy, wd, cx, 3, out_scale=s, addend=add, add_scale=1.0, stats=dots, dot_src=xin)
-    assert _kernel() == "conv_igemm<bf16,16,16,64,32,3,4,1>+tr", _kernel()
+    assert _kernel() == kname, _kernel()
     yb = ops.conv2d(gy, wd, cx, 3, addend=add, relu_mask=xin)
-    assert _kernel() == "conv_igemm<bf16,16,16,64,32,3,4,1>+tr", _kernel()
+    assert _kernel() == kname, _kernel()
     tot = dots.buf.sum(0).cpu().double()
     for b in range(B):
         raw = CR.conv_dgrad(_nchw(gy, b), w.cpu())
