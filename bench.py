@@ -287,7 +287,8 @@ def main():
         # HBM bytes per launch from the PMC counters: collected offline by tools/pmc_traffic.sh (separate rocprofv3 --pmc
         # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
         traffic, tsrc = None, None
-        tname = next((t for t in ("r03_conv_traffic_v6.json", "r03_conv_traffic_v3.json", "r03_conv_traffic_v2.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r01_conv_traffic.json")
+        # (this round's file only: a file of an earlier round describes other kernels - without it the field is null)
+        tname = "r04_conv_traffic.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and a.mtype == 2 and a.img_size == 1024 and a.batch == 8 and a.dtype == "bf16":
             with open(tpath) as f:
@@ -295,7 +296,7 @@ def main():
             traffic, tsrc = tj["traffic_bytes_per_launch"], "offline PMC (tools/pmc_traffic.sh, separate rocprofv3 --pmc passes over this command), profiles/" + tname
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": tsrc,
-                           "kernel": "conv_igemm_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + upconv_fir_kernel + upconv_stream_kernel (all conv launches of a step: dge_conv2d, dge_upconv_fir)",
+                           "kernel": "conv_igemm_kernel<*> + conv_pp_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + upconv_fir_kernel + upconv_stream_kernel (all conv launches of a step: dge_conv2d, dge_conv_pp, dge_upconv_fir)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "timing": "HIP events around every conv launch of two extra steps run on ONE stream (the timed steps above overlap the three loss windows and the weight re-pack on side streams)",
                            "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,

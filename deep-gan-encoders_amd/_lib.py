@@ -26,6 +26,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ConvPPDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w_pp", C.c_void_p), ("y", C.c_void_p), ("w_bstride", C.c_longlong),
+        ("out_scale", C.c_void_p), ("bias", C.c_void_p), ("noise", C.c_void_p), ("noise_w", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
+        ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int), ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float),
+    ]
+
+
 class S2GradEntry(C.Structure):
     _fields_ = [("P", C.c_void_p), ("st", C.c_void_p), ("d", C.c_void_p), ("s", C.c_void_p), ("bias", C.c_void_p), ("wsq", C.c_void_p),
                 ("gs", C.c_void_p), ("wstyle", C.c_void_p),
@@ -146,6 +155,9 @@ SIGNATURES = {
     "dge_in_bwd_fused": [_P, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dge_sum_slots_planar_multi": [C.POINTER(SumPlanarEntry), _I, _P],
     "dge_heads_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],
+    "dge_conv_pp_supported": [_I, _I, _I, _I, _I, _I],
+    "dge_pack_conv_pp": [_P, _P, _I, _I, _F, _P, _P, _F, _I, _I, _P],
+    "dge_conv_pp": [C.POINTER(ConvPPDesc), _P],
 }
 
 _lib = None

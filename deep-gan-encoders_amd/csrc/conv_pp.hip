@@ -1,0 +1,487 @@
+// conv_pp: 3x3 stride-1 convolution of the MFMA-bound layers (C >= 128, 32^2 .. 256^2) as a ping-pong implicit GEMM.
+//
+// Reference math: ModulateConvBlock.forward, stride-1 branch, in the reference's own FUSED-modulation form
+// (model/stylegan2_generator.py:858-875: the style multiplies the weight, the demodulation divides it, one weight per sample;
+// :898-904 conv; :911-921 noise, bias, lrelu*sqrt2), and the plain conv + bias + ReLU layers of LPIPS' VGG16.
+//
+// Why a second kernel next to conv_igemm: that one runs a workgroup as ONE serial pipeline (stage -> barrier -> stage) and gets
+// its overlap from a second resident workgroup; measured 0.40-0.49 matrix-pipe utilisation with 38 % of wave time parked at
+// s_waitcnt / barriers.  Here the two waves of a SIMD are given opposite roles on purpose:
+//   * 8 waves = two groups of four (wave w and w+4 share a SIMD).  In every PHASE one group issues the 16 MFMAs of a cluster
+//     (one tap of one 32-channel K chunk: 128 pixels x 64 channels per wave) while the other group reads the 12 fragments of
+//     ITS next cluster from LDS and issues the LDS-DMAs of the stages to come; one s_barrier per phase flips the roles.
+//   * every operand reaches LDS by DMA, nothing is staged through registers: the halo tile (18 x 34 pixels x 64 B per chunk)
+//     through a buffer descriptor of the sample's image (out-of-range lanes write zeros = the zero padding), the weights as a
+//     linear copy of an LDS image prepared once per forward by dge_pack_conv_pp - per SAMPLE when the layer is modulated (style,
+//     demodulation and activation gain folded into the weight).  No VALU instruction touches an operand on its way in.
+//   * the weight ring is a whole K chunk deep (9 taps: slot = tap, compile time), requested 8 clusters ahead; the next halo
+//     tile is requested during the first taps of the current chunk; arrival is counted with s_waitcnt vmcnt(N).
+//   * LDS images are "part-major" per 1 KiB DMA piece (16 rows x 4 parts of 16 B: byte = part*256 + row*16), which makes every
+//     ds_read_b128 fragment read conflict free for any 32 consecutive pixels / the permuted weight rows without an XOR swizzle.
+//   * accumulators are transposed (weights = MFMA A operand, rows permuted by tr_chan_of_row): a lane ends with two runs of 8
+//     channels of one pixel and stores 16-byte vectors straight from registers.
+#include <type_traits>
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/dge_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+namespace {
+
+struct PPParams {
+    const bf16_t* x; const bf16_t* w; bf16_t* y;
+    long long w_bstride;                      // bytes between the samples' weight images (0 = shared)
+    const float* bias; const float* noise; const float* noise_w;
+    int B, H, W, Cin, Cout;
+    int noise_bstride, noise_w_stride, act;
+    float bias_scale, gain;
+    int tiles_x, tiles_y, ntn, nchunks;
+    int dbg;
+};
+
+__device__ __forceinline__ unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+// raw buffer descriptor (gfx9 layout): base, stride 0, num_records in bytes, DATA_FORMAT = 32
+__device__ __forceinline__ rsrc_t make_rsrc(unsigned long long base, unsigned bytes) {
+    rsrc_t r;
+    r[0] = rfl((unsigned)base); r[1] = rfl((unsigned)(base >> 32) & 0xffffu); r[2] = rfl(bytes); r[3] = 0x00020000u;
+    return r;
+}
+// one 1 KiB piece, global -> LDS, through the image descriptor: lanes whose offset is out of range write zeros
+__device__ __forceinline__ void dma_buf(unsigned voff, rsrc_t rs, unsigned soff, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(voff), "s"(m0v), "s"(rs), "s"(soff) : "memory");
+}
+// one 1 KiB piece of the weight image: wave-uniform 64-bit base + lane*16
+__device__ __forceinline__ void dma_lin(unsigned voff, unsigned long long sbase, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(m0v) : "memory");
+}
+__device__ __forceinline__ int tr_chan_of_row(int m) {
+    const int j = m >> 3, k = (m >> 2) & 1, i = m & 3;
+    return 16 * (j >> 1) + 8 * k + 4 * (j & 1) + i;
+}
+
+// development aid (DGE_CONV_DBG bit 8 = 256): shader-clock stamps of workgroup 0, waves 0 and 4, read back by dge_dbg_pp_prof
+__device__ long long g_pp_prof[2][1024];
+
+// LDS map: halo buffer 0 | weight slots 0-2 | halo buffer 1 (at 64 KiB: the buffer toggle is one XOR) | weight slots 3-8
+constexpr int H1_OFF = 65536, WLO_OFF = 40960, WHI_OFF = 106496, PP_LDS = WHI_OFF + 6 * 8192;   // + 8 x 1 KiB of epilogue staging
+__host__ __device__ constexpr int wslot_off(int t) { return t < 3 ? WLO_OFF + t * 8192 : WHI_OFF + (t - 3) * 8192; }
+
+// Persistent: workgroup i (XCD i % 8) walks the tiles x*Tx + j + k*(workgroups per XCD) of its XCD's contiguous range; the cluster
+// stream runs on across tile seams (the last chunk of a tile requests the first halo tile and the first weights of the next one),
+// so a seam costs the epilogue's VALU work and the issue of its stores, not a drain + refill of the pipeline.  vmcnt counts
+// stores too, in issue order: the first seven waits after an epilogue that issued all of its 16 stores allow 16 more outstanding
+// operations (a wave with out-of-image rows issues fewer stores and keeps the strict counts, i.e. waits for them).
+// The DMAs of a cluster are issued between the MFMAs of its COMPUTE phase (two short asm statements with precomputed scalar
+// operands: in front of the LOAD phase they were on the critical path of the phase).  In the workgroup's last chunk the
+// requests go on as dummies (own halo tile, own first weight slots: nobody reads them) so that the wait counts stay the same.
+template <int PT, bool DBG, bool NWC>
+__global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
+    constexpr int TH = 4 * PT, HH = TH + 2, HPIX = HH * 34, HPIECES = (HPIX + 15) / 16, HPW = (HPIECES + 7) / 8;
+    static_assert(HPW * 8 * 1024 <= WLO_OFF && HPW <= 8, "halo tile (incl. the all-zero pieces of the waves that have one piece less)");
+    constexpr int VM_B = 6;                                              // W pieces a wave has issued after the one cluster c + 1 needs
+    constexpr int VM_T8 = (VM_B + 3 - HPW) < VM_B ? (VM_B + 3 - HPW) : VM_B;   // ... after its last halo piece of the chunk
+    constexpr int NSTORE = 4 * PT;                                       // stores of one epilogue, per wave
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS + 8192];
+    const unsigned lds0 = lds_off(lds);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = rfl(tid >> 6), g = wave >> 2, q = wave & 3;
+    // the parameters are re-read from the kernel argument segment where they are used (tile seams, epilogue): held in SGPRs for
+    // the whole kernel they push the main loop's scalars into spills
+    typedef const __attribute__((address_space(4))) PPParams* kparg_t;       // (the struct is the kernel's only argument: offset 0)
+    const kparg_t kp = (kparg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    auto P = [&]() { kparg_t r = kp; asm volatile("" : "+s"(r)); return r; };
+    const int nchunks = p_.nchunks;
+    const int dbg = DBG ? p_.dbg : 0;
+    int pidx = 0;
+    auto stamp = [&](int tag) {
+        if constexpr (DBG) {
+            if ((dbg & 256) && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && pidx < 1022) {
+                g_pp_prof[g][pidx++] = ((long long)tag << 48) | (long long)(__builtin_readcyclecounter() & 0xffffffffffffll);
+                g_pp_prof[g][1023] = pidx;
+            }
+        }
+    };
+    // tiles of this workgroup
+    const int ntiles = p_.tiles_x * p_.tiles_y * p_.B * p_.ntn;
+    const int per_xcd = (ntiles + 7) >> 3, stride = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int tile = xcd * per_xcd + (blockIdx.x >> 3);
+    const int tile_end = min((xcd + 1) * per_xcd, ntiles);
+    if (tile >= tile_end) return;                                        // (whole workgroup)
+
+    int x0, y0, b, nt;                         // tile whose accumulators are live
+    rsrc_t rs;                                 // image descriptor the halo DMAs read through (the NEXT tile's during a tile's last chunk)
+    unsigned hoff[HPW];
+    unsigned long long wt;                     // weight image of the current tile (+ this wave's piece)
+    auto decode = [&](int id, int& tx0, int& ty0, int& tb, int& tnt) {
+        const auto p = P();
+        tnt = id % p->ntn; id /= p->ntn;                                // N tiles of one pixel tile back to back: the halo stays in L2
+        tx0 = (id % p->tiles_x) * 32; id /= p->tiles_x;
+        ty0 = (id % p->tiles_y) * TH; tb = id / p->tiles_y;
+    };
+    auto halo_src = [&](int tx0, int ty0, int tb) {
+        const auto p = P();
+        const unsigned long long xb = (unsigned long long)p->x + (unsigned long long)tb * p->H * p->W * p->Cin * 2ull;
+        rs = make_rsrc(xb, (unsigned)(p->H * p->W * p->Cin * 2));
+        // source offsets of this wave's halo pieces (piece P = wave + 8k: 16 pixels x 4 parts, lane = part*16 + pixel)
+        // (recomputed per tile on purpose: hoisted out of the tile loop these lane constants are spilled around it)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+#pragma unroll
+        for (int k = 0; k < HPW; k++) {
+            const int Pc = wave + 8 * k;
+            const int hp = Pc * 16 + (lane_o & 15), qd = lane_o >> 4;
+            const int hr = hp / 34, hx = hp - hr * 34;
+            const int gy = ty0 + hr - 1, gx = tx0 + hx - 1;
+            const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->H) & ((unsigned)gx < (unsigned)p->W);
+            hoff[k] = ok ? (unsigned)(((gy * p->W + gx) * p->Cin + qd * 8) * 2) : 0x80000000u;
+        }
+    };
+    auto wbase = [&](int tb, int tnt) {
+        const auto p = P();
+        return (unsigned long long)p->w + (unsigned long long)tb * p->w_bstride + (unsigned long long)tnt * nchunks * (9ull * 8192) +
+               (unsigned)wave * 1024u;
+    };
+    const unsigned wvoff = lane * 16;
+    const unsigned wm0 = rfl(lds0 + wave * 1024);                       // this wave's piece of a weight slot / halo buffer 0
+
+    // fragment addresses.  Pixels: halo row rr of this wave's strip, column l31 + dx -> linear halo index hp, image position
+    // (hp >> 4) KiB + (hp & 15) * 16 + part * 256 with part = 2 ks + kh (ks = 32-byte K slice: +512 as an immediate).
+    unsigned atab[PT + 2][3];
+#pragma unroll
+    for (int rr = 0; rr < PT + 2; rr++)
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int hp = (PT * q + rr) * 34 + l31 + dx;
+            atab[rr][dx] = (unsigned)((hp >> 4) * 1024 + (hp & 15) * 16 + kh * 256);
+        }
+    unsigned wlo, whi;
+    {
+        const int n = tr_chan_of_row(l31);
+        const unsigned wl = (unsigned)(g * 4096 + (n >> 4) * 1024 + (n & 15) * 16 + kh * 256);
+        wlo = WLO_OFF + wl; whi = WHI_OFF + wl;
+    }
+    f32x16_t acc[PT][2];
+
+    // ---- prologue: halo tile of chunk 0 of the first tile, weights of its clusters 0 .. 7
+    decode(tile, x0, y0, b, nt);
+    halo_src(x0, y0, b);
+    wt = wbase(b, nt);
+    StaticFor<HPW>::run([&](auto kc_) { constexpr int k = decltype(kc_)::value; dma_buf(hoff[k], rs, 0u, rfl(wm0 + k * 8192)); });
+    StaticFor<8>::run([&](auto cc) { constexpr int c = decltype(cc)::value; dma_lin(wvoff, wt + c * 8192ull, rfl(wm0 + wslot_off(c))); });
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    if (g == 1) asm volatile("s_barrier" ::: "memory");                 // group 1 runs one phase behind group 0
+    unsigned long long wptr = wt + 8 * 8192ull;                         // weight piece the next request reads (cluster c + 8)
+    unsigned hm0 = wm0 + H1_OFF;                                        // this wave's first piece of the halo buffer being FILLED
+
+    // One chunk = 9 clusters; ONE instance of this body in the kernel (copies of it at the merge points of the tile loop cost the
+    // register allocator 250-600 spilled registers).  relaxed: first chunk after an epilogue with all NSTORE stores in the queue;
+    // final: the workgroup's last chunk (no closing barrier).  wnext0: the piece requested after this chunk's tap-0 request (in a
+    // tile's last chunk the stream jumps to the next tile's image); hsoff: channel byte offset of the halo tile requested here.
+    auto chunk = [&](bool relaxed, bool final, unsigned long long wnext0, unsigned hsoff) {
+        StaticFor<9>::run([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            constexpr int dy = t / 3, dx = t % 3;
+            // ------------------------------------------------ LOAD phase of cluster c0 + t
+            stamp(1);
+            uint4 xa[PT][2], wa[2][2];
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) xa[i][ks] = *(const uint4*)(lds + atab[i + dy][dx] + ks * 512);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++)
+                    wa[j][ks] = *(const uint4*)(lds + (t < 3 ? wlo + t * 8192 : whi + (t - 3) * 8192) + j * 2048 + ks * 512);
+            __builtin_amdgcn_sched_barrier(0);
+            // the weights of the NEXT cluster (and, at the last tap, the next halo tile) have landed - for this wave's pieces;
+            // the barrier makes it true for everybody's.  lgkmcnt(0): this phase's reads are done before anyone overwrites.
+            constexpr int VM_N = t == 8 ? VM_T8 : VM_B;
+            if (t < 7 && relaxed) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_N) : "memory");
+            stamp(2);
+            if (!(t == 8 && final && g == 1)) asm volatile("s_barrier" ::: "memory");
+            stamp(3);
+            __builtin_amdgcn_sched_barrier(0);
+            // ------------------------------------------------ COMPUTE phase: 16 MFMAs, the cluster's DMA requests in their shadow
+            if (!(DBG && (dbg & 2))) {
+                __builtin_amdgcn_s_setprio(1);
+                StaticFor<16>::run([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, ks = m >> 3, i = (m >> 1) & (PT - 1), j = m & 1;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wa[j][ks], *(const bf16x8_t*)&xa[i][ks],
+                                                                        acc[i][j], 0, 0, 0);
+                    if constexpr (m == 3 && t < HPW) {      // halo piece t of the tile the next chunk reads
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(DBG && (dbg & 4)))
+                            asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                         :: "v"(hoff[t]), "s"(hm0), "s"(rs), "s"(hsoff), "i"(t * 8192) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (m == 7) {                  // weight piece of cluster c + 8 into the slot cluster c - 1 was read from
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(DBG && (dbg & 1)))
+                            asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                                         :: "v"(wvoff), "s"(wm0), "s"(wptr), "i"(wslot_off((t + 8) % 9)) : "memory");
+                        wptr = t == 0 ? wnext0 : wptr + 8192ull;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                if constexpr (t < HPW)
+                    asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                 :: "v"(hoff[t]), "s"(hm0), "s"(rs), "s"(hsoff), "i"(t * 8192) : "memory");
+                asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                             :: "v"(wvoff), "s"(wm0), "s"(wptr), "i"(wslot_off((t + 8) % 9)) : "memory");
+                wptr = t == 0 ? wnext0 : wptr + 8192ull;
+#pragma unroll
+                for (int i = 0; i < PT; i++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) asm volatile("" :: "v"(xa[i][ks].x), "v"(xa[i][ks].w), "v"(wa[i & 1][ks].x), "v"(wa[i & 1][ks].w));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(4);
+            if (!(t == 8 && final)) asm volatile("s_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        hm0 ^= (unsigned)H1_OFF;                   // the next chunk reads the buffer just filled and fills the other one
+#pragma unroll
+        for (int rr = 0; rr < PT + 2; rr++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) atab[rr][dx] ^= (unsigned)H1_OFF;
+    };
+
+    // Additive terms of the epilogue (noise * strength + bias, stylegan2_generator.py:911-920, times the activation gain) are the
+    // INITIAL value of the accumulators: their loads are issued at the start of the previous tile's epilogue and consumed at its
+    // end, so no memory latency sits between a tile's last MFMA and its stores, and the epilogue is lrelu + pack + store.
+    struct AddT { float ab[2][16], anw[NWC ? 2 : 1][NWC ? 16 : 1], anz[PT]; };
+    auto add_load = [&](AddT& A, int tx0, int ty0, int tb, int tnt) {
+        float (&ab)[2][16] = A.ab; float (&anw)[NWC ? 2 : 1][NWC ? 16 : 1] = A.anw; float (&anz)[PT] = A.anz;
+        const auto p = P();
+        const float bg = p->bias_scale * p->gain;
+        const int gx = tx0 + l31;
+#pragma unroll
+        for (int i = 0; i < PT; i++) {
+            const int gy = ty0 + PT * q + i;
+            anz[i] = (p->noise && gy < p->H && gx < p->W) ? p->noise[(size_t)tb * p->noise_bstride + gy * p->W + gx] : 0.f;
+        }
+        if constexpr (!NWC) anw[0][0] = p->noise ? p->noise_w[0] * p->gain : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e4 = 0; e4 < 2; e4++) {
+                    const int c0 = tnt * 128 + g * 64 + j * 32 + 8 * kh + 16 * h + 4 * e4, r = 8 * h + 4 * e4;
+                    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p->bias) b4 = *(const float4*)(p->bias + c0);
+                    ab[j][r] = b4.x * bg; ab[j][r + 1] = b4.y * bg; ab[j][r + 2] = b4.z * bg; ab[j][r + 3] = b4.w * bg;
+                    if constexpr (NWC) {
+                        float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p->noise) n4 = *(const float4*)(p->noise_w + c0);
+                        anw[j][r] = n4.x * p->gain; anw[j][r + 1] = n4.y * p->gain; anw[j][r + 2] = n4.z * p->gain; anw[j][r + 3] = n4.w * p->gain;
+                    }
+                }
+    };
+    auto add_apply = [&](const AddT& A) {
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(A.anw[NWC ? j : 0][NWC ? r : 0], A.anz[i], A.ab[j][r]);
+    };
+    { AddT A; add_load(A, x0, y0, b, nt); add_apply(A); }
+
+    // epilogue staging: lanes write (pixel, 16-byte piece) of 16 pixels x 32 channels, read back lane-linear = 4 lanes per pixel
+    const unsigned est_w = PP_LDS + wave * 1024 + (l31 & 15) * 64 + kh * 16, est_r = PP_LDS + wave * 1024 + lane * 16;
+
+    bool relaxed = false;                       // an epilogue's NSTORE stores of this wave are in the queue
+    for (;;) {
+        const int next = tile + stride;
+        const bool has_next = next < tile_end;
+        int nx0 = 0, ny0 = 0, nb_ = 0, nnt = 0;
+        unsigned long long nwt = 0;
+        for (int kc = 0; kc < nchunks; kc++) {
+            const bool lastc = kc == nchunks - 1;
+            unsigned long long wnext0 = wptr + 8192ull;
+            unsigned hsoff = (unsigned)(kc + 1) * 64u;
+            if (lastc && has_next) {           // the stream runs on into the next tile: its halo source, its weight image
+                decode(next, nx0, ny0, nb_, nnt);
+                halo_src(nx0, ny0, nb_);
+                nwt = wbase(nb_, nnt);
+                wnext0 = nwt;
+                hsoff = 0u;
+            } else if (lastc) {                // dummies from here on (own image: valid addresses, slots nobody reads any more)
+                wnext0 = wt;
+                hsoff = 0u;
+            }
+            chunk(kc == 0 && relaxed, lastc && !has_next, wnext0, hsoff);
+        }
+        // ------------------------------------------------------------ epilogue: activation, pack, 64-byte runs through LDS
+        stamp(5);
+        if (DBG && (dbg & 8)) {
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][15]));
+        } else {
+            AddT A;                              // (consumed after the stores below; at the last tile: a second copy of its own, unused)
+            add_load(A, has_next ? nx0 : x0, has_next ? ny0 : y0, has_next ? nb_ : b, has_next ? nnt : nt);
+            const auto p = P();
+            const float slope = p->act == DGE_ACT_LRELU ? 0.2f : (p->act == DGE_ACT_RELU ? 0.f : 1.f);
+            const int cb2 = p->Cout * 2;
+            // Stores go through a descriptor of the sample's output image: out-of-image lanes carry an out-of-range offset and are
+            // dropped by the hardware, rows below the image use an empty descriptor - every wave issues exactly NSTORE stores
+            // (the wait counts of the next tile's first chunk rely on it).  A lane's accumulators are two 16-byte runs of one
+            // pixel; stored as they are, one instruction touches 32 lines with 32 bytes each and the store path pays per line.
+            const unsigned ybytes = (unsigned)(p->H * p->W) * (unsigned)cb2;
+            bf16_t* ybase = p->y + (size_t)b * p->H * p->W * p->Cout;
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, ybytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_0 = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, 0, 0x00020000);
+            unsigned voff[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int px = 16 * r + (lane >> 2);
+                voff[r] = (x0 + px < p->W) ? (unsigned)(px * cb2 + (lane & 3) * 16) : 0x80000000u;
+            }
+#pragma unroll
+            for (int i = 0; i < PT; i++) {
+                const int gy = y0 + PT * q + i;
+                const unsigned rowoff = (unsigned)((gy * p->W + x0) * cb2 + (nt * 128 + g * 64) * 2);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const f32x16_t a = acc[i][j];
+                    float v0[8], v1[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) { v0[r] = fmaxf(a[r], a[r] * slope); v1[r] = fmaxf(a[8 + r], a[8 + r] * slope); }
+                    const uint4 o0 = pack16(v0, (bf16_t*)nullptr), o1 = pack16(v1, (bf16_t*)nullptr);
+                    if (DBG && (dbg & 128)) { asm volatile("" :: "v"(o0.x), "v"(o0.w), "v"(o1.x), "v"(o1.w)); continue; }
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        if ((l31 >> 4) == r) {
+                            *(uint4*)(lds + est_w) = o0;
+                            *(uint4*)(lds + est_w + 32) = o1;
+                        }
+                        // lanes exchange data through LDS inside one wave: without the wave-level fence + barrier the compiler may
+                        // (and did) run the read of the lanes that do not write in this round ahead of the other lanes' writes
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const u32x4_t o = *(const u32x4_t*)(lds + est_r);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (gy < p->H) __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff[r], rowoff + j * 64, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b128(o, rs_0, voff[r], 0, 0);
+                    }
+                }
+            }
+            relaxed = !(DBG && ((dbg & 16) || (dbg & 128)));
+            add_apply(A);
+        }
+        stamp(6);
+        if (!has_next) break;
+        tile = next; x0 = nx0; y0 = ny0; b = nb_; nt = nnt; wt = nwt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the dummy requests of the last chunk target this workgroup's LDS
+}
+
+// LDS image of the weights, one 8 KiB block per (sample, N tile, K chunk, tap): 8 pieces of 16 rows, part-major inside a piece.
+// mode 0: GEMM (n, k) = (out channel, in channel), tap as stored.  mode 1 (data gradient): (n, k) = (in channel, out channel) of
+// the forward weight, taps flipped.  in_scale [nb][K] / out_scale [nb][N] (either may be null) and `gain` are folded:
+// W' = bf16((w*wscale) * (in_scale[k] * (gain*out_scale[n])))  - the association oracle/conv_ref.py:modconv_folded uses.
+__global__ void conv_pp_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int K, float wscale,
+                                    const float* __restrict__ in_scale, const float* __restrict__ out_scale, float gain, int nb, int mode) {
+    const int nchunks = K / 32, ntn = N / 128;
+    const long total = (long)nb * ntn * nchunks * 9 * 512;          // 16-byte groups
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        long e = idx;
+        const int r = e % 16; e /= 16;
+        const int qd = e % 4; e /= 4;
+        const int pc = e % 8; e /= 8;
+        const int t = e % 9; e /= 9;
+        const int kc = e % nchunks; e /= nchunks;
+        const int nt = e % ntn;
+        const int b = (int)(e / ntn);
+        const int n = nt * 128 + pc * 16 + r, k0 = kc * 32 + qd * 8;
+        const float on = gain * (out_scale ? out_scale[(size_t)b * N + n] : 1.f);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int k = k0 + j;
+            const float wv = mode == 0 ? w[((size_t)n * K + k) * 9 + t] : w[((size_t)k * N + n) * 9 + (8 - t)];
+            const float m = (in_scale ? in_scale[(size_t)b * K + k] : 1.f) * on;
+            v[j] = (wv * wscale) * m;
+        }
+        *(uint4*)(out + idx * 8) = pack16(v, (bf16_t*)nullptr);
+    }
+}
+
+}  // namespace
+
+// development aid, not part of the C ABI (include/dge_hip.h): copies the stamps of the last DGE_CONV_DBG & 256 launch to the host
+extern "C" int dge_dbg_pp_prof(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_pp_prof), sizeof(long long) * 2048, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+extern "C" int dge_conv_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype) {
+    if (dtype != DGE_BF16 || getenv("DGE_NO_PP")) return 0;
+    if (Cin % 32 != 0 || Cout % 128 != 0 || Cin < 64) return 0;
+    if ((long long)H * W * Cin * 2 >= (1ll << 31)) return 0;
+    // one workgroup per CU and no overlap between tiles: the grid must fill the chip
+    const long tiles = (long)B * ((H + 15) / 16) * ((W + 31) / 32) * (Cout / 128);
+    return tiles >= 256 ? 1 : 0;
+}
+
+extern "C" int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, float wscale, const float* in_scale, const float* out_scale,
+                                float gain, int nb, int mode, hipStream_t s) {
+    DGE_CHECK(w_oihw && out, "pack_conv_pp: null tensor");
+    DGE_CHECK(N % 128 == 0 && K % 32 == 0 && nb >= 1 && (mode == 0 || mode == 1), "pack_conv_pp: N=%d must be a multiple of 128, K=%d of 32", N, K);
+    DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_conv_pp: per-sample copies need a per-sample scale");
+    const long total = (long)nb * 9 * N * K / 8;
+    long grid = (total + 255) / 256; if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode);
+    DGE_LAUNCH_CHECK("pack_conv_pp");
+    return 0;
+}
+
+extern "C" int dge_conv_pp(const dge_conv_pp_desc* d, hipStream_t s) {
+    DGE_CHECK(d && d->x && d->w_pp && d->y, "conv_pp: null tensor");
+    DGE_CHECK(dge_conv_pp_supported(d->B, d->H, d->W, d->Cin, d->Cout, DGE_BF16), "conv_pp: %dx%d Cin=%d Cout=%d B=%d is not a shape dge_conv_pp_supported() accepts",
+              d->H, d->W, d->Cin, d->Cout, d->B);
+    DGE_CHECK(!d->noise || d->noise_w, "conv_pp: noise needs its weight");
+    DGE_CHECK(!d->out_scale, "conv_pp: a per-sample output scale is folded into the weight image (dge_pack_conv_pp), not applied by the launch");
+    DGE_CHECK(d->gain > 0.f, "conv_pp: the gain is folded into scale / noise / bias and must be positive");
+    PPParams p;
+    p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w_pp; p.y = (bf16_t*)d->y;
+    p.w_bstride = d->w_bstride * 2;
+    p.bias = d->bias; p.noise = d->noise; p.noise_w = d->noise_w;
+    p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout;
+    p.noise_bstride = d->noise_batch > 1 ? d->H * d->W : 0; p.noise_w_stride = d->noise_w_per_channel ? 1 : 0; p.act = d->act;
+    p.bias_scale = d->bias_scale; p.gain = d->gain;
+    p.tiles_x = (d->W + 31) / 32; p.tiles_y = (d->H + 15) / 16; p.ntn = d->Cout / 128; p.nchunks = d->Cin / 32;
+    p.dbg = dge_env().conv_dbg;
+    const long tiles = (long)p.tiles_x * p.tiles_y * p.B * p.ntn;
+    // one workgroup per CU (152 KB of LDS each), 32 per XCD; each walks its share of its XCD's tile range
+    int cus = 256;
+    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount / 8 * 8; }
+    const long grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus;
+    dge_note_kernel("conv_pp<bf16,16,32,128>");
+    // NWC: noise weight per channel (model/E/E.py:60-62) instead of StyleGAN2's scalar strength
+    if (p.noise_w_stride) {
+        if (p.dbg) hipLaunchKernelGGL((conv_pp_kernel<4, true, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_pp_kernel<4, false, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    } else {
+        if (p.dbg) hipLaunchKernelGGL((conv_pp_kernel<4, true, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv_pp_kernel<4, false, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    }
+    DGE_LAUNCH_CHECK("conv_pp");
+    return 0;
+}

@@ -5,7 +5,7 @@ import math
 
 import torch
 
-from ._lib import lib, check, ConvDesc, DgeError
+from ._lib import lib, check, ConvDesc, ConvPPDesc, DgeError
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
@@ -402,6 +402,55 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         return None
     if pool_out and pool_mask:
         return out, mask
+    return out
+
+
+def conv_pp_supported(B, H, W, cin, cout, dtype):
+    """True when a 3x3 stride-1 launch of this shape runs on the ping-pong implicit GEMM (csrc/conv_pp.hip: C >= 128 at 64^2 .. 256^2)"""
+    return bool(lib().dge_conv_pp_supported(int(B), int(H), int(W), int(cin), int(cout), int(dtype)))
+
+
+def pack_conv_pp(w, wscale=1.0, in_scale=None, out_scale=None, gain=1.0, dgrad=False, out=None):
+    """LDS image of w [Cout,Cin,3,3] f32 for conv_pp: one shared copy, or - with in_scale [B,K] / out_scale [B,N] - B per-sample copies with
+    style, demodulation and gain folded in (the reference's fused modulation, stylegan2_generator.py:858-875).  dgrad: the copy the
+    data gradient reads ((n, k) = (in, out) channel, taps flipped).  Returns a [nb, 9*N*K] bf16 tensor."""
+    cout, cin = w.shape[0], w.shape[1]
+    N, K = (cin, cout) if dgrad else (cout, cin)
+    nb = 1
+    for t in (in_scale, out_scale):
+        if t is not None:
+            nb = t.shape[0]
+    if out is None:
+        out = torch.empty((nb, 9 * N * K), dtype=torch.bfloat16, device=w.device)
+    check(lib().dge_pack_conv_pp(_f32(w.detach().contiguous()), _p(out), N, K, float(wscale), _f32(in_scale), _f32(out_scale), float(gain),
+                                 nb, 1 if dgrad else 0, _stream()), "dge_pack_conv_pp")
+    return out
+
+
+def conv_pp(x, w_pp, cout, out_scale=None, bias=None, bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, out=None):
+    """x [B,H,W,Cin] bf16 -> y [B,H,W,cout]: 3x3 stride-1 conv with the weights of pack_conv_pp (w_pp.shape[0] = 1: shared, = B: per sample)"""
+    B, H, W, Cin = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device)
+    if w_pp.shape[0] not in (1, B) or w_pp.shape[1] != 9 * Cin * cout or w_pp.dtype != torch.bfloat16:
+        raise DgeError("conv_pp: weight image does not match the launch")
+    d = ConvPPDesc()
+    d.x, d.w_pp, d.y = _p(x), _p(w_pp), _p(out)
+    d.w_bstride = 0 if w_pp.shape[0] == 1 else w_pp.shape[1]
+    d.out_scale, d.bias, d.noise, d.noise_w = _f32(out_scale), _f32(bias), _f32(noise), _f32(noise_w)
+    d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, cout
+    d.noise_batch = 1 if noise is None else noise.shape[0]
+    d.noise_w_per_channel = 0 if (noise_w is None or noise_w.numel() == 1) else 1
+    d.act, d.bias_scale, d.gain = act, bias_scale, gain
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().dge_conv_pp(C.byref(d), _stream()), "dge_conv_pp")
+        e1.record()
+        abytes = sum(t.numel() * t.element_size() for t in (x, out, w_pp))
+        PROFILE.append((e0, e1, 2.0 * 9.0 * Cin * cout * H * W * B, (B, H, W, Cin, cout, 3, False, False), abytes))
+    else:
+        check(lib().dge_conv_pp(C.byref(d), _stream()), "dge_conv_pp")
     return out
 
 

@@ -419,6 +419,37 @@ int dge_upconv_fir(const void* x, const void* w_packed, void* y, const float* in
                    const float* noise, int noise_bstride, const float* noise_w, int noise_w_stride, const float* bias,
                    float bias_scale, float gain, int act, int B, int H, int W, int Cin, int Cout, int dtype, dge_stream_t stream);
 
+/* ---- Ping-pong implicit GEMM for the MFMA-bound 3x3 stride-1 layers (csrc/conv_pp.hip) -----------------------------------
+ * ModulateConvBlock.forward, stride-1 branch, in the reference's FUSED-modulation form (stylegan2_generator.py:858-875: the
+ * style multiplies the weight, the demodulation divides it, one weight per sample; :898-904 conv; :911-921 noise, bias,
+ * lrelu*sqrt2) for the layers with >= 128 output channels at 64^2 .. 256^2, and plain conv + bias + ReLU (LPIPS' VGG16).
+ * dge_pack_conv_pp writes the LDS image the kernel streams: per (sample, 128-wide N tile, 32-channel K chunk, tap) one 8 KiB
+ * block; `nb` = 1 shared copy or B per-sample copies with in_scale [nb][K] / out_scale [nb][N] / gain folded in:
+ * W'[b][n][k] = dtype((w*wscale) * (in_scale[b][k] * (gain*out_scale[b][n]))).  mode 0: (n, k) = (out, in) channel of w_oihw
+ * [N][K][3][3]; mode 1 (data gradient): w_oihw is [K][N][3][3], taps flipped.  9*N*K elements per copy.
+ * dge_conv_pp: y[b] = act(conv3x3(x[b], W'[b]) * m + noise*noise_w*gain + bias*bias_scale*gain), m = out_scale*gain, or 1
+ * when out_scale is NULL (folded weights carry demodulation and gain: `gain` then only multiplies noise and bias).
+ * bf16 only; shapes per dge_conv_pp_supported(). */
+typedef struct dge_conv_pp_desc {
+    const void* x;            /* [B,H,W,Cin] bf16 */
+    const void* w_pp;         /* dge_pack_conv_pp */
+    void* y;                  /* [B,H,W,Cout] bf16 */
+    long long w_bstride;      /* elements between the samples' weight copies (9*Cin*Cout), 0 = one shared copy */
+    const float* out_scale;   /* optional [B,Cout] */
+    const float* bias;        /* optional [Cout] */
+    const float* noise;       /* optional [noise_batch,H,W] */
+    const float* noise_w;     /* [Cout] or [1] */
+    int B, H, W, Cin, Cout;
+    int noise_batch;          /* 1 = shared plane, else B */
+    int noise_w_per_channel;
+    int act;                  /* DGE_ACT_* */
+    float bias_scale, gain;
+} dge_conv_pp_desc;
+int dge_conv_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype);
+int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, float wscale, const float* in_scale, const float* out_scale,
+                     float gain, int nb, int mode, dge_stream_t stream);
+int dge_conv_pp(const dge_conv_pp_desc* d, dge_stream_t stream);
+
 /* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */
 /* pixel-wise feature normalisation over the channel axis of an NHWC tensor (PixelNormLayer :207-216) */
 int dge_pixelnorm_nhwc(const void* x, void* y, long npix, int C, float eps, int dtype, dge_stream_t stream);
