@@ -334,6 +334,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
         } else {
             AddT A;                              // (consumed after the stores below; at the last tile: a second copy of its own, unused)
             add_load(A, has_next ? nx0 : x0, has_next ? ny0 : y0, has_next ? nb_ : b, has_next ? nnt : nt);
+            // Seam choreography: group 0 lets group 1 finish its last cluster (one extra barrier here), then BOTH groups run their
+            // epilogues in the same phase - two waves per SIMD interleave their LDS / store latencies - and group 1 adds its extra
+            // barrier behind the epilogue, which puts it one phase behind group 0 again.  (Serial: 2 x 8.4 k cycles per seam.)
+            if (has_next && g == 0) asm volatile("s_barrier" ::: "memory");
             const auto p = P();
             const float slope = p->act == DGE_ACT_LRELU ? 0.2f : (p->act == DGE_ACT_RELU ? 0.f : 1.f);
             const int cb2 = p->Cout * 2;
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
             }
             relaxed = !(DBG && ((dbg & 16) || (dbg & 128)));
             add_apply(A);
+            if (has_next && g == 1) asm volatile("s_barrier" ::: "memory");
         }
         stamp(6);
         if (!has_next) break;
@@ -397,30 +402,44 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
 // mode 0: GEMM (n, k) = (out channel, in channel), tap as stored.  mode 1 (data gradient): (n, k) = (in channel, out channel) of
 // the forward weight, taps flipped.  in_scale [nb][K] / out_scale [nb][N] (either may be null) and `gain` are folded:
 // W' = bf16((w*wscale) * (in_scale[k] * (gain*out_scale[n])))  - the association oracle/conv_ref.py:modconv_folded uses.
-__global__ void conv_pp_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int K, float wscale,
+// One workgroup per (N tile, K chunk, 16-row piece): its 16 x 32 x 9 source weights are read once, coalesced, into LDS and
+// written out as the nine 1 KiB pieces of every sample's image.
+__global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int K, float wscale,
                                     const float* __restrict__ in_scale, const float* __restrict__ out_scale, float gain, int nb, int mode) {
+    __shared__ float wl[16][32][9 + 1];                              // [row][k][tap] (+1: the tap-strided reads below)
     const int nchunks = K / 32, ntn = N / 128;
-    const long total = (long)nb * ntn * nchunks * 9 * 512;          // 16-byte groups
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-        long e = idx;
-        const int r = e % 16; e /= 16;
-        const int qd = e % 4; e /= 4;
-        const int pc = e % 8; e /= 8;
-        const int t = e % 9; e /= 9;
-        const int kc = e % nchunks; e /= nchunks;
-        const int nt = e % ntn;
-        const int b = (int)(e / ntn);
-        const int n = nt * 128 + pc * 16 + r, k0 = kc * 32 + qd * 8;
-        const float on = gain * (out_scale ? out_scale[(size_t)b * N + n] : 1.f);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int k = k0 + j;
-            const float wv = mode == 0 ? w[((size_t)n * K + k) * 9 + t] : w[((size_t)k * N + n) * 9 + (8 - t)];
-            const float m = (in_scale ? in_scale[(size_t)b * K + k] : 1.f) * on;
-            v[j] = (wv * wscale) * m;
+    int bid = blockIdx.x;
+    const int pc = bid % 8; bid /= 8;
+    const int kc = bid % nchunks;
+    const int nt = bid / nchunks;
+    const int n0 = nt * 128 + pc * 16, k0 = kc * 32;
+    const int tid = threadIdx.x;
+    if (mode == 0) {                       // w[n][k][tap]: per row 288 contiguous floats
+        for (int idx = tid; idx < 16 * 288; idx += 256) {
+            const int r = idx / 288, e = idx - r * 288;
+            wl[r][e / 9][e % 9] = w[((size_t)(n0 + r) * K + k0) * 9 + e] * wscale;
         }
-        *(uint4*)(out + idx * 8) = pack16(v, (bf16_t*)nullptr);
+    } else {                               // w[k][n][8 - tap]: per k 144 contiguous floats
+        for (int idx = tid; idx < 32 * 144; idx += 256) {
+            const int k = idx / 144, e = idx - k * 144;
+            wl[e / 9][k][8 - e % 9] = w[((size_t)(k0 + k) * N + n0) * 9 + e] * wscale;
+        }
+    }
+    __syncthreads();
+    for (int b = blockIdx.y; b < nb; b += gridDim.y) {
+        bf16_t* ob = out + ((((size_t)b * ntn + nt) * nchunks + kc) * 9 * 8 + pc) * 512;       // (elements; tap stride 8 * 512)
+        for (int idx = tid; idx < 9 * 64; idx += 256) {
+            const int t = idx >> 6, qd = (idx >> 4) & 3, r = idx & 15;
+            const float on = gain * (out_scale ? out_scale[(size_t)b * N + n0 + r] : 1.f);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int k = qd * 8 + j;
+                const float m = (in_scale ? in_scale[(size_t)b * K + k0 + k] : 1.f) * on;
+                v[j] = wl[r][k][t] * m;
+            }
+            *(uint4*)(ob + (size_t)t * 8 * 512 + (qd * 16 + r) * 8) = pack16(v, (bf16_t*)nullptr);
+        }
     }
 }
 
@@ -437,7 +456,8 @@ extern "C" int dge_conv_pp_supported(int B, int H, int W, int Cin, int Cout, int
     if ((long long)H * W * Cin * 2 >= (1ll << 31)) return 0;
     // one workgroup per CU and no overlap between tiles: the grid must fill the chip
     const long tiles = (long)B * ((H + 15) / 16) * ((W + 31) / 32) * (Cout / 128);
-    return tiles >= 256 ? 1 : 0;
+    static const int min_tiles = getenv("DGE_PP_MIN_TILES") ? atoi(getenv("DGE_PP_MIN_TILES")) : 256;
+    return tiles >= min_tiles ? 1 : 0;
 }
 
 extern "C" int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, float wscale, const float* in_scale, const float* out_scale,
@@ -445,9 +465,8 @@ extern "C" int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, fl
     DGE_CHECK(w_oihw && out, "pack_conv_pp: null tensor");
     DGE_CHECK(N % 128 == 0 && K % 32 == 0 && nb >= 1 && (mode == 0 || mode == 1), "pack_conv_pp: N=%d must be a multiple of 128, K=%d of 32", N, K);
     DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_conv_pp: per-sample copies need a per-sample scale");
-    const long total = (long)nb * 9 * N * K / 8;
-    long grid = (total + 255) / 256; if (grid > 65536) grid = 65536;
-    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode);
+    const long grid = (long)(N / 128) * (K / 32) * 8;
+    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)nb), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode);
     DGE_LAUNCH_CHECK("pack_conv_pp");
     return 0;
 }

@@ -123,6 +123,16 @@ class LPIPS(nn.Module):
             self._cache[key] = hit
         return hit[1]
 
+    def _packed_pp(self, ci):
+        """shared weight image of conv ci for ops.conv_pp (cached on the weight's version)"""
+        w = self.convs[ci].weight
+        ver = (w._version, w.data_ptr())
+        hit = self._cache.get(("pp", ci))
+        if hit is None or hit[0] != ver:
+            hit = (ver, ops.pack_conv_pp(w.detach().float(), 1.0))
+            self._cache[("pp", ci)] = hit
+        return hit[1]
+
     def _scaling_host(self):
         """Host copies of the ScalingLayer constants (kernel arguments); read back from the device only when the
         buffers change -- a .tolist() per call would put a device synchronisation into every loss evaluation."""
@@ -165,7 +175,12 @@ class LPIPS(nn.Module):
                 cur = y
                 continue
             conv = self.convs[ci]
-            cur = ops.conv2d(cur, self._packed(ci, dt, ops.PACK_FWD, cur.shape[1:3]), item[1], 3, bias=conv.bias.detach(), act=ops.ACT_RELU)
+            Bc, Hc, Wc, Cc = cur.shape
+            if Cc >= 64 and ops.conv_pp_supported(Bc, Hc, Wc, Cc, item[1], dt):
+                # the MFMA-bound VGG layers (>= 128 output channels on a grid that fills the chip): ping-pong implicit GEMM
+                cur = ops.conv_pp(cur, self._packed_pp(ci), item[1], bias=conv.bias.detach(), act=ops.ACT_RELU)
+            else:
+                cur = ops.conv2d(cur, self._packed(ci, dt, ops.PACK_FWD, cur.shape[1:3]), item[1], 3, bias=conv.bias.detach(), act=ops.ACT_RELU)
             acts.append(cur)
             ci += 1
         val = torch.zeros(B, dtype=torch.float32, device=dev)

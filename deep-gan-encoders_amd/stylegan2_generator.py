@@ -184,6 +184,14 @@ class ModulateConvBlock(nn.Module):
             assert rgb is None
             return ops.upconv_fir(x, wu, self.out_c, in_scale=s, out_scale=d, bias=self.bias, bias_scale=self.bscale,
                                   noise=noise, noise_w=nw, act=self.act, gain=self.gain)
+        B, H, W, _ = x.shape
+        if (rgb is None and not self.up and d is not None and s is not None and self.ksize == 3
+                and ops.conv_pp_supported(B, H, W, self.in_c, self.out_c, dt)):
+            # MFMA-bound layers (>= 128 channels at 64^2 .. 256^2): the reference's fused modulation (:858-875) - style, demodulation
+            # and gain folded into one weight image per sample - feeding the ping-pong implicit GEMM (csrc/conv_pp.hip)
+            wpp = ops.pack_conv_pp(self.weight, self.wscale, in_scale=s, out_scale=d, gain=self.gain)
+            return ops.conv_pp(x, wpp, self.out_c, bias=self.bias, bias_scale=self.bscale, noise=noise, noise_w=nw, act=self.act,
+                               gain=self.gain)
         packed, _ = self._prepared(dt)
         return ops.conv2d(x, packed, self.out_c, 3, up=self.up, in_scale=s, out_scale=d, bias=self.bias,
                           bias_scale=self.bscale, noise=noise, noise_w=nw, act=self.act, gain=self.gain, rgb=rgb)

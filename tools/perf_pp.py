@@ -7,6 +7,8 @@ from dge_amd import ops
 from dge_amd._lib import last_kernel
 
 SHAPES = [(8, 128, 128, 256), (8, 256, 256, 128), (8, 512, 512, 64), (16, 128, 128, 128), (16, 256, 256, 64), (16, 64, 128, 128)]
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    SHAPES = [(16, 512, 512, 32), (8, 512, 512, 32), (16, 256, 256, 48), (16, 256, 256, 44), (16, 128, 128, 88), (8, 256, 128, 64), (8, 128, 128, 128), (8, 256, 256, 64)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     SHAPES = SHAPES[:3]
 
