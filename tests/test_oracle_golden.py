@@ -368,3 +368,49 @@ def test_elem_ref_generator_tails_equal_autograd_of_the_reference_restatement():
     gns, gb = torch.autograd.grad((rgb2 * gimg).sum(), (ns, b))
     assert abs(float(R[:, 1].sum()) - float(gns)) < 2e-4 * abs(float(gns)) + 1e-5
     assert torch.allclose(R[:, 2].float(), gb, rtol=2e-4, atol=2e-5)
+
+
+def test_step_ref_reproduces_the_reference_run():
+    """oracle/step_ref.py - the composition the full-size step test and bench.py's cpu_baseline trust - against the reference's OWN
+    two-iteration E_align_s2 run (tests/golden/step_s2.npz, made by tools/gen_golden.py:gen_step from the reference's modules):
+    train-mode generator pass (w_avg EMA, style mixing with the reference's np.random draw order, :177-191), encoder, synthesis,
+    the three space_loss terms, both backward phases with LREQAdam in between (quirk Q3), all in one call per iteration."""
+    import numpy as np
+    from oracle import step_ref
+    from oracle import lpips_ref as LR
+    from tests.golden import recipe as R
+    from tests.helpers import s2_shapes, enc_shapes
+    g = golden("step_s2.npz")
+    PG = R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11)
+    PE = {k: v.clone().requires_grad_(True) for k, v in R.fill_encoder(enc_shapes(16, 64, 5), seed=31).items()}
+    PL = LR.seeded_params(0)
+    # lr-equalisation coefficients as the reference tags them (model/utils/lreq.py:60-62,118-120): taken from the module surface,
+    # whose tags tests/test_step_gpu.py checks against the reference's own optimiser run
+    from dge_amd.encoder import BE
+    from tests.helpers import s2_shapes, enc_shapes
+    coefs = {n: p.lr_equalization_coef for n, p in BE(startf=16, maxf=64, layer_count=5).named_parameters() if hasattr(p, "lr_equalization_coef")}
+    state = {"_coef": coefs}
+    new_z = R.randn("step.new_z", (2, 512), 1)
+    nl = O.s2_num_layers(PG)
+    for it in range(2):
+        np.random.seed(it)
+        u = np.random.uniform()
+        cutoff = np.random.randint(1, nl) if u < 0.9 else 0
+        z = R.randn(f"step.z{it}", (2, 512), 1)
+        noises = [R.randn(f"step.it{it}.noise{i}", s, 1) for i, s in enumerate(O.enc_noise_shapes(5, 2, 64))]
+        rec = {}
+        r = step_ref.e_align_step(PG, PE, PL, z, noises, lr=0.0015, state=state, record=rec, train=dict(new_z=new_z, u=u, cutoff=cutoff))
+        close(r["wp"], g[f"it{it}_w1"], rtol=1e-5)
+        close(r["imgs1"], g[f"it{it}_imgs1"], rtol=2e-5)
+        close(r["w2"], g[f"it{it}_w2"], rtol=2e-4)
+        close(r["imgs2"], g[f"it{it}_imgs2"], rtol=2e-4)
+        ref_l = g[f"it{it}_losses"]
+        got = [r["loss_tsa"], *r["loss_parts"], r["loss_w"]]
+        for a, b in zip(got, ref_l):
+            assert abs(a - b) < 2e-4 * abs(b), (it, got, ref_l)
+        close(PG["truncation.w_avg"], g[f"it{it}_w_avg"], rtol=1e-6)
+        for key in g.files:
+            if key.startswith(f"it{it}_grad2:"):
+                close(rec["grad2"][key.split(":", 1)[1]], g[key], rtol=2e-3)
+            if key.startswith(f"it{it}_after_phase2:"):
+                close(PE[key.split(":", 1)[1]].detach(), g[key], rtol=2e-5)

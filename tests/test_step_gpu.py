@@ -532,13 +532,22 @@ def test_deterministic_mode_makes_the_step_bit_reproducible(cd):
         assert abs(a[0] - b[0]) < (1e-4 if cd == "f32" else 2e-2) * abs(a[0]) and abs(a[1] - b[1]) < (1e-4 if cd == "f32" else 2e-2) * abs(a[1])
 
 
-def test_fullsize_step_bf16_matches_cpu_oracle():
-    """One complete two-phase step at the BENCHMARKED size and precision (StyleGAN2-1024 + E.BE(16, L=9) + LPIPS, bf16; batch 2,
-    the reference's default, E_align_s2.py:308) against oracle/step_ref.py run on the host cores on the same seeded weights, z and
-    injected noise (E_align_s2.py:102-221): imgs1, w2, imgs2, both losses and - Adam-free - the encoder GRADIENTS of the image
-    phase and of the latent phase (the latter with the once-updated weights, quirk Q3).  This is the only place where the
-    non-conv kernels, the statistics slots and the > 2^28-element index paths of the whole pipeline meet the oracle at the
-    benchmark's shapes.  Bounds: 2x the values measured on MI355X (in the comments)."""
+@pytest.mark.parametrize("mode,B,cd", [("eval", 2, "bf16"), ("train", 4, "bf16"), ("eval", 2, "f32")])
+def test_fullsize_step_bf16_matches_cpu_oracle(mode, B, cd):
+    """One complete two-phase step at the BENCHMARKED size and precision (StyleGAN2-1024 + E.BE(16, L=9) + LPIPS, bf16) against
+    oracle/step_ref.py run on the host cores on the same seeded weights, z and injected noise (E_align_s2.py:102-221): imgs1, w2,
+    imgs2, both losses and - Adam-free - the encoder GRADIENTS of the image phase and of the latent phase (the latter with the
+    once-updated weights, quirk Q3).  "eval": batch 2, the reference's default (E_align_s2.py:308), generator in eval mode;
+    "train": the mode bench.py measures - the generator stays in train mode as in the reference's script (quirk Q1: w_avg EMA +
+    style mixing, stylegan2_generator.py:177-191; the np.random draws are made to mix, so the mixing path is the one compared) -
+    at batch 4 (the host oracle takes ~5 s per sample).  This is the only place where the non-conv kernels, the statistics slots
+    and the > 2^28-element index paths of the whole pipeline meet the oracle at the benchmark's shapes.  step_ref itself is pinned
+    on the reference's own two-iteration run (tests/test_oracle_golden.py::test_step_ref_reproduces_the_reference_run).
+    Bounds: 2x the values measured on MI355X (in the comments).
+    The "f32" case is the ATTRIBUTION run: the same step with f32 storage and exact-f32 MFMAs on the same kernels.  Every bf16
+    figure drops by two to three orders of magnitude (worst per-tensor gradient error 0.12 -> see FULLSIZE_STEP_BOUNDS_F32), i.e.
+    the bf16 errors - including the 12 % on decode_block.0.inver_mod1.weight, a gradient that is a small difference of large
+    per-channel statistics at 1024^2 - are the storage format's, not a kernel's."""
     import os
     import dge_amd
     from dge_amd.encoder import BE
@@ -546,20 +555,35 @@ def test_fullsize_step_bf16_matches_cpu_oracle():
     from dge_amd.e_align import EAlignStep
     from oracle import step_ref
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    B, S, L = 2, 1024, 9
+    S, L = 1024, 9
     PG = R.fill_s2(s2_shapes(S), seed=1)
     PE0 = R.fill_encoder(enc_shapes(16, 512, L), seed=2)
     PL = LR.seeded_params(0)
     z = R.randn("fullstep.z", (B, 512), 0)
     noises = [R.randn(f"fullstep.n{i}", s, 0) for i, s in enumerate(O.enc_noise_shapes(L, B, S))]
-    G = dge_amd.StyleGAN2Generator(S, compute_dtype="bf16").cuda()
+    G = dge_amd.StyleGAN2Generator(S, compute_dtype=cd).cuda()
     G.load_state_dict(PG)
-    G.eval()
+    train = None
+    it = 0
+    if mode == "train":
+        import numpy as np
+        G.train()
+        # an iteration number whose np.random draws DO mix (u < 0.9) with a cutoff inside the truncated layers
+        for it in range(64):
+            np.random.seed(it)
+            u = np.random.uniform()
+            if u < 0.9:
+                cutoff = int(np.random.randint(1, 2 * 9))
+                if 3 <= cutoff <= 12:
+                    break
+        train = dict(new_z=R.randn("fullstep.new_z", (B, 512), 0), u=u, cutoff=cutoff)
+    else:
+        G.eval()
     for p in G.parameters():
         p.requires_grad_(False)
-    E = BE(startf=16, maxf=512, layer_count=L, compute_dtype="bf16").cuda()
+    E = BE(startf=16, maxf=512, layer_count=L, compute_dtype=cd).cuda()
     E.load_state_dict(PE0)
-    LP = LPIPS(compute_dtype="bf16").cuda()
+    LP = LPIPS(compute_dtype=cd).cuda()
     LP.load_state_dict(PL)
     st = EAlignStep(G, E, LP, lr=0.0015, batch_size=B)
     got_grads = []
@@ -569,13 +593,17 @@ def test_fullsize_step_bf16_matches_cpu_oracle():
         got_grads.append({n: p.grad.detach().float().cpu().clone() for n, p in E.named_parameters() if p.grad is not None})
         return opt_step(**kw)
     st.opt.step = recording_step
-    r = st.step(0, z=z, noises=[n.cuda() for n in noises])
+    r = st.step(it, z=z, noises=[n.cuda() for n in noises], new_z=None if train is None else train["new_z"].cuda())
     torch.cuda.synchronize()
     # ---- the oracle, same inputs, with the encoder's lr-equalisation coefficients (they shape the phase-2 weights)
     coefs = {n: getattr(p, "lr_equalization_coef", None) for n, p in E.named_parameters()}
     PE = {k: v.clone().requires_grad_(True) for k, v in PE0.items()}
     rec = {}
-    ref = step_ref.e_align_step(PG, PE, PL, z, noises, state={"_coef": {k: c for k, c in coefs.items() if c is not None}}, record=rec)
+    PG = {k: v.clone() for k, v in PG.items()}          # (train mode updates truncation.w_avg in place)
+    ref = step_ref.e_align_step(PG, PE, PL, z, noises, state={"_coef": {k: c for k, c in coefs.items() if c is not None}}, record=rec,
+                                train=train)
+    if train is not None:
+        assert relerr(G.truncation.w_avg, PG["truncation.w_avg"]) < 1e-5
     meas = dict(imgs1=relerr(r["imgs1"], ref["imgs1"]), w2=relerr(r["w2"], ref["w2"]), imgs2=relerr(r["imgs2"], ref["imgs2"]),
                 loss_tsa=abs(float(r["loss_tsa"]) - ref["loss_tsa"]) / abs(ref["loss_tsa"]),
                 loss_w=abs(float(r["loss_w"]) - ref["loss_w"]) / abs(ref["loss_w"]))
@@ -597,12 +625,26 @@ def test_fullsize_step_bf16_matches_cpu_oracle():
                 worst[(ph, "cos" if cos == cos_min else "l2")] = n
             tot_num += ((g - gr) ** 2).sum().item(); tot_den += (gr ** 2).sum().item()
         meas[f"{key}_cos_min"], meas[f"{key}_l2_max"], meas[f"{key}_l2_all"] = cos_min, l2_max, (tot_num / tot_den) ** 0.5
-    print("full-size bf16 step vs CPU oracle:", {k: f"{v:.3e}" for k, v in meas.items()}, worst)
-    for k, bound in FULLSIZE_STEP_BOUNDS.items():
+    print(f"full-size {cd} step ({mode}, batch {B}) vs CPU oracle:", {k: f"{v:.3e}" for k, v in meas.items()}, worst)
+    for k, bound in (FULLSIZE_STEP_BOUNDS if cd == "bf16" else FULLSIZE_STEP_BOUNDS_F32).items():
         v = meas[k]
         assert (v > bound) if k.endswith("cos_min") else (v < bound), (k, v, bound)
 
 
+# the f32 attribution run: 2x the values measured on MI355X (round 4, in the comments)
+FULLSIZE_STEP_BOUNDS_F32 = {
+    "imgs1": 3.6e-6,            # 1.8e-6 of max|image|
+    "w2": 1.1e-6,               # 5.2e-7
+    "imgs2": 3.7e-6,            # 1.85e-6
+    "loss_tsa": 1.6e-6,         # 7.9e-7
+    "loss_w": 3e-7,             # 1.3e-7
+    "grad1_cos_min": 0.999999,  # 1 - 2e-7
+    "grad1_l2_max": 1.6e-3,     # 8.0e-4 (bf16: 0.12 on decode_block.0.inver_mod1.weight)
+    "grad1_l2_all": 1.1e-4,     # 5.4e-5 (bf16: 0.020)
+    "grad2_cos_min": 0.999999,
+    "grad2_l2_max": 4.4e-4,     # 2.2e-4 (bf16: 0.085)
+    "grad2_l2_all": 2.4e-5,     # 1.2e-5 (bf16: 0.014)
+}
 # bound = 2x the value measured on MI355X (round 3, in the comment); cosines: 1 - 2 x (1 - measured)
 FULLSIZE_STEP_BOUNDS = {
     "imgs1": 1.9e-2,            # 9.1e-3 of max|image|
