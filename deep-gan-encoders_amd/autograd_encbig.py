@@ -41,7 +41,7 @@ def big_encoder_forward(E, img, cond_vector, noises=None, save=False, truncation
         c1 = {} if save else None
         a1, b1 = blk.batch_norm_1.affine(truncation, cond, training, c1)
         n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
-        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=a1, in_shift=b1, noise=n1,
+        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD, H), Cc, 3, in_scale=a1, in_shift=b1, noise=n1,
                         noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1), act=ops.ACT_LRELU)
         rec = dict(x=x, a1=a1, b1=b1, c1=c1, n1=n1, x1=x1) if save else None
         if not blk.has_second_conv:
@@ -52,7 +52,7 @@ def big_encoder_forward(E, img, cond_vector, noises=None, save=False, truncation
         c2 = {} if save else None
         a2, b2 = blk.batch_norm_2.affine(truncation, cond, training, c2)
         n2 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
-        x2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=a2, in_shift=b2, noise=n2,
+        x2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H), C2, 3, in_scale=a2, in_shift=b2, noise=n2,
                         noise_w=blk.noise_weight_2.detach().reshape(-1), bias=blk.bias_2.detach().reshape(-1), act=ops.ACT_LRELU)
         xp = ops.blend(x, pool=True)                                  # avg_pool2d of the block input (residual branch)
         if Cc != C2:
@@ -128,6 +128,7 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
         blk, rec = E.decode_block[j], saved["blocks"][j]
         pre = f"decode_block.{j}."
         Cc, C2 = blk.inputs, blk.outputs
+        H = R >> j
         x, x1 = rec["x"], rec["x1"]
         red1 = ops.zeros((Cc, 2), dev)
         extra, extra_pool, extra_scale = None, False, 1.0
@@ -142,7 +143,7 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
             ops.conv_wgrad(g_pre2, x1, gW2, rec["a2"], rec["b2"])
             grads[pre + "conv_2.weight"] = gW2
             dots2 = ops.zeros((B, Cc, 2), dev)
-            g_u2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots2, dot_src=x1)
+            g_u2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
             _cbn_param_grads(blk.batch_norm_2, rec["c2"], dots2, cond, grads, pre + "batch_norm_2")
             g_pre1 = ops.in_bwd(g_u2, x1, _affine_coef(rec["a2"]), noise=rec["n1"], act=True, red=red1)
             if has3:
@@ -166,7 +167,7 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
         ops.conv_wgrad(g_pre1, x, gW1, rec["a1"], rec["b1"])
         grads[pre + "conv_1.weight"] = gW1
         dots1 = ops.zeros((B, Cc, 2), dev)
-        g_u1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD), Cc, 3, stats=dots1, dot_src=x)
+        g_u1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
         _cbn_param_grads(blk.batch_norm_1, rec["c1"], dots1, cond, grads, pre + "batch_norm_1")
         g_out = ops.in_bwd(g_u1, x, _affine_coef(rec["a1"]), extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
     fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float())

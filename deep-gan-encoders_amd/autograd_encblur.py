@@ -53,7 +53,7 @@ def blur_encoder_forward(E, img, noises=None, save=False):
         w1 = ops.linear(musig1, blk.inver_mod1.weight.detach(), blk.inver_mod1.bias.detach())
         n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
         st1 = zeros(Cc)
-        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
+        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD, H), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
                         noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
                         act=ops.ACT_LRELU, stats=st1)
         musig2, sc2, sh2 = ops.stats_finalize(st1, H * H)
@@ -62,7 +62,7 @@ def blur_encoder_forward(E, img, noises=None, save=False):
         nstats = zeros(C2) if not last else None
         if not last:
             y2 = ops.blur_noise_act(ops.blend(x1, sc=sc2, sh=sh2), None, None, None, blur=True, act=False)   # blur(IN2(x1))
-            wpk = _packed(cache, blk.conv_2, dt, ops.PACK_FWD)
+            wpk = _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H)
             n2 = noises[ni]; ni += 1
             nw2, b2 = blk.noise_weight_2.detach().reshape(-1), blk.bias_2.detach().reshape(-1)
             if blk.fused_scale:        # conv(s2, transform_kernel) == pool(conv); noise/bias/lrelu at half resolution
@@ -132,7 +132,7 @@ def blur_encoder_backward(E, saved, g_w, g_const=None, need_img=False):
             gW2 = ops.zeros(tuple(blk.conv_2.weight.shape), dev)
             ops.conv_wgrad(g_c2, rec["y2"], gW2)
             grads[pre + "conv_2.weight"] = gW2
-            g_y2b = ops.conv2d(g_c2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3)
+            g_y2b = ops.conv2d(g_c2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3)
             g_y2 = ops.blur_noise_act(g_y2b, None, None, None, blur=True, act=False)                 # Blur is self-adjoint
             dots2 = ops.dot_stats(g_y2, x1)
             if has3:
@@ -160,7 +160,7 @@ def blur_encoder_backward(E, saved, g_w, g_const=None, need_img=False):
         ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
         grads[pre + "conv_1.weight"] = gW1
         dots1 = ops.zeros((B, Cc, 2), dev)
-        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD), Cc, 3, stats=dots1, dot_src=x)
+        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
         coef1 = ops.in_bwd_coef(dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
         g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
     fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float())

@@ -35,7 +35,7 @@ def pg_encoder_forward(E, img, noises=None, save=False):
         musig1, sc1, sh1 = ops.stats_finalize(stats, H * H)
         st1 = zeros(Cc)
         n1 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
-        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
+        x1 = ops.conv2d(x, _packed(cache, blk.conv_1, dt, ops.PACK_FWD, H), Cc, 3, in_scale=sc1, in_shift=sh1, noise=n1,
                         noise_w=blk.noise_weight_1.detach().reshape(-1), bias=blk.bias_1.detach().reshape(-1),
                         act=ops.ACT_LRELU, stats=st1)
         rec = dict(x=x, musig1=musig1, sc1=sc1, sh1=sh1, n1=n1, x1=x1) if save else None
@@ -46,7 +46,7 @@ def pg_encoder_forward(E, img, noises=None, save=False):
             break
         musig2, sc2, sh2 = ops.stats_finalize(st1, H * H)
         n2 = noises[ni].reshape(B, H, H).contiguous(); ni += 1
-        pre2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD), C2, 3, in_scale=sc2, in_shift=sh2, noise=n2,
+        pre2 = ops.conv2d(x1, _packed(cache, blk.conv_2, dt, ops.PACK_FWD, H), C2, 3, in_scale=sc2, in_shift=sh2, noise=n2,
                           noise_w=blk.noise_weight_2.detach().reshape(-1), bias=blk.bias_2.detach().reshape(-1))
         if Cc != C2:
             st3 = zeros(C2)
@@ -115,7 +115,7 @@ def pg_encoder_backward(E, saved, g_z):
             ops.conv_wgrad(g_s, x1, gW2, rec["sc2"], rec["sh2"])
             grads[pre + "conv_2.weight"] = gW2
             dots2 = ops.zeros((B, Cc, 2), dev)
-            g_y2 = ops.conv2d(g_s, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots2, dot_src=x1)
+            g_y2 = ops.conv2d(g_s, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
             coef2 = ops.in_bwd_coef(dots2, None, rec["musig2"], rec["sc2"], rec["sh2"], N)
             g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1)
             if has3:
@@ -141,7 +141,7 @@ def pg_encoder_backward(E, saved, g_z):
         ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
         grads[pre + "conv_1.weight"] = gW1
         dots1 = ops.zeros((B, Cc, 2), dev)
-        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD), Cc, 3, stats=dots1, dot_src=x)
+        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
         coef1 = ops.in_bwd_coef(dots1, None, rec["musig1"], rec["sc1"], rec["sh1"], N)
         g_out = ops.in_bwd(g_y1, x, coef1, extra=extra, extra_pool=False, extra_scale=1.0)
     fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float())

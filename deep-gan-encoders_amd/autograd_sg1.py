@@ -57,7 +57,7 @@ def decode_run(G, styles, lod, noises=None, save=False):
         s1 = ops.linear(styles[:, 2 * i], blk.style_1.weight.detach(), blk.style_1.bias.detach())
         a, b = ops.affine_compose(sc1, sh1, s1)
         st2 = ops.zeros((B, Cc, 2), dev)
-        x = ops.conv2d(y, blk._packed(blk.conv_2, dt, ops.PACK_FWD), Cc, 3, in_scale=a, in_shift=b,
+        x = ops.conv2d(y, blk._packed(blk.conv_2, dt, ops.PACK_FWD, res), Cc, 3, in_scale=a, in_shift=b,
                        noise=noise_for(B, res), noise_w=blk.noise_weight_2.detach().reshape(-1),
                        bias=blk.bias_2.detach().reshape(-1), act=ops.ACT_LRELU, stats=st2)
         _, sc2, sh2 = ops.stats_finalize(st2, res * res)
@@ -98,7 +98,7 @@ def decode_backward(G, lod, saved, g_image):
         ops.linear_t(gs, blk.style_2.weight.detach(), g_styles[:, 2 * i + 1], accumulate=True)
         g_pre = ops.in_bwd(g_u, rec["x"], coef, act=True)
         dots = ops.zeros((B, Cc, 2), dev)
-        g_u = ops.conv2d(g_pre, blk._packed(blk.conv_2, dt, ops.PACK_DGRAD), Cc, 3, stats=dots, dot_src=rec["y"])
+        g_u = ops.conv2d(g_pre, blk._packed(blk.conv_2, dt, ops.PACK_DGRAD, res), Cc, 3, stats=dots, dot_src=rec["y"])
         if DEBUG_TAP is not None:
             DEBUG_TAP[2 * i] = g_u
         # ---- style_1 / instance norm / lrelu behind the blurred conv_1 output

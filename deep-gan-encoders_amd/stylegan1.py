@@ -56,8 +56,12 @@ class DecodeBlock(nn.Module):
         self.style_2 = ln.Linear(latent_size, 2 * outputs, gain=1)
         self._cache = {}
 
-    def _packed(self, conv, dtype, mode):
+    def _packed(self, conv, dtype, mode, hw=None):
+        """`hw`: resolution a stride-1 3x3 conv reads this copy at (the low-resolution blocks keep theirs in fragment order for
+        csrc/conv_small.hip)"""
         w = conv.weight
+        if hw is not None:
+            mode = ops.pack_mode_for(w, mode, hw, hw, dtype)
         key = (id(conv), mode, dtype)
         ver = (w._version, w.data_ptr(), getattr(w, "_dge_gen", 0))
         hit = self._cache.get(key)

@@ -77,11 +77,11 @@ def _grad_report(named, ref):
 # --------------------------------------------------------------------------------------------- StyleGAN1 (configs 2 and 5)
 SG1_KERNELS = {
     (64, 7, 8): ["conv_igemm<bf16,16,16,128,32,3,2,2>", "conv_igemm<bf16,16,16,64,32,3,4,1>", "conv_igemm<bf16,16,16,64,32,3,4,1>+tr",
-                 "conv_igemm<bf16,8,8,64,128,3,2,2>"],
+                 "conv_igemm<bf16,8,8,64,128,3,2,2>", "conv_small<bf16,8,8,64,512>"],
     (64, 7, 32): ["conv_igemm<bf16,16,16,128,32,3,2,2>", "conv_igemm<bf16,16,16,128,32,3,2,2>+tr", "conv_igemm<bf16,16,16,64,32,3,4,1>",
-                  "conv_igemm<bf16,16,16,64,32,3,4,1>+tr", "conv_igemm<bf16,8,8,64,128,3,2,2>"],
+                  "conv_igemm<bf16,16,16,64,32,3,4,1>+tr", "conv_igemm<bf16,8,8,64,128,3,2,2>", "conv_small<bf16,8,8,64,512>"],
     (16, 9, 1): ["conv_igemm<bf16,16,16,32,32,3,4,1>", "conv_igemm<bf16,16,16,64,32,3,4,1>", "conv_igemm<bf16,8,8,64,128,3,2,2>",
-                 "conv_stream<bf16,16,16,enc_stats>"],
+                 "conv_stream<bf16,16,16,enc_stats>", "conv_small<bf16,8,8,64,512>"],
 }
 IG = "conv_igemm<bf16,"
 PG_KERNELS = [IG + "16,16,128,32,3,2,2>+tr", IG + "16,16,64,32,3,4,1>+tr", IG + "8,8,64,128,3,2,2>", "conv_stream<bf16,64,64,gen>"]
@@ -99,7 +99,8 @@ BLUR1024_KERNELS = [IG + "16,16,32,32,1,4,1>", IG + "16,16,32,32,3,4,1>", IG + "
                     IG + "8,8,64,128,1,2,2>", IG + "8,8,64,128,3,2,2>", IG + "8,8,64,64,1,2,2>", "conv_pw<bf16,16,32>", "conv_pw<bf16,32,32>",
                     "conv_stream<bf16,16,16,dot>", "conv_stream<bf16,16,16,enc_stats>", "conv_stream<bf16,16,32,gen>", "conv_stream<bf16,32,16,gen>",
                     "conv_stream<bf16,32,32,dot>", "conv_stream<bf16,32,64,gen>", "conv_stream<bf16,64,32,gen>", "conv_stream<bf16,64,64,dot>",
-                    "conv_wgrad_tr<1,16>", "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,32,32,3>", "wgrad_dma<16,64,32,2>", "wgrad_dma<16,64,64,2>"]
+                    "conv_wgrad_tr<1,16>", "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,32,32,3>", "wgrad_dma<16,64,32,2>", "wgrad_dma<16,64,64,2>",
+                    "conv_small<bf16,8,8,64,512>"]
 
 
 @pytest.mark.parametrize("startf,L,B", [(64, 7, 8), (64, 7, 32), (16, 9, 1)])
