@@ -173,6 +173,8 @@ def main():
     sync()
     for i in range(a.warmup):
         run(i)
+    if dist.is_initialized():
+        st.comm_stats = {"events": []}         # EAlignStep._sync_grads: events around the exposed part of the gradient exchange
     dt, step_stats = timed_steps(run, a.warmup, a.steps, sync)
     if world > 1:
         t = torch.tensor([dt], device=dev)
@@ -200,6 +202,12 @@ def main():
         out["dist"] = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(), "rccl_version": rccl,
                        "exact_global_batch": bool(st.exact_ddp), "collectives_per_step": "w_avg mean, packed loss sums (1 per phase), "
                        "gradient bucket early + remainder (2 per phase)"}
+        cs = getattr(st, "comm_stats", None)
+        if cs and cs["events"]:
+            ex = [e0.elapsed_time(e1) for e0, e1 in cs["events"]]
+            # two gradient exchanges per step (image phase, latent phase): what the compute stream waited for, rank 0
+            out["dist"].update({"exposed_grad_exchange_ms_per_step": sum(ex) / a.steps, "exposed_grad_exchange_ms_per_phase_median": _pct(ex, 0.5),
+                                "early_bucket_bytes": cs.get("early_bytes"), "remainder_bucket_bytes": cs.get("remainder_bytes")})
 
     # ---- the same step at the reference's DEFAULT batch (E_align_s2.py:308: batch_size 2) and with G in eval mode (no w_avg
     #      EMA / style mixing: SURVEY config 3's eval line); short timed regions, N = 1 only
@@ -210,8 +218,8 @@ def main():
             for i in range(3):
                 st2.step(i)
             d2, s2 = timed_steps(lambda i: st2.step(i), 3, 10, sync)
-            extras["batch2"] = {"value": 2 * 10 / d2, "unit": "images/sec", "ms_per_step": d2 / 10 * 1e3, "step_ms_median": s2["median"],
-                                "note": "reference default batch (E_align_s2.py:308), eager"}
+            extras["batch2_eager"] = {"value": 2 * 10 / d2, "unit": "images/sec", "ms_per_step": d2 / 10 * 1e3, "step_ms_median": s2["median"],
+                                      "note": "reference default batch (E_align_s2.py:308), eager launches (--launch eager)"}
             # the same batch replayed from a captured hipGraph: at this batch the eager step is bound by the host's launch rate
             try:
                 if a.no_extra_graph:
@@ -220,10 +228,12 @@ def main():
                 for i in range(2):
                     st2.replay()
                 dg, sg = timed_steps(lambda i: st2.replay(), 0, 10, sync)
-                extras["batch2_graph"] = {"value": 2 * 10 / dg, "unit": "images/sec", "ms_per_step": dg / 10 * 1e3, "step_ms_median": sg["median"],
-                                          "note": "batch 2, hipGraph replay of the captured iteration (EAlignStep.capture / replay)"}
+                extras["batch2"] = {"value": 2 * 10 / dg, "unit": "images/sec", "ms_per_step": dg / 10 * 1e3, "step_ms_median": sg["median"],
+                                    "note": "reference default batch (E_align_s2.py:308) in the default launch mode of `python -m dge_amd.e_align` "
+                                            "at batch <= 2 on one GPU: hipGraph replay of the captured iteration (EAlignStep.capture / replay; "
+                                            "replays equal the eager iteration sequence: tests/test_step_gpu.py::test_graph_replay_*)"}
             except Exception as ex:
-                extras["batch2_graph"] = {"value": None, "note": f"not measured: {ex}"}
+                extras["batch2"] = {"value": None, "note": f"not measured: {ex}"}
             del st2
         G.eval()
         for i in range(2):

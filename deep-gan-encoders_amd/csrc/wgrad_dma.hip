@@ -359,6 +359,8 @@ int launch(const void* g, const void* x, const float* sc, const float* sh, float
     gps = (tps + per - 1) / per;
     const int groups = B * gps;
     const int groups8 = groups < 8 ? groups : (groups + 7) / 8 * 8;   // padding groups return at once (XCD-aware placement, see the kernel)
+    // deterministic mode: (o, i) tile domains x (sample, group) slots x 32 x 32 x 9 floats; too large -> the caller's other kernel
+    if (!dge_det_fits(noi, (long long)B * gps, 1024 * 9)) return 1;
     dge_note_kernel("wgrad_dma<%d,%d,%d,%d>", C::TH, C::GP, C::XP, C::NS);
     hipLaunchKernelGGL(kern, dim3(noi, groups8), dim3(C::NW * 64), lds_bytes, s, (const bf16_t*)g, (const bf16_t*)x, sc, sh, dw, B, H, W,
                        cout, cin, tx, ty, per, gps);

@@ -51,6 +51,20 @@ class LREQAdam(Optimizer):
         self._graph_corr.copy_(torch.tensor(vals, dtype=torch.float32))
         self._graph_call = 0
 
+    def graph_snapshot(self):
+        """Host-side counters before a stream capture ..."""
+        return (getattr(self, "_graph_t", None), {p: st["step"] for p, st in self.state.items() if len(st)})
+
+    def graph_restore(self, snap):
+        """... and their rollback after it: step() calls made while a hipGraph is being CAPTURED advance the step counters on the
+        host although no update runs on the device (the captured iteration is recorded, not executed); left in place, every
+        replay would apply sqrt(1 - beta2^t) one iteration ahead of the eager sequence.  Parameters that got their state inside
+        the capture go back to step 0."""
+        self._graph_t, steps = snap
+        for p, st in self.state.items():
+            if len(st):
+                st["step"] = steps.get(p, 0)
+
     def graph_count_replay(self):
         """After every graph replay: the region's step() calls did not run on the host, so advance the per-parameter step
         counters here (optimizer.state_dict() and a later eager step() then see the true t)."""
@@ -84,8 +98,13 @@ class LREQAdam(Optimizer):
             saved = [(p, p.grad) for p in group["params"]]
             try:
                 for p in group["params"]:
+                    if p.dtype != torch.float32:
+                        raise RuntimeError("LREQAdam.tick: float32 parameters only")
                     p.grad = z[:p.numel()].view_as(p) if len(self.state.get(p, {})) else None
+                gens = [(p, getattr(p, "_dge_gen", 0)) for p in group["params"]]
                 self.step()
+                for p, gen in gens:          # no value changed: the packed weight copies stay valid (step() marks them stale)
+                    p._dge_gen = gen
             finally:
                 for p, g in saved:
                     p.grad = g

@@ -243,11 +243,22 @@ class EAlignStep:
         missing = [n for n, p in lay["named"].items() if p.grad is None and n not in early]
         for n in missing:                                   # parameters without a gradient this phase contribute zeros
             lay["views"][n].zero_()
+        # comm_stats (bench.py --gpus N): events on the compute stream around the part of the exchange the step waits for - the
+        # remainder bucket plus whatever of the early bucket the backward did not cover
+        cs = getattr(self, "comm_stats", None)
+        if cs is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if work is not None:
             _all_reduce(self._flat[lay["n_early"]:])
             work.wait()
         else:
             _all_reduce(self._flat)
+        if cs is not None:
+            e1.record()
+            cs["events"].append((e0, e1))
+            cs["early_bytes"] = 4 * lay["n_early"] if work is not None else 0
+            cs["remainder_bytes"] = 4 * (self._flat.numel() - (lay["n_early"] if work is not None else 0))
         for n, p in lay["named"].items():
             if p.grad is not None:
                 p.grad = lay["views"][n]
@@ -261,7 +272,8 @@ class EAlignStep:
         which bounds the step at the reference's default batch of 2).  Host-side decisions of an iteration become device
         inputs: z (static buffer), the style-mixing mask (StyleGAN2 train mode, same np.random draw order as the
         reference) and Adam's sqrt(1 - beta2^t) factors.  Encoder / StyleGAN1 noise comes from torch's graph-safe
-        device generator.  `warmup` + 1 real iterations run inside this call."""
+        device generator.  `warmup` real iterations run inside this call (plus one eager iteration in front of them in the legacy
+        stage-1 form); the captured iteration itself is only recorded."""
         if self.dist_on:
             raise RuntimeError("hipGraph capture is offered for single-process runs only (collectives are not captured)")
         # Capturing after EAGER steps of the same encoder used to end in a segmentation fault inside capture_end (round 2:
@@ -283,7 +295,13 @@ class EAlignStep:
         self._g_z = torch.zeros(B, self.z_dim, device=self.dev)
         if isinstance(self.gen, _StyleGAN2Adapter):
             self.gen.mix_mask = torch.zeros(self.G.num_layers, device=self.dev)
-        self.opt.graph_begin(2, self.dev)
+        # optimizer calls of one iteration: two in stage 2 (image phase, latent phase), one in stage 1 - two again in its legacy
+        # zero_grad form (tick() + step()), where the tick is skipped while no parameter has state yet: one eager iteration
+        # first gives every parameter its state, so that every captured / replayed iteration makes the same number of calls
+        calls = 2 if (self.stage == 2 or not self.zero_grad_to_none) else 1
+        if self.stage == 1 and not self.zero_grad_to_none and not any(len(st) for st in self.opt.state.values()):
+            self.step(0)
+        self.opt.graph_begin(calls, self.dev)
         self._g_iter = 0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -295,9 +313,13 @@ class EAlignStep:
         from .autograd_enc import prime_pack_tables
         prime_pack_tables(self.E)
         self._graph = torch.cuda.CUDAGraph()
-        self._graph_inputs(self._g_iter); self._g_iter += 1
+        # the captured iteration is RECORDED, not executed: the host-side counters it advances (Adam's t, the iteration number that
+        # seeds z and the mixing mask) are rolled back, so that the first replay is iteration `warmup` of the sequence
+        snap = self.opt.graph_snapshot()
+        self._graph_inputs(self._g_iter)
         with torch.cuda.graph(self._graph):
             self._g_out = self.step(0, z=self._g_z)
+        self.opt.graph_restore(snap)
         return self._g_out
 
     def _graph_inputs(self, iteration):
@@ -573,8 +595,17 @@ def train(tensor_writer=None, args=None):
                        allow_standin=getattr(args, "allow_standin_lpips", False))
     st = EAlignStep(G, E, LP, lr=args.lr, beta_1=args.beta_1, batch_size=args.batch_size, z_dim=args.z_dim, mapping=Gm,
                     stage=getattr(args, "stage", 2), zero_grad_to_none=not getattr(args, "legacy_zero_grad", False))
+    # Launch mode.  At the reference's default batch (2, E_align_s2.py:308) the eager step is bound by the host's launch rate
+    # (~560 launches): single-process runs at batch <= 2 therefore replay the iteration from a captured hipGraph by default
+    # (EAlignStep.capture: z, style-mixing mask and Adam factors become device inputs; same numbers, see
+    # tests/test_step_gpu.py::test_graph_replay_*).  --launch eager / graph overrides; --mtype 4 and the deterministic mode stay eager.
+    mode = getattr(args, "launch", "auto")
+    use_graph = mode == "graph" or (mode == "auto" and not st.dist_on and args.batch_size <= 2 and args.mtype != 4
+                                    and not getattr(args, "deterministic", False))
+    if use_graph:
+        st.capture()
     for iteration in range(args.iterations):
-        r = st.step(iteration)
+        r = st.replay(iteration) if use_graph else st.step(iteration)
         if iteration % 100 == 0:
             print("ep_%d_iter_%d" % (iteration // 30000, iteration % 30000), "loss_tsa", float(r["loss_tsa"]),
                   "loss_w", float(r["loss_w"]))
@@ -592,6 +623,8 @@ def main(argv=None):
     parser.add_argument("--batch_size", type=int, default=2)
     parser.add_argument("--experiment_dir", default=None)
     add_model_args(parser)
+    parser.add_argument("--launch", choices=("auto", "eager", "graph"), default="auto",
+                        help="auto: hipGraph replay of the iteration for single-process runs at batch <= 2, eager otherwise")
     parser.add_argument("--stage", type=int, default=2, help="2: E_align_s2.py; 1: E_align_cropping_s1.py (latent phase only trains E)")
     parser.add_argument("--legacy_zero_grad", action="store_true", help="stage 1: optimizer.zero_grad() as torch < 2.0 (zero-filled gradients, the "
                         "reference's pinned environment): the first optimizer step of an iteration ticks every Adam state")

@@ -54,12 +54,17 @@ def _run_steps(B, nsteps=2):
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                    # RCCL: one device per rank
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out = _run_steps(2)
         # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process
@@ -69,12 +74,17 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_times_b_equal_one_process_at_2b():
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_times_b_equal_one_process_at_2b(backend):
+    """gloo: both ranks on the one GPU of the box.  nccl: the same over RCCL with one device per rank - the path bench.py --gpus N
+    runs (collectives on RCCL's stream, asynchronous early bucket); needs two devices, skipped on a single-GPU box."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one device per rank: fewer than two GPUs visible")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in procs)

@@ -361,6 +361,58 @@ def test_graph_replay_of_the_training_step_runs():
     assert len(set(losses)) == 3            # a new z every replay
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_graph_replay_of_stage1_equals_eager_iterations(legacy):
+    """Stage 1 makes ONE optimizer call per iteration (two in its legacy zero_grad form: tick + step, the tick only once every
+    parameter has state): the captured region's Adam step factors must follow that count, or replays drift from eager iterations
+    by a sqrt(1 - beta2^t) ratio.  Same z sequence (set_seed per iteration), encoder noise switched off on both sides: the
+    parameters after capture (warm-up + captured iteration) + replays must equal the same number of eager iterations."""
+    import dge_amd
+    from dge_amd.encoder import BE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.e_align import EAlignStep
+
+    def build():
+        G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="f32").cuda()
+        G.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+        G.eval()
+        for p in G.parameters():
+            p.requires_grad_(False)
+        E = BE(startf=16, maxf=64, layer_count=5, compute_dtype="f32").cuda()
+        sd = R.fill_encoder(enc_shapes(16, 64, 5), seed=31)
+        for k in sd:
+            if "noise_weight" in k:
+                sd[k] = torch.zeros_like(sd[k])      # (the eager and the graph path draw their noise from different generators)
+        E.load_state_dict(sd)
+        for k, p in E.named_parameters():
+            if "noise_weight" in k:
+                p.requires_grad_(False)               # ... and they stay zero: no optimizer step moves them
+        LP = LPIPS(compute_dtype="f32").cuda()
+        LP.load_state_dict(LR.seeded_params(0))
+        return EAlignStep(G, E, LP, lr=0.0015, batch_size=2, stage=1, zero_grad_to_none=not legacy), E
+    a, Ea = build()
+    b, Eb = build()
+    n0 = 1 if legacy else 0                # capture() runs one eager iteration first in the legacy form (states must exist)
+    b.capture(warmup=1)                    # real iterations: n0 eager + 1 warm-up (the captured one is only recorded)
+    for _ in range(3):
+        b.replay()
+    ntot = n0 + 1 + 3
+    # eager twin: the same z sequence - capture / replay number their iterations from 0, the eager pre-iteration used 0 as well
+    seq = ([0] if legacy else []) + [0, 1, 2, 3]
+    for it in seq:
+        a.step(it)
+    assert len(seq) == ntot
+    worst = 0.0
+    for (k, pa), (_, pb) in zip(Ea.state_dict().items(), Eb.state_dict().items()):
+        if "noise_weight" in k:
+            continue
+        worst = max(worst, relerr(pb, pa.cpu().numpy()))
+    t_a = max(st["step"] for st in a.opt.state.values() if len(st))
+    t_b = max(st["step"] for st in b.opt.state.values() if len(st))
+    assert t_a == t_b, (t_a, t_b)
+    assert worst < 2e-4, worst              # f32 atomics order only; a wrong step count shows as ~1e-2
+
+
 def test_two_phase_step_pggan_matches_reference_run():
     """--mtype 3 (PGGAN generator + E_PG encoder, BASELINE config 1) in the evident-intent form of SURVEY Q5, against two
     iterations run with the reference's own modules (tests/golden/step_pg.npz): images, latents, losses and encoder
