@@ -1,3 +1,9 @@
+// EXPERIMENT COPY of deep-gan-encoders_amd/csrc/conv_stream.hip as of round 4, with the DGE_SC_* timing / tuning switches the product
+// translation unit no longer carries (ring depth, waves per workgroup, prefetch distance, phase timestamps, and the ablations
+// DGE_SC_NOMFMA / NOK / NOEPI / NOSTORE / STOREPAT / NTSTORE / NTLOAD / NOWAIT / SAMEROW / TWOCHAIN - several of which compute
+// WRONG results on purpose: they time a phase, they are not variants of the kernel).  Built by tools/build_variant.sh into a
+// separate library for A/B timing (DGE_LIB_PATH); never linked into libdge_hip.so.
+
 // Streaming 3x3 convolution for the HBM-bound layers (Cin, Cout <= 64 at >= 128^2; bf16), gfx950.
 //
 // The 512^2 / 1024^2 layers of the generator (64 / 32 channels) and the first encoder blocks (16 / 32 channels) sit far
@@ -26,14 +32,18 @@
 //
 // Reference math: model/stylegan2_generator.py:855-922 (stride-1 branch), model/E/E.py:50-85.
 #include <type_traits>
-#include "common.h"
+#include "../../deep-gan-encoders_amd/csrc/common.h"
 #include <stdlib.h>
-#include "conv_params.h"
+#include "../../deep-gan-encoders_amd/csrc/conv_params.h"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+#ifdef DGE_SC_NTLOAD
+#define DGE_LDS " nt lds\n\t"
+#else
 #define DGE_LDS " lds\n\t"
+#endif
 
 __device__ __forceinline__ unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned lds_off(const void* p) {
@@ -118,7 +128,10 @@ template <int CIN, int COUT, int FL>
 struct SC {
     static constexpr int PXB = CIN * 2, CH = PXB / 16, LOGCH = ilog2(CH), KS = CIN / 16;
     static constexpr int TEAM = COUT == 64 ? 2 : 1;                            // waves sharing one strip: 32 output channels each
-    static constexpr int TPW = 4 / TEAM;                            // independent teams per workgroup (one wave per SIMD)
+#ifndef DGE_SC_WAVES
+#define DGE_SC_WAVES 4
+#endif
+    static constexpr int TPW = DGE_SC_WAVES / TEAM;                            // independent teams per workgroup (one wave per SIMD)
     static constexpr int MT = COUT / 32 > 0 ? COUT / 32 : 1;                   // M tiles of the strip (Cout 16: one half-empty tile)
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
@@ -127,9 +140,16 @@ struct SC {
     static_assert(!RGB || COUT == 32 || (COUT == 64 && TEAM == 2), "fused toRGB: 32 output channels per wave, one wave or a 2-wave team per pixel");
     static constexpr bool DOT = FL == FL_DOT || PREP, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS || POOL;
     static constexpr bool NOISE = !DOT || PREP;
-    static constexpr int NR = 6;                 // ring rows = unroll period
+#ifndef DGE_SC_NR
+#define DGE_SC_NR 6
+#define DGE_SC_D 2
+#endif
+#ifndef DGE_SC_NR_DOT
+#define DGE_SC_NR_DOT 6
+#endif
+    static constexpr int NR = DOT ? DGE_SC_NR_DOT : DGE_SC_NR;                 // ring rows = unroll period
     static constexpr int dot_depth(int nr) { for (int d = 4; d >= 1; d--) if (d <= nr - 3 && nr % (d + 1) == 0) return d; return 1; }
-    static constexpr int D = DOT ? dot_depth(6) : 2;            // rows in flight ahead of the newest live row (<= NR - 3)
+    static constexpr int D = DOT ? dot_depth(DGE_SC_NR_DOT) : DGE_SC_D;            // rows in flight ahead of the newest live row (<= NR - 3)
     static constexpr int DR = DOT ? D + 1 : NR;                                // dot ring rows (must divide NR)
     static_assert(NR % DR == 0, "dot ring period");
     static constexpr int CPB = COUT * 2;
@@ -237,7 +257,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
         const int gy = r0 - 1 + h;
         const bool xv = (unsigned)gy < (unsigned)p.H && h <= rows + 1;
         const rsrc_t rx = make_rsrc(xptr, xv ? xrow_bytes : 0u);
+#ifndef DGE_SC_SAMEROW
         xptr += xrow_bytes;
+#endif
         const unsigned m0x = lds0 + C::X_OFF + slot * C::RB;
         dma_row<CIN, C::TEAM>(wave, voff, voff_b, voff_c, rx, rs_null, m0x, lds0 + C::DUMMY_OFF);
         const bool ov = h >= 2 && h <= rows + 1;                                        // output row gy - 1 lies inside the segment
@@ -424,26 +446,43 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     const float pns = (C::PREP && p.prep_noise && p.prep_ns) ? p.prep_ns[0] : 0.f;
 
     // ---- one output row.  I = position in the ring period (compile time): halo rows in slots I, I+1, I+2 (mod NR)
+#ifdef DGE_SC_TIMING
+    long long* tlog = (long long*)(lds + C::T_OFF);      // [16 steps][5] of job 0 (the table is dead once the constants are in registers)
+    const bool tjob = blockIdx.x == 64 && wid == 0;
+#define DGE_T(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); \
+                      if (tjob && s >= 40 && s < 56 && lane == 0) tlog[(s - 40) * 5 + k] = t_; } while (0)
+#else
 #define DGE_T(k)
+#endif
     auto step = [&](auto ic, int s, unsigned npar) {
         constexpr int I = decltype(ic)::value;
         DGE_T(0);
         // row s+2 (and the noise / dot row s) has landed when at most (D-1) rows' loads are still in flight
+#ifndef DGE_SC_NOWAIT
         // loads issued after row s+2's: the rows of the D-1 steps before this one, plus the noise piece if one of them was
         // a period start (ring position 0)
         constexpr int NAFTER = (C::D - 1) * C::LPR + ((C::NOISE && I >= 1 && I <= C::D - 1) ? 1 : 0);
         asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NAFTER) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+#endif
         if constexpr (C::RGB && C::TEAM == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (wave 1's partial sums of row s-1 are in LDS)
         if constexpr (C::TEAM == 2) __builtin_amdgcn_s_barrier();     // the partner's pieces landed; it finished step s-1
         if constexpr (C::RGB && C::TEAM == 2) { if (wave == 0 && s > 0) rgb_flush(s - 1); }
         DGE_T(1);
         if constexpr (C::NOISE && I == 0) issue_noise(s + C::NR, npar ^ 1024u);   // the next period's rows into the other buffer
         issue(s + 2 + C::D, (I + 2 + C::D) % C::NR, (I + C::D) % C::DR);
+#ifdef DGE_SC_NOMFMA
+        if (p.dbg != 12345) return;
+#endif
         DGE_T(2);
 
         const int gy = r0 + s;
         constexpr int NQ = 9 * C::KS;
-        constexpr int PF = NQ < 6 ? NQ : 6;
+#ifndef DGE_SC_PF
+#define DGE_SC_PF 6
+#endif
+        constexpr int PF = NQ < DGE_SC_PF ? NQ : DGE_SC_PF;
         auto frag_addr = [&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int tap = q / C::KS, ks = q % C::KS, dy = tap / 3, dx = tap % 3;
@@ -454,16 +493,34 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
         uint4 bq[PF];
         StaticFor<PF>::run([&](auto qc) { bq[decltype(qc)::value] = lds_u4(frag_addr(qc)); });
         f32x16_t acc[C::MTW];
+#ifdef DGE_SC_TWOCHAIN
+        f32x16_t acc2[C::MTW];
+#endif
+#ifdef DGE_SC_NOK
+        acc[0] = biasv[0];
+        if (p.dbg == 12345)
+#endif
         StaticFor<NQ>::run([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int tap = q / C::KS, ks = q % C::KS;
             const bf16x8_t bf = *(const bf16x8_t*)&bq[q % PF];
 #pragma unroll
             for (int mt = 0; mt < C::MTW; mt++) {
+#ifdef DGE_SC_TWOCHAIN
+                if constexpr (q & 1)
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[mt][tap][ks], bf, q == 1 ? zero16 : acc2[mt], 0, 0, 0);
+                else
+#endif
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[mt][tap][ks], bf, q == 0 ? (C::DOT ? zero16 : biasv[mt]) : acc[mt], 0, 0, 0);
             }
             if constexpr (q + PF < NQ) bq[q % PF] = lds_u4(frag_addr(std::integral_constant<int, q + PF>{}));
         });
+#ifdef DGE_SC_TWOCHAIN
+#pragma unroll
+        for (int mt = 0; mt < C::MTW; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[mt][r] += acc2[mt][r];
+#endif
 
         // pin the issue order: PF (+ noise) reads, then one read per MTW MFMAs, then the last PF fragments' MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, PF + (C::NOISE ? 1 : 0), 0);
@@ -472,7 +529,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         });
         __builtin_amdgcn_sched_group_barrier(0x008, PF * C::MTW, 0);
+#ifdef DGE_SC_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[0][15]));
+#endif
         DGE_T(3);
+#ifdef DGE_SC_NOEPI
+        if (acc[0][0] != 12345.f) return;
+#endif
         // ---------------- epilogue: this lane = pixel gx, NREG channels per tile
         unsigned char* __restrict__ yrow = Yb + (size_t)gy * yrow_bytes;
 #pragma unroll
@@ -590,6 +653,27 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 }
                 if (p.rgb_skip_y) continue;
             }
+#ifdef DGE_SC_NOSTORE
+            if (o0.x != 0x12345u || o1.y != 0x54321u) continue;
+#endif
+#ifdef DGE_SC_STOREPAT          // timing experiment (wrong placement of the data): 1 = lane-linear 1 KB per instruction,
+                                // 2 = 16 pixels x 64 B per instruction, one chunk per 16-lane row
+            {
+                unsigned char* base = yrow + (size_t)x0 * C::CPB;
+                const unsigned lo = DGE_SC_STOREPAT == 1 ? lane * 16 : (lane & 15) * 64 + (lane >> 4) * 16;
+                *(uint4*)(base + lo) = o0;
+                *(uint4*)(base + lo + 1024) = o1;
+                continue;
+            }
+#endif
+#ifdef DGE_SC_NTSTORE
+            if (full_strip) {
+                typedef unsigned u4v __attribute__((ext_vector_type(4)));
+                const u4v a0 = {o0.x, o0.y, o0.z, o0.w}, a1 = {o1.x, o1.y, o1.z, o1.w};
+                asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(a0) : "memory");
+                if constexpr (NREG == 16) asm volatile("global_store_dwordx4 %0, %1, off offset:32 nt" :: "v"(dst), "v"(a1) : "memory");
+            } else
+#endif
             if (full_strip) {
                 *(uint4*)dst = o0;
                 if constexpr (NREG == 16) *(uint4*)(dst + 32) = o1;
@@ -619,6 +703,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     }
     // no DMA may land after the wave has given its LDS back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DGE_SC_TIMING
+    if (tjob && lane < 40) ((long long*)p.y)[lane * 2] = tlog[lane * 2], ((long long*)p.y)[lane * 2 + 1] = tlog[lane * 2 + 1];
+#endif
 
     // ---- statistics: reduce over the 32 pixel lanes, one atomic per channel per wave
     if constexpr (C::STATS || C::DOT) {
@@ -774,7 +861,13 @@ bool dge_conv_rgb_ok(const ConvParams& p, int dtype, int ksize) {
 
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s) {
 #define GO(CI, CO) if (p.Cin == CI && p.Cout == CO) return launch_flavour<CI, CO>(p, s)
+#ifdef DGE_SC_ONLY          // tuning builds: one channel configuration
+#define GO2(...) GO(__VA_ARGS__)
+    GO2(DGE_SC_ONLY);
+#undef GO2
+#else
     GO(16, 16); GO(16, 32); GO(16, 64); GO(32, 16); GO(32, 32); GO(32, 64); GO(64, 16); GO(64, 32); GO(64, 64);
+#endif
 #undef GO
     dge_set_error("conv_stream: unsupported channel configuration %d -> %d", p.Cin, p.Cout);
     return -1;
