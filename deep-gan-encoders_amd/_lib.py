@@ -23,6 +23,7 @@ class ConvDesc(C.Structure):
         ("prep_stats", C.c_void_p), ("mask_relu", C.c_int), ("in_t2d", C.c_int),
         ("rgb_w", C.c_void_p), ("rgb_style", C.c_void_p), ("rgb_bias", C.c_void_p), ("rgb_out", C.c_void_p), ("rgb_wscale", C.c_float),
         ("rgb_skip_y", C.c_int), ("pool_out", C.c_int), ("pool_mask", C.c_void_p),
+        ("prefetch_w", C.c_void_p), ("prefetch_ntot", C.c_int), ("prefetch_cin", C.c_int),
     ]
 
 

@@ -111,6 +111,9 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     p.rgb_w = d->rgb_out ? d->rgb_w : nullptr; p.rgb_style = d->rgb_style; p.rgb_bias = d->rgb_bias; p.rgb_out = d->rgb_out;
     p.rgb_wscale = d->rgb_wscale; p.rgb_skip_y = (d->rgb_out && d->rgb_skip_y) ? 1 : 0;
     p.pool_out = d->pool_out ? 1 : 0; p.pool_mask = d->pool_out ? (unsigned*)d->pool_mask : nullptr;
+    const bool pf = d->w_layout == 1 && d->prefetch_w && d->prefetch_ntot >= 64 && d->prefetch_ntot % 64 == 0 &&
+                    (d->prefetch_cin == 512 || d->prefetch_cin == 256);
+    p.pf_w = pf ? d->prefetch_w : nullptr; p.pf_ntot = pf ? d->prefetch_ntot : 0; p.pf_cin = pf ? d->prefetch_cin : 0;
     if (d->pool_out)
         DGE_CHECK(!d->up && dge_conv_pool_ok(p, d->dtype, d->ksize), "conv2d: the pooled epilogue is offered where dge_conv_pool_supported() "
                   "says so (conv_2 of the first encoder blocks on the streaming kernel)");

@@ -55,6 +55,11 @@ struct ConvParams {
     // (optional) receives the signs of the full-resolution values, [B, H/2*W/2, Cout/8] words (dge_blend_pool_mask's layout)
     int pool_out;
     unsigned* pool_mask;
+    // conv_small.hip only: fragment-ordered weights of the NEXT low-resolution launch of the stream (or null).  Every workgroup
+    // touches its share of the slice its XCD's workgroups will read, so that launch finds the 590 KB per N tile in L2 instead of
+    // pulling it from HBM behind a cold miss (measured 22-24 us cold against 13-17 us hot per launch at 4^2 .. 16^2).
+    const void* pf_w;
+    int pf_ntot, pf_cin;
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);

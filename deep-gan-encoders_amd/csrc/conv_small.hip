@@ -38,9 +38,13 @@ constexpr int A_MAX = HH * rpitch_of(CIN_MAX);                 // 106,240 B
 constexpr int RED_BYTES = 8 * 2 * 16 * 64 * 4;                 // K-quarter partial sums of all waves: 64 KB (over the dead halo tile)
 constexpr int EST_BYTES = 4 * 32 * SmallCfg::ESTR;             // epilogue staging of the 4 carrier waves
 constexpr int N_BYTES = 4 * SmallCfg::BM * 4;                  // noise tile (x4 phases in up mode)
-constexpr int LDS_BYTES = A_MAX + N_BYTES;
+constexpr int PF_BYTES = 8 * 256;                              // landing zone of the next launch's weight prefetch (never read)
+constexpr int LDS_BYTES = A_MAX + N_BYTES + PF_BYTES;
 static_assert(RED_BYTES + EST_BYTES <= A_MAX, "reduction + staging must fit the halo region");
 
+__device__ __forceinline__ unsigned lds_base_u32(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
 __device__ __forceinline__ f32x16_t mma(const uint4& a, const uint4& b, f32x16_t c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&a, *(const bf16x8_t*)&b, c, 0, 0, 0);
 }
@@ -81,6 +85,26 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
     for (int t = 0; t < PF; t++)
 #pragma unroll
         for (int j = 0; j < KQ; j++) bw[t][j] = *(const uint4*)(wbase + t * tap_stride + j * 1024);   // fly under the halo staging
+
+    // ---- L2 warm-up for the next low-resolution launch of the stream (ConvParams::pf_w): this workgroup runs on XCD blockIdx.x % 8,
+    // and so will the workgroups of that launch that read N tiles [x*nt/8, (x+1)*nt/8) (same XCD-aware order); the workgroups of
+    // an XCD share the lines of those slices, one 128-byte line per lane, as LDS-DMA into a dummy zone (no register is written,
+    // nothing waits: the requests drain behind the main loop; s_waitcnt vmcnt(0) at the end of the kernel).
+    if (p.pf_w) {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3, R = max(1, (int)gridDim.x >> 3);
+        const int nt_n = p.pf_ntot / BN, kst_n = p.pf_cin / 16;
+        const int n_lo = xcd * nt_n / 8, n_hi = max(n_lo + 1, (xcd + 1) * nt_n / 8);
+        const unsigned lines_tap = (unsigned)(n_hi - n_lo) * 2u * kst_n * 8u;            // 128-byte lines of the slice, per tap
+        const unsigned nlines = 9u * lines_tap;
+        const size_t tap_stride_n = (size_t)(p.pf_ntot / 32) * kst_n * 1024;
+        const unsigned m0v = lds_base_u32(lds) + A_MAX + N_BYTES + wave * 256;
+        for (unsigned l = (unsigned)r * 512u + tid; l - lane < nlines; l += (unsigned)R * 512u) {   // (wave-uniform trip count)
+            const unsigned tp = l / lines_tap, within = l - tp * lines_tap;
+            const unsigned char* a = (const unsigned char*)p.pf_w + tp * tap_stride_n + (size_t)n_lo * 2 * kst_n * 1024 + (size_t)within * 128;
+            if (l >= nlines) a = (const unsigned char*)p.pf_w;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" : : "v"(a), "s"(m0v) : "memory");
+        }
+    }
 
     // ---- halo tile of all input channels: global -> registers -> (affine) -> LDS, zero outside the image
     {
@@ -193,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_small_kernel(ConvParams p) {
     }
     conv_epilogue<bf16_t, SmallCfg, TH, TW, BN, 2, 2, 512, MODE>(p, tile, lds + RED_BYTES, ldsN, b, x0, y0, bn0, ntile, vbid, tx_i, ty_i,
                                                             wave, lane, tid, carrier);
+    if (p.pf_w) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the prefetch requests target this workgroup's LDS
 }
 
 int max_hw() {

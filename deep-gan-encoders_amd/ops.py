@@ -11,6 +11,8 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
 PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP, PACK_SG1_UP_DGRAD, PACK_UPT2D_DGRAD = 0, 1, 2, 3, 4, 5, 6
 PACK_FRAG = 0x100     # OR-ed into a pack mode: MFMA-fragment order for the low-resolution kernel (csrc/conv_small.hip)
+import os as _os
+_PF = {"on": not _os.environ.get("DGE_NO_PREFETCH"), "prev": None, "next": {}}     # low-resolution weight prefetch chain (conv2d)
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag, algorithmic_bytes) per conv launch
 
 
@@ -360,6 +362,16 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     d.ksize, d.up, d.in_s2d, d.in_up2 = ksize, 1 if up else 0, 1 if in_s2d else 0, 1 if in_up2 else 0
     d.in_relu = 1 if in_relu else 0
     d.w_layout = 1 if getattr(w_packed, "_dge_frag", False) else 0
+    if d.w_layout and _PF["on"]:
+        # L2 warm-up hint for the low-resolution kernel: the launch warms the weights of the low-resolution launch that followed it
+        # the LAST time it ran (a step repeats its launch sequence; packed copies keep their addresses) - dge_conv_desc.prefetch_w
+        key = w_packed.data_ptr()
+        if _PF["prev"] is not None and _PF["prev"] != key:
+            _PF["next"][_PF["prev"]] = (key, w_packed.shape[1], w_packed.shape[2], w_packed)
+        _PF["prev"] = key
+        nxt = _PF["next"].get(key)
+        if nxt is not None:
+            d.prefetch_w, d.prefetch_ntot, d.prefetch_cin = C.c_void_p(nxt[0]), int(nxt[1]), int(nxt[2])
     if prep is not None:
         if stats is None or dot_src is None:
             raise DgeError("conv2d: prep needs stats and dot_src")

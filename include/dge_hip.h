@@ -114,6 +114,11 @@ typedef struct dge_conv_desc {
      * position (2oy, 2ox), (2oy, 2ox+1), (2oy+1, 2ox), (2oy+1, 2ox+1), bit e = channel e of the 8-channel chunk). */
     int pool_out;             /* 0 / 1 */
     void* pool_mask;
+    /* Low-resolution launches (w_layout = 1) only, optional: w_packed / packed N / Cin of the NEXT such launch on this stream.  The
+     * launch then warms the L2 slices that one will read (its weights are 4.7 MB per layer and arrive HBM-cold otherwise).  Pure
+     * hint: no effect on results; NULL = none. */
+    const void* prefetch_w;
+    int prefetch_ntot, prefetch_cin;
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
