@@ -222,8 +222,10 @@ def test_hip_e_blur_gradients_vs_reference_golden(cd):
     x, w = E(img, noises=noises)
     loss = (x * R.randn("eb.gx", tuple(x.shape), 63).cuda()).sum() + (w * R.randn("eb.gw", tuple(w.shape), 63).cuda()).sum()
     loss.backward()
-    # (the functional is a signed sum with heavy cancellation: |loss| = 17 against sum|terms| ~ 1e3, hence 10 % in bf16)
-    assert abs(float(loss) - float(g["loss"])) < (2e-4 if cd == "f32" else 0.1) * abs(float(g["loss"]))
+    # (the functional is a signed sum with heavy cancellation: |loss| = 17 against sum|terms| ~ 1e3: one bf16 rounding of the terms
+    #  is ~ 4e-3 * 1e3 / 17 = 0.24 of |loss|; runs land at 0.02 .. 0.11 depending on the order of the f32 atomics - one of
+    #  ~12 runs of an unchanged build exceeded the former 0.1)
+    assert abs(float(loss) - float(g["loss"])) < (2e-4 if cd == "f32" else 0.25) * abs(float(g["loss"]))
     named = {k: p.grad for k, p in E.named_parameters()}
     if cd == "f32":
         # 1e-2 for the per-tensor L2 (see test_hip_e_pg_gradients_vs_reference_golden: leaky-relu kink flips move the small
