@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
 // written out as the nine 1 KiB pieces of every sample's image.
 __global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int K, float wscale,
                                     const float* __restrict__ in_scale, const float* __restrict__ out_scale, float gain, int nb, int mode) {
-    __shared__ float wl[16][32][9 + 1];                              // [row][k][tap] (+1: the tap-strided reads below)
+    __shared__ __attribute__((aligned(16))) float wl[16][9][32 + 4];         // [row][tap][k] (+4: the row / tap strided reads below)
     const int nchunks = K / 32, ntn = N / 128;
     int bid = blockIdx.x;
     const int pc = bid % 8; bid /= 8;
@@ -417,28 +417,32 @@ __global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restri
     if (mode == 0) {                       // w[n][k][tap]: per row 288 contiguous floats
         for (int idx = tid; idx < 16 * 288; idx += 256) {
             const int r = idx / 288, e = idx - r * 288;
-            wl[r][e / 9][e % 9] = w[((size_t)(n0 + r) * K + k0) * 9 + e] * wscale;
+            wl[r][e % 9][e / 9] = w[((size_t)(n0 + r) * K + k0) * 9 + e] * wscale;
         }
     } else {                               // w[k][n][8 - tap]: per k 144 contiguous floats
         for (int idx = tid; idx < 32 * 144; idx += 256) {
             const int k = idx / 144, e = idx - k * 144;
-            wl[e / 9][k][8 - e % 9] = w[((size_t)(k0 + k) * N + n0) * 9 + e] * wscale;
+            wl[e / 9][8 - e % 9][k] = w[((size_t)(k0 + k) * N + n0) * 9 + e] * wscale;
         }
     }
     __syncthreads();
+    // thread = (part qd, row r) of the piece, fixed over taps and samples: its 8 in-channel scales and its row's out-channel scale
+    // are loaded once per sample; per (sample, tap) it reads 8 consecutive floats and writes one 16-byte group
+    const int qd = (tid >> 4) & 3, r = tid & 15, tq = tid >> 6;          // taps tq, tq + 4, tq + 8
     for (int b = blockIdx.y; b < nb; b += gridDim.y) {
-        bf16_t* ob = out + ((((size_t)b * ntn + nt) * nchunks + kc) * 9 * 8 + pc) * 512;       // (elements; tap stride 8 * 512)
-        for (int idx = tid; idx < 9 * 64; idx += 256) {
-            const int t = idx >> 6, qd = (idx >> 4) & 3, r = idx & 15;
-            const float on = gain * (out_scale ? out_scale[(size_t)b * N + n0 + r] : 1.f);
-            float v[8];
+        float m[8];
+        const float on = gain * (out_scale ? out_scale[(size_t)b * N + n0 + r] : 1.f);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int k = qd * 8 + j;
-                const float m = (in_scale ? in_scale[(size_t)b * K + k0 + k] : 1.f) * on;
-                v[j] = wl[r][k][t] * m;
+        for (int j = 0; j < 8; j++) m[j] = (in_scale ? in_scale[(size_t)b * K + k0 + qd * 8 + j] : 1.f) * on;
+        bf16_t* ob = out + ((((size_t)b * ntn + nt) * nchunks + kc) * 9 * 8 + pc) * 512 + (qd * 16 + r) * 8;   // (elements; tap stride 8 * 512)
+#pragma unroll
+        for (int ti = 0; ti < 3; ti++) {
+            const int t = tq + 4 * ti;
+            if (t < 9) {
+                const float4 a = *(const float4*)&wl[r][t][qd * 8], c = *(const float4*)&wl[r][t][qd * 8 + 4];
+                const float v[8] = {a.x * m[0], a.y * m[1], a.z * m[2], a.w * m[3], c.x * m[4], c.y * m[5], c.z * m[6], c.w * m[7]};
+                *(uint4*)(ob + (size_t)t * 8 * 512) = pack16(v, (bf16_t*)nullptr);
             }
-            *(uint4*)(ob + (size_t)t * 8 * 512 + (qd * 16 + r) * 8) = pack16(v, (bf16_t*)nullptr);
         }
     }
 }
@@ -466,7 +470,7 @@ extern "C" int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, fl
     DGE_CHECK(N % 128 == 0 && K % 32 == 0 && nb >= 1 && (mode == 0 || mode == 1), "pack_conv_pp: N=%d must be a multiple of 128, K=%d of 32", N, K);
     DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_conv_pp: per-sample copies need a per-sample scale");
     const long grid = (long)(N / 128) * (K / 32) * 8;
-    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)nb), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode);
+    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)(grid >= 256 ? (nb + 1) / 2 : nb)), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode);
     DGE_LAUNCH_CHECK("pack_conv_pp");
     return 0;
 }

@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, "/root/repo")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))))
 import torch
 import dge_amd
 from dge_amd.encoder import BE
