@@ -149,6 +149,26 @@ def _dgrad_weight(L, dtype):
     return c[1]
 
 
+def _pp_dgrad(L, B, hg, dtype):
+    """the data gradient of this layer runs on conv_pp (GEMM K = out channels, x 4 phases for the folded up layer; N = in channels)"""
+    import os
+    K = 4 * L.out_c if L.up else L.out_c
+    return (not L.up or L.out_c % 32 == 0) and ops.conv_pp_supported(B, hg, hg, K, L.in_c, dtype) and not os.environ.get("DGE_NO_PP_DG")
+
+
+def _dgrad_weight_pp(L, d):
+    """per-sample data-gradient weight image of conv_pp: W'[b] = bf16(w * wscale * d[b, o]); the up layer goes through its folded f32
+    rows (packed once per weight version)"""
+    if not L.up:
+        return ops.pack_conv_pp(L.weight, L.wscale, in_scale=d, dgrad=True)
+    key = ("dgpp", L.weight._version, L.weight.data_ptr(), getattr(L.weight, "_dge_gen", 0))
+    c = L._cache.get("dgpp")
+    if c is None or c[0] != key:
+        c = (key, ops.pack_conv_weight(L.weight, ops.PACK_UPFOLD_DGRAD, ops.F32, L.wscale))
+        L._cache["dgpp"] = c
+    return ops.pack_conv_pp_rows(c[1], L.in_c, in_scale=d, in_period=L.out_c)
+
+
 def synthesis_backward(mod, wp, saved, g_image):
     """d(image)/d(wp) contracted with g_image [B,3,R,R] -> g_wp [B,num_layers,512].
 
@@ -214,7 +234,13 @@ def synthesis_backward(mod, wp, saved, g_image):
             Lp = getattr(mod, f"layer{i - 1}")
             P_next = ops.SlotStats(B, L.in_c, dev)
             prep = dict(gain=Lp.gain, noise=layers[i - 1]["noise"], ns=Lp.noise_strength.detach().reshape(1), stats=P_next)
-        if t2d:      # phase form: FIR^T (times the demodulation factor) to the t grid, then the 4-tap conv
+        hg = L.res // 2 if L.up else L.res
+        if fused and d_in is not None and not t2d and _pp_dgrad(L, B, hg, dt):
+            # MFMA-bound launches on the ping-pong kernel (csrc/conv_pp.hip): the demodulation factor is folded into a per-sample
+            # weight image instead of scaling g_z in a prologue
+            g_xprev = ops.conv_pp(g_y, _dgrad_weight_pp(L, d_in), L.in_c, dgrad=True, in_s2d=L.up, out_scale=rec["s"], addend=addend,
+                                  add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
+        elif t2d:      # phase form: FIR^T (times the demodulation factor) to the t grid, then the 4-tap conv
             g_xprev = ops.conv2d(ops.fir_t2d(g_y, d_in), _dgrad_weight(L, dt), L.in_c, 3, in_t2d=True, out_scale=rec["s"], addend=addend,
                                  add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
         else:

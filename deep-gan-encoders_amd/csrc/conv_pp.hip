@@ -39,6 +39,17 @@ struct PPParams {
     float bias_scale, gain;
     int tiles_x, tiles_y, ntn, nchunks;
     int dbg;
+    // halo source: plain (SH x SW pixels of SC = Cin channels) or space-to-depth (in_s2d: the image is [2H][2W][Cin/4], logical channel
+    // (phase py*2+px, c) of pixel (y, x) lives at pixel (2y+py, 2x+px); a 32-channel K chunk lies inside one phase)
+    int s2d, SW, SC, cpp;                     // cpp: K chunks per phase
+    long long x_bstride;                      // bytes per sample of the source image
+    // data-gradient epilogue (EPI == 2), the menu of conv_epilogue.h MODE 1 / 2 on the raw accumulator a:
+    //   stats += (sum a*dot, sum a); v = a*out_scale + add_scale*addend; mask_relu: v *= [dot > 0];
+    //   prep: v = g_z = v*prep_gain*lrelu'(dot), prep_stats += (sum g_z*(z - ns*noise), sum g_z)       (ConvParams::prep)
+    const float* out_scale; const bf16_t* dot; const bf16_t* add; float add_scale;
+    float* stats; float* prep_stats; int stats_slots;
+    int prep, mask_relu, prep_noise_bstride;
+    float prep_gain; const float* prep_noise; const float* prep_ns;
 };
 
 __device__ __forceinline__ unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -79,8 +90,11 @@ __host__ __device__ constexpr int wslot_off(int t) { return t < 3 ? WLO_OFF + t 
 // The DMAs of a cluster are issued between the MFMAs of its COMPUTE phase (two short asm statements with precomputed scalar
 // operands: in front of the LOAD phase they were on the critical path of the phase).  In the workgroup's last chunk the
 // requests go on as dummies (own halo tile, own first weight slots: nobody reads them) so that the wait counts stay the same.
-template <int PT, bool DBG, bool NWC>
+template <int PT, bool DBG, int EPI>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
+    // EPI 0 / 1: forward epilogue (scalar noise strength / noise weight per channel); EPI 2 + 2*flavour + addend: data-gradient epilogue,
+    // flavour 0 = statistics + fused tail backward (prep), 1 = statistics, 2 = ReLU mask
+    constexpr bool NWC = EPI == 1, DG = EPI >= 2, ADD = DG && ((EPI - 2) & 1), PREP = DG && ((EPI - 2) >> 1) == 0, MASK = DG && ((EPI - 2) >> 1) == 2;
     constexpr int TH = 4 * PT, HH = TH + 2, HPIX = HH * 34, HPIECES = (HPIX + 15) / 16, HPW = (HPIECES + 7) / 8;
     static_assert(HPW * 8 * 1024 <= WLO_OFF && HPW <= 8, "halo tile (incl. the all-zero pieces of the waves that have one piece less)");
     constexpr int VM_B = 6;                                              // W pieces a wave has issued after the one cluster c + 1 needs
@@ -126,8 +140,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
     };
     auto halo_src = [&](int tx0, int ty0, int tb) {
         const auto p = P();
-        const unsigned long long xb = (unsigned long long)p->x + (unsigned long long)tb * p->H * p->W * p->Cin * 2ull;
-        rs = make_rsrc(xb, (unsigned)(p->H * p->W * p->Cin * 2));
+        const unsigned long long xb = (unsigned long long)p->x + (unsigned long long)tb * (unsigned long long)p->x_bstride;
+        rs = make_rsrc(xb, (unsigned)p->x_bstride);
+        const int mul = p->s2d ? 2 : 1;
         // source offsets of this wave's halo pieces (piece P = wave + 8k: 16 pixels x 4 parts, lane = part*16 + pixel)
         // (recomputed per tile on purpose: hoisted out of the tile loop these lane constants are spilled around it)
         int lane_o = lane;
@@ -139,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
             const int hr = hp / 34, hx = hp - hr * 34;
             const int gy = ty0 + hr - 1, gx = tx0 + hx - 1;
             const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->H) & ((unsigned)gx < (unsigned)p->W);
-            hoff[k] = ok ? (unsigned)(((gy * p->W + gx) * p->Cin + qd * 8) * 2) : 0x80000000u;
+            hoff[k] = ok ? (unsigned)((((gy * p->SW + gx) * mul) * p->SC + qd * 8) * 2) : 0x80000000u;
         }
     };
     auto wbase = [&](int tb, int tnt) {
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
     // register allocator 250-600 spilled registers).  relaxed: first chunk after an epilogue with all NSTORE stores in the queue;
     // final: the workgroup's last chunk (no closing barrier).  wnext0: the piece requested after this chunk's tap-0 request (in a
     // tile's last chunk the stream jumps to the next tile's image); hsoff: channel byte offset of the halo tile requested here.
-    auto chunk = [&](bool relaxed, bool final, unsigned long long wnext0, unsigned hsoff) {
+    auto chunk = [&](int relaxed, bool final, unsigned long long wnext0, unsigned hsoff) {
         StaticFor<9>::run([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             constexpr int dy = t / 3, dx = t % 3;
@@ -203,7 +218,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
             // the weights of the NEXT cluster (and, at the last tap, the next halo tile) have landed - for this wave's pieces;
             // the barrier makes it true for everybody's.  lgkmcnt(0): this phase's reads are done before anyone overwrites.
             constexpr int VM_N = t == 8 ? VM_T8 : VM_B;
-            if (t < 7 && relaxed) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE) : "memory");
+            if (t < 7 && DG && relaxed == NSTORE + 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE + 4) : "memory");
+            else if (t < 7 && relaxed) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_N) : "memory");
             stamp(2);
             if (!(t == 8 && final && g == 1)) asm volatile("s_barrier" ::: "memory");
@@ -297,12 +313,19 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][j][r] = fmaf(A.anw[NWC ? j : 0][NWC ? r : 0], A.anz[i], A.ab[j][r]);
     };
-    { AddT A; add_load(A, x0, y0, b, nt); add_apply(A); }
+    if constexpr (DG) {
+#pragma unroll
+        for (int i = 0; i < PT; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    } else { AddT A; add_load(A, x0, y0, b, nt); add_apply(A); }
 
     // epilogue staging: lanes write (pixel, 16-byte piece) of 16 pixels x 32 channels, read back lane-linear = 4 lanes per pixel
     const unsigned est_w = PP_LDS + wave * 1024 + (l31 & 15) * 64 + kh * 16, est_r = PP_LDS + wave * 1024 + lane * 16;
 
-    bool relaxed = false;                       // an epilogue's NSTORE stores of this wave are in the queue
+    int relaxed = 0;                            // memory operations of this wave's last epilogue that may still be in the queue (NSTORE stores, + 4 atomics)
     for (;;) {
         const int next = tile + stride;
         const bool has_next = next < tile_end;
@@ -312,6 +335,11 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
             const bool lastc = kc == nchunks - 1;
             unsigned long long wnext0 = wptr + 8192ull;
             unsigned hsoff = (unsigned)(kc + 1) * 64u;
+            if (P()->s2d) {
+                const auto p = P();
+                const int ph = (kc + 1) / p->cpp, wi = (kc + 1) - ph * p->cpp;
+                hsoff = (unsigned)((((ph >> 1) * p->SW + (ph & 1)) * p->SC + wi * 32) * 2);
+            }
             if (lastc && has_next) {           // the stream runs on into the next tile: its halo source, its weight image
                 decode(next, nx0, ny0, nb_, nnt);
                 halo_src(nx0, ny0, nb_);
@@ -322,7 +350,210 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
                 wnext0 = wt;
                 hsoff = 0u;
             }
-            chunk(kc == 0 && relaxed, lastc && !has_next, wnext0, hsoff);
+            chunk(kc == 0 ? relaxed : 0, lastc && !has_next, wnext0, hsoff);
+        }
+        if constexpr (DG) {
+            // ---------------------------------------------------- data-gradient epilogue (conv_epilogue.h MODE 1 / 2 on this tile form)
+            // The raw f32 accumulators go through LDS one MFMA block (32 pixels x 32 channels) at a time (the halo buffer the last chunk
+            // read is free until the next tile's first cluster requests chunk 1 into it: 5 KiB per wave, pixel pitch 144 B) and come
+            // back in two rounds of 16 pixels: a lane holds 8 consecutive channels of one pixel = the 16 bytes of dot_src / addend / y
+            // it loads and stores (64-byte runs per pixel).  Rounds run (channel block j, row i, half r); the requests of round
+            // R + DEP are issued while round R is worked on.  No branch inside the rounds (the flavour is a template parameter, rows
+            // and columns outside the image are out-of-range offsets of the buffer descriptors: loads return zeros, stores are
+            // dropped, and the accumulators of such pixels are zeroed up front so that they stay out of the sums): every wave issues
+            // the same NSTORE stores, and the compiler's wait counts for the prefetched operands stay exact.
+            // Per-channel sums: 32 per lane and channel block (4 sums x 8 channels), reduce-scattered over the 16 pixel lanes (30
+            // exchange-adds) so that TWO atomic instructions with 64 distinct addresses flush a block.  The arithmetic is written on
+            // float pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): the seam is bound by VALU issue, two waves per SIMD.
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            stamp(5);
+            if (has_next) { if (g == 0) asm volatile("s_barrier" ::: "memory"); }
+            else asm volatile("s_barrier" ::: "memory");           // (last tile: group 1 has read the halo buffer before anyone scribbles on it)
+            const auto p = P();
+            const int H_ = p->H, W_ = p->W, Co = p->Cout, cb2 = Co * 2;
+            const unsigned ybytes = (unsigned)(H_ * W_) * (unsigned)cb2;
+            const size_t boff = (size_t)b * H_ * W_ * Co;
+            bf16_t* ybase = p->y + boff;
+            const bool has_dot = p->dot != nullptr;
+            const bool has_nz = PREP && p->prep_noise && p->prep_ns;
+            const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(ybase, 0, ybytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(has_dot ? (bf16_t*)p->dot + boff : ybase, 0, has_dot ? ybytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(ADD ? (bf16_t*)p->add + boff : ybase, 0, ADD ? ybytes : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_n = __builtin_amdgcn_make_buffer_rsrc(
+                has_nz ? (float*)p->prep_noise + (size_t)b * p->prep_noise_bstride : (float*)ybase, 0, has_nz ? (unsigned)(H_ * W_ * 4) : 0, 0x00020000);
+            const float pg = p->prep_gain, pz = 1.f / p->prep_gain;
+            const float pns = has_nz ? p->prep_ns[0] : 0.f;
+            const float add_scale = p->add_scale;
+            const float* osc = p->out_scale ? p->out_scale + (size_t)b * Co : nullptr;
+            float* const t_st = p->stats ? p->stats + ((size_t)(tile % p->stats_slots) * p->B + b) * Co * 2 : nullptr;
+            float* const t_pr = (PREP && p->prep_stats) ? p->prep_stats + ((size_t)(tile % p->stats_slots) * p->B + b) * Co * 2 : nullptr;
+            // byte offsets of this lane's pixel (first row of the wave's strip) + its 16 bytes of the 64-channel group; the row (and
+            // the channel block) is added per round, so a row below the image is past the descriptor's end by itself
+            unsigned voff[2], nvoff[2];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const int px = 16 * r + (lane >> 2);
+                const bool ok = x0 + px < W_;
+                voff[r] = ok ? (unsigned)(((y0 + PT * q) * W_ + x0 + px) * cb2 + (nt * 128 + g * 64) * 2 + (lane & 3) * 16) : 0x80000000u;
+                nvoff[r] = ok ? (unsigned)(((y0 + PT * q) * W_ + x0 + px) * 4) : 0x80000000u;
+            }
+            if (y0 + TH > H_ || x0 + 32 > W_) {
+                // ragged tile: the accumulators of pixels outside the image (computed from the zero-padded halo, not zero) must stay
+                // out of the sums
+                const bool cok = x0 + l31 < W_;
+                const int rows_ok = H_ - (y0 + PT * q);
+#pragma unroll
+                for (int i = 0; i < PT; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) acc[i][j][r] = (cok && i < rows_ok) ? acc[i][j][r] : 0.f;
+            }
+            const unsigned stg = (hm0 - wm0) + (unsigned)wave * 5120u;
+            const unsigned st_w = stg + l31 * 144 + kh * 32, st_r = stg + (lane >> 2) * 144 + (lane & 3) * 32;
+            const int cbase = nt * 128 + g * 64 + (lane & 3) * 8;            // + j*32: first of this lane's 8 channels on the read side
+            const unsigned rowb = (unsigned)(W_ * cb2), rown = (unsigned)(W_ * 4);
+            constexpr int DEP = 3;                       // rounds the requests run ahead (a round is ~0.7 us, an HBM miss 1.5-2.5)
+            u32x4_t dq[DEP], aq[ADD ? DEP : 1];
+            float nq[PREP ? DEP : 1];
+            auto issue = [&](auto Rc) {
+                constexpr int R = decltype(Rc)::value, j = R >> 3, i = (R >> 1) & 3, r = R & 1, sl = R % DEP;
+                if (DBG && (dbg & 1024)) return;
+                const unsigned vo = voff[r] + (unsigned)i * rowb;
+                dq[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo, j * 64, 0);
+                if constexpr (ADD) aq[sl] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, vo, j * 64, 0);
+                if constexpr (PREP) nq[sl] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_n, nvoff[r] + (unsigned)i * rown, 0, 0));
+            };
+            StaticFor<DEP>::run([&](auto Rc) { issue(Rc); });
+            v2f posc[4], ps0[4], ps1[4], pt0[4], pt1[4];
+            StaticFor<16>::run([&](auto Rc) {
+                constexpr int R = decltype(Rc)::value, j = R >> 3, i = (R >> 1) & 3, r = R & 1, sl = R % DEP;
+                if constexpr ((R & 7) == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { ps0[e] = 0.f; ps1[e] = 0.f; pt0[e] = 0.f; pt1[e] = 0.f; posc[e] = 1.f; }
+                    if (osc) {
+                        const float4 s0 = *(const float4*)(osc + cbase + j * 32), s1 = *(const float4*)(osc + cbase + j * 32 + 4);
+                        posc[0] = v2f{s0.x, s0.y}; posc[1] = v2f{s0.z, s0.w}; posc[2] = v2f{s1.x, s1.y}; posc[3] = v2f{s1.z, s1.w};
+                    }
+                }
+                if constexpr (r == 0) {
+                    // all 64 lanes park the block (32 pixels x 32 channels, f32) - both halves r read it back
+                    const f32x16_t a = acc[i][j];
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int e4 = 0; e4 < 2; e4++)
+                            *(float4*)(lds + st_w + h * 64 + e4 * 16) = make_float4(a[8 * h + 4 * e4], a[8 * h + 4 * e4 + 1], a[8 * h + 4 * e4 + 2], a[8 * h + 4 * e4 + 3]);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                v2f f[4];
+                {
+                    const float4 f0 = *(const float4*)(lds + st_r + r * 2304), f1 = *(const float4*)(lds + st_r + r * 2304 + 16);
+                    f[0] = v2f{f0.x, f0.y}; f[1] = v2f{f0.z, f0.w}; f[2] = v2f{f1.x, f1.y}; f[3] = v2f{f1.z, f1.w};
+                }
+                if constexpr (r == 1) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                const u32x4_t dv = dq[sl], av = aq[ADD ? sl : 0];
+                const float nzs = PREP ? pns * nq[PREP ? sl : 0] : 0.f;
+                if constexpr (R + DEP < 16) issue(std::integral_constant<int, R + DEP>{});
+                v2f d[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) d[e] = v2f{__uint_as_float(dv[e] << 16), __uint_as_float(dv[e] & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if constexpr (!MASK) ps0[e] = __builtin_elementwise_fma(f[e], d[e], ps0[e]);
+                    if constexpr (!MASK && !PREP) ps1[e] += f[e];           // (the synthesis chain has no use for the plain sum)
+                    f[e] *= posc[e];
+                }
+                if constexpr (ADD) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const v2f ad = v2f{__uint_as_float(av[e] << 16), __uint_as_float(av[e] & 0xffff0000u)};
+                        f[e] = __builtin_elementwise_fma(v2f{add_scale, add_scale}, ad, f[e]);
+                    }
+                }
+                if constexpr (MASK) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { f[e].x = d[e].x > 0.f ? f[e].x : 0.f; f[e].y = d[e].y > 0.f ? f[e].y : 0.f; }
+                }
+                if constexpr (PREP) {
+                    if (!(DBG && (dbg & 2048))) {
+                        // lrelu'(x) and the inverse activation from the stored x = lrelu(z)*gain: factor pairs (1, 1) for x > 0, (0.2, 5) else
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const bool p0 = d[e].x > 0.f, p1 = d[e].y > 0.f;
+                            const v2f sf = v2f{p0 ? pg : 0.2f * pg, p1 ? pg : 0.2f * pg}, zf = v2f{p0 ? pz : 5.f * pz, p1 ? pz : 5.f * pz};
+                            const v2f gz = f[e] * sf;
+                            const v2f zt = __builtin_elementwise_fma(d[e], zf, v2f{-nzs, -nzs});
+                            pt0[e] = __builtin_elementwise_fma(gz, zt, pt0[e]);
+                            pt1[e] += gz;
+                            f[e] = gz;
+                            __builtin_amdgcn_sched_barrier(0);       // (keeps the compare masks and gz / zt of one pair short-lived)
+                        }
+                    }
+                }
+                u32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) o[e] = pack2bf(f[e].x, f[e].y);
+                if (DBG && (dbg & 128)) asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+                else __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, voff[r] + (unsigned)i * rowb, j * 64, 0);
+                // One basic block: instruction selection is free to sink the sum updates down to the flush (keeping every round's
+                // operands alive: 150 spilled registers) - the empty asm statements pin them to their round
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    if constexpr (!MASK) asm volatile("" : "+v"(ps0[e]));
+                    if constexpr (!MASK && !PREP) asm volatile("" : "+v"(ps1[e]));
+                    if constexpr (PREP) asm volatile("" : "+v"(pt0[e]), "+v"(pt1[e]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((R & 7) == 7 && !MASK) {
+                    if ((t_st || t_pr) && !(DBG && (dbg & 512))) {
+                        float v[32];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            v[2 * e] = ps0[e].x; v[2 * e + 1] = ps0[e].y; v[8 + 2 * e] = ps1[e].x; v[9 + 2 * e] = ps1[e].y;
+                            v[16 + 2 * e] = pt0[e].x; v[17 + 2 * e] = pt0[e].y; v[24 + 2 * e] = pt1[e].x; v[25 + 2 * e] = pt1[e].y;
+                        }
+                        StaticFor<4>::run([&](auto Lc) {
+                            constexpr int L = decltype(Lc)::value, half = 16 >> L;
+                            const bool up = (lane >> (2 + L)) & 1;
+#pragma unroll
+                            for (int k = 0; k < half; k++) {
+                                const float keep = up ? v[half + k] : v[k], send = up ? v[k] : v[half + k];
+                                v[k] = keep + __shfl_xor(send, 4 << L, 64);
+                            }
+                        });
+                        // this lane's two sums: index (b2 b3 b4 b5 k) of (sum s = idx >> 3, channel e = idx & 7), bN = lane bit N
+                        const int sidx = (((lane >> 2) & 1) << 1) | ((lane >> 3) & 1);
+                        const int e0 = (((lane >> 4) & 1) << 2) | (((lane >> 5) & 1) << 1);
+                        float* tab = (sidx & 2) ? t_pr : t_st;
+                        if (tab) {
+                            float* dst = tab + (cbase + j * 32 + e0) * 2 + (sidx & 1);
+                            atomicAdd(dst, v[0]);
+                            atomicAdd(dst + 2, v[1]);
+                        }
+                    }
+                }
+            });
+#pragma unroll
+            for (int i = 0; i < PT; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            // the relaxed counts of the next tile's first chunk: NSTORE stores, + 4 atomic instructions when a statistics table
+            // exists (lanes whose table is null are masked off; the instruction is issued for the others)
+            relaxed = (DBG && (dbg & (128 | 512 | 16))) ? 0 : ((!MASK && (t_st || t_pr)) ? NSTORE + 4 : NSTORE);
+            if (has_next && g == 1) asm volatile("s_barrier" ::: "memory");
+            stamp(6);
+            if (!has_next) break;
+            tile = next; x0 = nx0; y0 = ny0; b = nb_; nt = nnt; wt = nwt;
+            continue;
         }
         // ------------------------------------------------------------ epilogue: activation, pack, 64-byte runs through LDS
         stamp(5);
@@ -387,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
                     }
                 }
             }
-            relaxed = !(DBG && ((dbg & 16) || (dbg & 128)));
+            relaxed = (DBG && ((dbg & 16) || (dbg & 128))) ? 0 : NSTORE;
             add_apply(A);
             if (has_next && g == 1) asm volatile("s_barrier" ::: "memory");
         }
@@ -405,7 +636,8 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
 // One workgroup per (N tile, K chunk, 16-row piece): its 16 x 32 x 9 source weights are read once, coalesced, into LDS and
 // written out as the nine 1 KiB pieces of every sample's image.
 __global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int K, float wscale,
-                                    const float* __restrict__ in_scale, const float* __restrict__ out_scale, float gain, int nb, int mode) {
+                                    const float* __restrict__ in_scale, const float* __restrict__ out_scale, float gain, int nb, int mode,
+                                    int src_rows, int in_period) {
     __shared__ __attribute__((aligned(16))) float wl[16][9][32 + 4];         // [row][tap][k] (+4: the row / tap strided reads below)
     const int nchunks = K / 32, ntn = N / 128;
     int bid = blockIdx.x;
@@ -419,10 +651,15 @@ __global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restri
             const int r = idx / 288, e = idx - r * 288;
             wl[r][e % 9][e / 9] = w[((size_t)(n0 + r) * K + k0) * 9 + e] * wscale;
         }
-    } else {                               // w[k][n][8 - tap]: per k 144 contiguous floats
+    } else if (mode == 1) {                // w[k][n][8 - tap]: per k 144 contiguous floats
         for (int idx = tid; idx < 32 * 144; idx += 256) {
             const int k = idx / 144, e = idx - k * 144;
             wl[e / 9][8 - e % 9][k] = w[((size_t)(k0 + k) * N + n0) * 9 + e] * wscale;
+        }
+    } else {                               // rows of a dge_pack_conv_weight copy in f32, [tap][src_rows][K]: 32 contiguous floats per (tap, row)
+        for (int idx = tid; idx < 9 * 16 * 32; idx += 256) {
+            const int k = idx & 31, r = (idx >> 5) & 15, t = idx >> 9;
+            wl[r][t][k] = w[((size_t)t * src_rows + n0 + r) * K + k0 + k] * wscale;
         }
     }
     __syncthreads();
@@ -433,7 +670,7 @@ __global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restri
         float m[8];
         const float on = gain * (out_scale ? out_scale[(size_t)b * N + n0 + r] : 1.f);
 #pragma unroll
-        for (int j = 0; j < 8; j++) m[j] = (in_scale ? in_scale[(size_t)b * K + k0 + qd * 8 + j] : 1.f) * on;
+        for (int j = 0; j < 8; j++) m[j] = (in_scale ? in_scale[(size_t)b * in_period + (k0 + qd * 8 + j) % in_period] : 1.f) * on;
         bf16_t* ob = out + ((((size_t)b * ntn + nt) * nchunks + kc) * 9 * 8 + pc) * 512 + (qd * 16 + r) * 8;   // (elements; tap stride 8 * 512)
 #pragma unroll
         for (int ti = 0; ti < 3; ti++) {
@@ -472,8 +709,21 @@ extern "C" int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, fl
     DGE_CHECK(N % 128 == 0 && K % 32 == 0 && nb >= 1 && (mode == 0 || mode == 1), "pack_conv_pp: N=%d must be a multiple of 128, K=%d of 32", N, K);
     DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_conv_pp: per-sample copies need a per-sample scale");
     const long grid = (long)(N / 128) * (K / 32) * 8;
-    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)(grid >= 256 ? (nb + 1) / 2 : nb)), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode);
+    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)(grid >= 256 ? (nb + 1) / 2 : nb)), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode, 0, K);
     DGE_LAUNCH_CHECK("pack_conv_pp");
+    return 0;
+}
+
+extern "C" int dge_pack_conv_pp_rows(const float* w_rows, int src_rows, void* out, int N, int K, const float* in_scale, int in_period,
+                                     const float* out_scale, float gain, int nb, hipStream_t s) {
+    DGE_CHECK(w_rows && out, "pack_conv_pp_rows: null tensor");
+    DGE_CHECK(N % 128 == 0 && K % 32 == 0 && nb >= 1 && src_rows >= N, "pack_conv_pp_rows: N=%d must be a multiple of 128 (<= src_rows=%d), K=%d of 32", N, src_rows, K);
+    DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_conv_pp_rows: per-sample copies need a per-sample scale");
+    DGE_CHECK(!in_scale || (in_period >= 1 && K % in_period == 0), "pack_conv_pp_rows: in_period=%d must divide K=%d", in_period, K);
+    const long grid = (long)(N / 128) * (K / 32) * 8;
+    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)(grid >= 256 ? (nb + 1) / 2 : nb)), dim3(256), 0, s, w_rows, (bf16_t*)out, N, K, 1.f, in_scale, out_scale, gain, nb, 2,
+                       src_rows, in_scale ? in_period : K);
+    DGE_LAUNCH_CHECK("pack_conv_pp_rows");
     return 0;
 }
 
@@ -482,7 +732,6 @@ extern "C" int dge_conv_pp(const dge_conv_pp_desc* d, hipStream_t s) {
     DGE_CHECK(dge_conv_pp_supported(d->B, d->H, d->W, d->Cin, d->Cout, DGE_BF16), "conv_pp: %dx%d Cin=%d Cout=%d B=%d is not a shape dge_conv_pp_supported() accepts",
               d->H, d->W, d->Cin, d->Cout, d->B);
     DGE_CHECK(!d->noise || d->noise_w, "conv_pp: noise needs its weight");
-    DGE_CHECK(!d->out_scale, "conv_pp: a per-sample output scale is folded into the weight image (dge_pack_conv_pp), not applied by the launch");
     DGE_CHECK(d->gain > 0.f, "conv_pp: the gain is folded into scale / noise / bias and must be positive");
     PPParams p;
     p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w_pp; p.y = (bf16_t*)d->y;
@@ -493,20 +742,47 @@ extern "C" int dge_conv_pp(const dge_conv_pp_desc* d, hipStream_t s) {
     p.bias_scale = d->bias_scale; p.gain = d->gain;
     p.tiles_x = (d->W + 31) / 32; p.tiles_y = (d->H + 15) / 16; p.ntn = d->Cout / 128; p.nchunks = d->Cin / 32;
     p.dbg = dge_env().conv_dbg;
+    p.s2d = d->in_s2d ? 1 : 0;
+    if (p.s2d) {
+        DGE_CHECK(d->dgrad, "conv_pp: in_s2d comes with the data-gradient form");
+        DGE_CHECK(d->Cin % 128 == 0, "conv_pp: in_s2d needs Cin / 4 = %d channels per phase in whole 32-channel chunks", d->Cin / 4);
+        p.SW = 2 * d->W; p.SC = d->Cin / 4; p.cpp = p.SC / 32;
+    } else { p.SW = d->W; p.SC = d->Cin; p.cpp = p.nchunks; }
+    p.x_bstride = (long long)d->H * d->W * d->Cin * 2;                 // (space-to-depth: 2H x 2W x Cin/4 - the same bytes)
+    p.out_scale = nullptr; p.dot = nullptr; p.add = nullptr; p.add_scale = 0.f; p.stats = nullptr; p.prep_stats = nullptr; p.stats_slots = 1;
+    p.prep = 0; p.mask_relu = 0; p.prep_noise_bstride = 0; p.prep_gain = 1.f; p.prep_noise = nullptr; p.prep_ns = nullptr;
+    if (d->dgrad) {
+        DGE_CHECK(!d->bias && !d->noise && d->act == DGE_ACT_NONE, "conv_pp: the data-gradient form has no bias / noise / activation");
+        DGE_CHECK(!d->prep || (d->dot_src && d->prep_stats && d->prep_gain > 0.f), "conv_pp: prep needs dot_src, prep_stats and a positive gain");
+        DGE_CHECK(!d->mask_relu || (d->dot_src && !d->prep), "conv_pp: mask_relu needs dot_src and excludes prep");
+        DGE_CHECK(!d->stats || d->dot_src, "conv_pp: statistics are (sum a*dot_src, sum a): dot_src missing");
+        DGE_CHECK(d->stats_slots >= 1 || (!d->stats && !d->prep_stats), "conv_pp: stats_slots");
+        p.out_scale = d->out_scale; p.dot = (const bf16_t*)d->dot_src; p.add = (const bf16_t*)d->addend; p.add_scale = d->add_scale;
+        p.stats = d->stats; p.prep_stats = d->prep ? d->prep_stats : nullptr; p.stats_slots = d->stats_slots >= 1 ? d->stats_slots : 1;
+        p.prep = d->prep ? 1 : 0; p.mask_relu = d->mask_relu ? 1 : 0; p.prep_gain = d->prep ? d->prep_gain : 1.f;
+        p.prep_noise = d->prep ? d->prep_noise : nullptr; p.prep_ns = d->prep ? d->prep_ns : nullptr;
+        p.prep_noise_bstride = d->prep_noise_batch > 1 ? d->H * d->W : 0;
+    } else {
+        DGE_CHECK(!d->out_scale, "conv_pp: a per-sample output scale is folded into the weight image (dge_pack_conv_pp), not applied by the launch");
+        DGE_CHECK(!d->dot_src && !d->addend && !d->stats && !d->prep && !d->mask_relu, "conv_pp: dot_src / addend / stats / prep / mask_relu belong to the data-gradient form (dgrad = 1)");
+    }
     const long tiles = (long)p.tiles_x * p.tiles_y * p.B * p.ntn;
-    // one workgroup per CU (152 KB of LDS each), 32 per XCD; each walks its share of its XCD's tile range
+    // one workgroup per CU (160 KB of LDS each), 32 per XCD; each walks its share of its XCD's tile range
     int cus = 256;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount / 8 * 8; }
     const long grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus;
-    dge_note_kernel("conv_pp<bf16,16,32,128>");
-    // NWC: noise weight per channel (model/E/E.py:60-62) instead of StyleGAN2's scalar strength
-    if (p.noise_w_stride) {
-        if (p.dbg) hipLaunchKernelGGL((conv_pp_kernel<4, true, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_pp_kernel<4, false, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
-    } else {
-        if (p.dbg) hipLaunchKernelGGL((conv_pp_kernel<4, true, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((conv_pp_kernel<4, false, false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    dge_note_kernel(d->dgrad ? (d->in_s2d ? (d->prep ? "conv_pp<bf16,16,32,128>+dg+s2d+prep" : "conv_pp<bf16,16,32,128>+dg+s2d")
+                                          : (d->prep ? "conv_pp<bf16,16,32,128>+dg+prep" : (d->mask_relu ? "conv_pp<bf16,16,32,128>+dg+mask" : "conv_pp<bf16,16,32,128>+dg")))
+                             : "conv_pp<bf16,16,32,128>");
+    // EPI 1: noise weight per channel (model/E/E.py:60-62) instead of StyleGAN2's scalar strength; EPI 2: data gradient
+    const int epi = d->dgrad ? 2 + 2 * (d->prep ? 0 : (d->mask_relu ? 2 : 1)) + (d->addend ? 1 : 0) : (p.noise_w_stride ? 1 : 0);
+#define PP_GO(E) do { if (p.dbg) hipLaunchKernelGGL((conv_pp_kernel<4, true, E>), dim3((unsigned)grid), dim3(512), 0, s, p); \
+                      else hipLaunchKernelGGL((conv_pp_kernel<4, false, E>), dim3((unsigned)grid), dim3(512), 0, s, p); } while (0)
+    switch (epi) {
+        case 0: PP_GO(0); break; case 1: PP_GO(1); break; case 2: PP_GO(2); break; case 3: PP_GO(3); break;
+        case 4: PP_GO(4); break; case 5: PP_GO(5); break; case 6: PP_GO(6); break; default: PP_GO(7); break;
     }
+#undef PP_GO
     DGE_LAUNCH_CHECK("conv_pp");
     return 0;
 }

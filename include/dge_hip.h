@@ -449,10 +449,30 @@ typedef struct dge_conv_pp_desc {
     int noise_w_per_channel;
     int act;                  /* DGE_ACT_* */
     float bias_scale, gain;
+    /* Data-gradient form (dgrad = 1; the epilogue menu of dge_conv_desc's dot_src / addend / stats / prep / mask_relu, same math:
+     * stylegan2_generator.py:908-921 adjoint, model/E/E.py:60-84 adjoint): on the raw accumulator a of W' (dge_pack_conv_pp mode 1 or
+     * dge_pack_conv_pp_rows, the demodulation factor of the layer above folded into K) -
+     *   stats[slot][b][c] += (sum a*dot_src, sum a) (with prep only the first: the synthesis chain has no use for the plain sum);
+ *   v = a*out_scale[b][c] + add_scale*addend;  mask_relu: v *= [dot_src > 0] (no statistics);
+     *   prep: v = g_z = v*prep_gain*lrelu'(dot_src), prep_stats[slot][b][c] += (sum g_z*(z - ns*noise), sum g_z), z = dot_src / (gain*slope).
+     * No bias / noise / activation.  in_s2d: x is [B,2H,2W,Cin/4] read space-to-depth (adjoint of the up layer in folded form,
+     * weights from dge_pack_conv_weight mode DGE_PACK_UPFOLD_DGRAD in f32 through dge_pack_conv_pp_rows). */
+    int dgrad, in_s2d, stats_slots, prep, prep_noise_batch, mask_relu;
+    float add_scale, prep_gain;
+    const void* dot_src;      /* [B,H,W,Cout] bf16 */
+    const void* addend;       /* [B,H,W,Cout] bf16 */
+    float* stats;             /* [stats_slots][B,Cout,2], pre-zeroed */
+    float* prep_stats;        /* [stats_slots][B,Cout,2], pre-zeroed */
+    const float* prep_noise;  /* [prep_noise_batch,H,W] or NULL */
+    const float* prep_ns;     /* device scalar or NULL */
 } dge_conv_pp_desc;
 int dge_conv_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype);
 int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, float wscale, const float* in_scale, const float* out_scale,
                      float gain, int nb, int mode, dge_stream_t stream);
+/* the same LDS image from rows of an f32 dge_pack_conv_weight copy [9][src_rows][K] (any of its modes: the folded up layer's data
+ * gradient, ...); in_scale [nb][in_period] repeats along K with period in_period (space-to-depth: the four phases of a channel) */
+int dge_pack_conv_pp_rows(const float* w_rows, int src_rows, void* out, int N, int K, const float* in_scale, int in_period,
+                          const float* out_scale, float gain, int nb, dge_stream_t stream);
 int dge_conv_pp(const dge_conv_pp_desc* d, dge_stream_t stream);
 
 /* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */

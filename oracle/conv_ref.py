@@ -142,6 +142,50 @@ def up_dgrad(g, w, wscale, hin):
     return torch.autograd.grad(y, x, g)[0]
 
 
+def upfold_weights(w, wscale=1.0):
+    """The up layer's linear part (`up_linear`: transposed conv with the flipped kernel, stride 2, then the 4x4 FIR,
+    stylegan2_generator.py:879-896) as FOUR 3x3 stride-1 convolutions, one per output phase: y[2m+py, 2n+px] = conv3x3(x, Wf[2py+px])[m, n].
+    Wf [4,O,I,3,3]; tap (a, c) reads x[m+a-1, n+c-1] and collects k1[ty] k1[tx] w[3-py-ty+2(a-1), 3-px-tx+2(c-1)], k1 = (1,3,3,1)/4.
+    (The folded form dge_pack_conv_weight builds; checked against up_linear in tests/test_oracle_golden.py.)"""
+    O, I = w.shape[:2]
+    k1 = torch.tensor([0.25, 0.75, 0.75, 0.25], dtype=w.dtype)
+    Wf = torch.zeros(4, O, I, 3, 3, dtype=w.dtype)
+    for py in range(2):
+        for px in range(2):
+            for a in range(3):
+                for c in range(3):
+                    for ty in range(4):
+                        wy = 3 - py - ty + 2 * (a - 1)
+                        if not 0 <= wy <= 2:
+                            continue
+                        for tx in range(4):
+                            wx = 3 - px - tx + 2 * (c - 1)
+                            if 0 <= wx <= 2:
+                                Wf[2 * py + px, :, :, a, c] += k1[ty] * k1[tx] * w[:, :, wy, wx]
+    return Wf * wscale
+
+
+def up_folded(x, Wf):
+    """the four phase convolutions of `upfold_weights`, interleaved: [B,I,H,W] -> [B,O,2H,2W]"""
+    B, _, H, W = x.shape
+    y = torch.zeros(B, Wf.shape[1], 2 * H, 2 * W, dtype=x.dtype)
+    for ph in range(4):
+        y[:, :, (ph >> 1)::2, (ph & 1)::2] = F.conv2d(x, Wf[ph], padding=1)
+    return y
+
+
+def dgrad_folded(g, w, wscale, d, up=False, q=_ident):
+    """Raw data gradient (before the style factor of the layer's input) of a modulated conv whose demodulation factor d [O] is
+    folded into the weight the gradient conv reads, W' = q(w*wscale*d[o]) (stride 1) / q(Wf*d[o]) (up layer in folded form): the
+    per-sample data-gradient weight image of csrc/conv_pp.hip.  g [1,O,Hg,Wg] -> [1,I,H,W], computed in f64."""
+    gd = g.double()
+    if not up:
+        return F.conv_transpose2d(gd, q(w * wscale * d[:, None, None, None]).double(), padding=1).float()
+    Wq = q(upfold_weights(w, wscale) * d[None, :, None, None, None]).double()
+    x = torch.zeros(1, w.shape[1], g.shape[2] // 2, g.shape[3] // 2, dtype=torch.float64, requires_grad=True)
+    return torch.autograd.grad(up_folded(x, Wq), x, gd)[0].float()
+
+
 def conv_wgrad(g, xn, k):
     """dW[o,i,ky,kx] = sum_{b,y,x} g[b,o,y,x] * xn[b,i,y+ky-p,x+kx-p] (zero padding): k*k plain matrix products"""
     p = k // 2

@@ -414,3 +414,24 @@ def test_step_ref_reproduces_the_reference_run():
                 close(rec["grad2"][key.split(":", 1)[1]], g[key], rtol=2e-3)
             if key.startswith(f"it{it}_after_phase2:"):
                 close(PE[key.split(":", 1)[1]].detach(), g[key], rtol=2e-5)
+
+
+def test_folded_up_layer_oracle_equals_the_reference_form():
+    """oracle/conv_ref.py:upfold_weights / up_folded / dgrad_folded (the four-phase 3x3 form whose data gradient csrc/conv_pp.hip
+    computes) against up_linear, the restatement of the reference's transposed conv + FIR (stylegan2_generator.py:879-896) that the
+    golden blocks pin above."""
+    from oracle import conv_ref as CR
+    torch.manual_seed(5)
+    w, x = torch.randn(6, 5, 3, 3), torch.randn(2, 5, 7, 9)
+    a = CR.up_linear(x, w, 0.3)
+    b = CR.up_folded(x.double(), CR.upfold_weights(w.double(), 0.3))
+    assert (a - b).abs().max().item() < 2e-6 * a.abs().max().item()
+    g = torch.randn(1, 6, 14, 18)
+    xx = torch.zeros(1, 5, 7, 9, requires_grad=True)
+    want = torch.autograd.grad(CR.up_linear(xx, w, 0.3), xx, g)[0]
+    got = CR.dgrad_folded(g, w, 0.3, torch.ones(6), up=True)
+    assert (got - want).abs().max().item() < 2e-6 * want.abs().max().item()
+    d = 0.5 + torch.rand(6)
+    want1 = CR.conv_dgrad(g * d[None, :, None, None], w, 0.3)
+    got1 = CR.dgrad_folded(g, w, 0.3, d)
+    assert (got1 - want1).abs().max().item() < 2e-6 * want1.abs().max().item()

@@ -12,8 +12,18 @@ w = torch.randn(cout, cin, 3, 3, device="cuda")
 s = 1.0 + 0.3 * torch.randn(B, cin, device="cuda"); d = 0.5 + torch.rand(B, cout, device="cuda")
 bias = torch.randn(cout, device="cuda"); nz = torch.randn(1, H, H, device="cuda"); nw = torch.full((1,), 0.3, device="cuda")
 wpp = ops.pack_conv_pp(w, 1.0 / (9 * cin) ** 0.5, in_scale=s, out_scale=d, gain=2 ** 0.5)
+DG = len(sys.argv) > 5 and sys.argv[5] == "dg"
+if DG:      # the data-gradient form with the fused tail backward (x plays g_z; cin -> cout is the GEMM's K -> N)
+    wpp = ops.pack_conv_pp(w, 1.0 / (9 * cout) ** 0.5, in_scale=s, dgrad=True)
+    xin = torch.randn(B, H, H, cout, device="cuda").bfloat16(); so = 1.0 + 0.3 * torch.randn(B, cout, device="cuda")
+    w = w.transpose(0, 1).contiguous()
+    wpp = ops.pack_conv_pp(w, 1.0 / (9 * cout) ** 0.5, in_scale=s, dgrad=True)
 for _ in range(3):
-    y = ops.conv_pp(x, wpp, cout, bias=bias, noise=nz, noise_w=nw, act=1, gain=2 ** 0.5)
+    if DG:
+        st, P = ops.SlotStats(B, cout, "cuda"), ops.SlotStats(B, cout, "cuda")
+        y = ops.conv_pp(x, wpp, cout, dgrad=True, out_scale=so, stats=st, dot_src=xin, prep=dict(gain=2 ** 0.5, noise=nz, ns=nw, stats=P))
+    else:
+        y = ops.conv_pp(x, wpp, cout, bias=bias, noise=nz, noise_w=nw, act=1, gain=2 ** 0.5)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 2048)()
 f = lib().dge_dbg_pp_prof
