@@ -34,7 +34,7 @@ class ConvPPDesc(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int), ("Cout", C.c_int),
         ("noise_batch", C.c_int), ("noise_w_per_channel", C.c_int), ("act", C.c_int), ("bias_scale", C.c_float), ("gain", C.c_float),
         ("dgrad", C.c_int), ("in_s2d", C.c_int), ("stats_slots", C.c_int), ("prep", C.c_int), ("prep_noise_batch", C.c_int), ("mask_relu", C.c_int),
-        ("add_scale", C.c_float), ("prep_gain", C.c_float),
+        ("in_t2d", C.c_int), ("add_scale", C.c_float), ("prep_gain", C.c_float),
         ("dot_src", C.c_void_p), ("addend", C.c_void_p), ("stats", C.c_void_p), ("prep_stats", C.c_void_p), ("prep_noise", C.c_void_p), ("prep_ns", C.c_void_p),
     ]
 
@@ -161,7 +161,7 @@ SIGNATURES = {
     "dge_heads_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],
     "dge_conv_pp_supported": [_I, _I, _I, _I, _I, _I],
     "dge_pack_conv_pp": [_P, _P, _I, _I, _F, _P, _P, _F, _I, _I, _P],
-    "dge_pack_conv_pp_rows": [_P, _I, _P, _I, _I, _P, _I, _P, _F, _I, _P],
+    "dge_pack_conv_pp_rows": [_P, _I, _P, _I, _I, _P, _I, _P, _F, _I, _I, _P],
     "dge_conv_pp": [C.POINTER(ConvPPDesc), _P],
 }
 

@@ -156,17 +156,19 @@ def _pp_dgrad(L, B, hg, dtype):
     return (not L.up or L.out_c % 32 == 0) and ops.conv_pp_supported(B, hg, hg, K, L.in_c, dtype) and not os.environ.get("DGE_NO_PP_DG")
 
 
-def _dgrad_weight_pp(L, d):
-    """per-sample data-gradient weight image of conv_pp: W'[b] = bf16(w * wscale * d[b, o]); the up layer goes through its folded f32
-    rows (packed once per weight version)"""
+def _dgrad_weight_pp(L, d, t2d=False):
+    """data-gradient weight image of conv_pp.  Stride 1 / folded up layer: per sample, W'[b] = bf16(w * wscale * d[b, o]) (the up layer
+    through its folded f32 rows, packed once per weight version); phase form: one shared 4-tap image, cached per weight version"""
     if not L.up:
         return ops.pack_conv_pp(L.weight, L.wscale, in_scale=d, dgrad=True)
-    key = ("dgpp", L.weight._version, L.weight.data_ptr(), getattr(L.weight, "_dge_gen", 0))
-    c = L._cache.get("dgpp")
+    name = "dgpp_t2d" if t2d else "dgpp"
+    key = (name, L.weight._version, L.weight.data_ptr(), getattr(L.weight, "_dge_gen", 0))
+    c = L._cache.get(name)
     if c is None or c[0] != key:
-        c = (key, ops.pack_conv_weight(L.weight, ops.PACK_UPFOLD_DGRAD, ops.F32, L.wscale))
-        L._cache["dgpp"] = c
-    return ops.pack_conv_pp_rows(c[1], L.in_c, in_scale=d, in_period=L.out_c)
+        rows = ops.pack_conv_weight(L.weight, ops.PACK_UPT2D_DGRAD if t2d else ops.PACK_UPFOLD_DGRAD, ops.F32, L.wscale)
+        c = (key, ops.pack_conv_pp_rows(rows, L.in_c, t2d=True) if t2d else rows)
+        L._cache[name] = c
+    return c[1] if t2d else ops.pack_conv_pp_rows(c[1], L.in_c, in_scale=d, in_period=L.out_c)
 
 
 def synthesis_backward(mod, wp, saved, g_image):
@@ -240,6 +242,10 @@ def synthesis_backward(mod, wp, saved, g_image):
             # weight image instead of scaling g_z in a prologue
             g_xprev = ops.conv_pp(g_y, _dgrad_weight_pp(L, d_in), L.in_c, dgrad=True, in_s2d=L.up, out_scale=rec["s"], addend=addend,
                                   add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
+        elif t2d and fused and prep is not None and _pp_dgrad(L, B, hg, dt):
+            # phase form on the ping-pong kernel: the same FIR^T pass, then the 4-tap conv with ONE shared weight image
+            g_xprev = ops.conv_pp(ops.fir_t2d(g_y, d_in), _dgrad_weight_pp(L, None, t2d=True), L.in_c, dgrad=True, in_t2d=True, out_scale=rec["s"],
+                                  addend=addend, add_scale=1.0, stats=st, dot_src=x_in, prep=prep)
         elif t2d:      # phase form: FIR^T (times the demodulation factor) to the t grid, then the 4-tap conv
             g_xprev = ops.conv2d(ops.fir_t2d(g_y, d_in), _dgrad_weight(L, dt), L.in_c, 3, in_t2d=True, out_scale=rec["s"], addend=addend,
                                  add_scale=1.0, stats=st, dot_src=x_in, prep=prep)

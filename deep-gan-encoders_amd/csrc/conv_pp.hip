@@ -39,6 +39,7 @@ struct PPParams {
     float bias_scale, gain;
     int tiles_x, tiles_y, ntn, nchunks;
     int dbg;
+    int VH, VW;                               // extent of the halo source in (virtual) pixels: H x W, or (H + 1) x (W + 1) under in_t2d
     // halo source: plain (SH x SW pixels of SC = Cin channels) or space-to-depth (in_s2d: the image is [2H][2W][Cin/4], logical channel
     // (phase py*2+px, c) of pixel (y, x) lives at pixel (2y+py, 2x+px); a 32-channel K chunk lies inside one phase)
     int s2d, SW, SC, cpp;                     // cpp: K chunks per phase
@@ -90,15 +91,21 @@ __host__ __device__ constexpr int wslot_off(int t) { return t < 3 ? WLO_OFF + t 
 // The DMAs of a cluster are issued between the MFMAs of its COMPUTE phase (two short asm statements with precomputed scalar
 // operands: in front of the LOAD phase they were on the critical path of the phase).  In the workgroup's last chunk the
 // requests go on as dummies (own halo tile, own first weight slots: nobody reads them) so that the wait counts stay the same.
-template <int PT, bool DBG, int EPI>
+// T2D (phase-form adjoint of the up layers, dge_fir_t2d + ConvParams::in_t2d): the source image has one more row and column than the
+// output grid and only the taps (dy, dx) in {1, 2}^2 exist: a chunk is 4 clusters.  The weight ring then holds two chunks (8 slots,
+// slot offsets in SGPRs, swapped per chunk), requests run 7 clusters ahead, and the five halo pieces of a wave go out with taps 0-2.
+template <int PT, bool DBG, int EPI, bool T2D = false>
 __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
     // EPI 0 / 1: forward epilogue (scalar noise strength / noise weight per channel); EPI 2 + 2*flavour + addend: data-gradient epilogue,
     // flavour 0 = statistics + fused tail backward (prep), 1 = statistics, 2 = ReLU mask
     constexpr bool NWC = EPI == 1, DG = EPI >= 2, ADD = DG && ((EPI - 2) & 1), PREP = DG && ((EPI - 2) >> 1) == 0, MASK = DG && ((EPI - 2) >> 1) == 2;
     constexpr int TH = 4 * PT, HH = TH + 2, HPIX = HH * 34, HPIECES = (HPIX + 15) / 16, HPW = (HPIECES + 7) / 8;
     static_assert(HPW * 8 * 1024 <= WLO_OFF && HPW <= 8, "halo tile (incl. the all-zero pieces of the waves that have one piece less)");
-    constexpr int VM_B = 6;                                              // W pieces a wave has issued after the one cluster c + 1 needs
-    constexpr int VM_T8 = (VM_B + 3 - HPW) < VM_B ? (VM_B + 3 - HPW) : VM_B;   // ... after its last halo piece of the chunk
+    constexpr int NTAP = T2D ? 4 : 9, WAHEAD = T2D ? 7 : 8;              // clusters per chunk; clusters the weight requests run ahead
+    constexpr int VM_B = WAHEAD - 2;                                     // W pieces a wave has issued after the one cluster c + 1 needs
+    // ... after its last halo piece of the chunk (9 taps: pieces with taps 0-4, then the W pieces of taps 4-7; T2D: last piece with tap 2)
+    constexpr int VM_T8 = T2D ? 1 : ((VM_B + 3 - HPW) < VM_B ? (VM_B + 3 - HPW) : VM_B);
+    constexpr int RLX = T2D ? 3 : 7;                                     // clusters after an epilogue whose W piece was requested before it
     constexpr int NSTORE = 4 * PT;                                       // stores of one epilogue, per wave
     __shared__ __attribute__((aligned(1024))) unsigned char lds[PP_LDS + 8192];
     const unsigned lds0 = lds_off(lds);
@@ -153,13 +160,13 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
             const int hp = Pc * 16 + (lane_o & 15), qd = lane_o >> 4;
             const int hr = hp / 34, hx = hp - hr * 34;
             const int gy = ty0 + hr - 1, gx = tx0 + hx - 1;
-            const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->H) & ((unsigned)gx < (unsigned)p->W);
+            const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->VH) & ((unsigned)gx < (unsigned)p->VW);
             hoff[k] = ok ? (unsigned)((((gy * p->SW + gx) * mul) * p->SC + qd * 8) * 2) : 0x80000000u;
         }
     };
     auto wbase = [&](int tb, int tnt) {
         const auto p = P();
-        return (unsigned long long)p->w + (unsigned long long)tb * p->w_bstride + (unsigned long long)tnt * nchunks * (9ull * 8192) +
+        return (unsigned long long)p->w + (unsigned long long)tb * p->w_bstride + (unsigned long long)tnt * nchunks * ((unsigned long long)NTAP * 8192) +
                (unsigned)wave * 1024u;
     };
     const unsigned wvoff = lane * 16;
@@ -175,12 +182,16 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
             const int hp = (PT * q + rr) * 34 + l31 + dx;
             atab[rr][dx] = (unsigned)((hp >> 4) * 1024 + (hp & 15) * 16 + kh * 256);
         }
-    unsigned wlo, whi;
+    unsigned wlo, whi, wl;
     {
         const int n = tr_chan_of_row(l31);
-        const unsigned wl = (unsigned)(g * 4096 + (n >> 4) * 1024 + (n & 15) * 16 + kh * 256);
+        wl = (unsigned)(g * 4096 + (n >> 4) * 1024 + (n & 15) * 16 + kh * 256);
         wlo = WLO_OFF + wl; whi = WHI_OFF + wl;
     }
+    // T2D: slot offsets of the chunk being read (wcur) and of the other one (wx = wcur ^ other: the swap is four s_xor)
+    unsigned wcur[4], wx[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { wcur[t] = wslot_off(t); wx[t] = wslot_off(t) ^ wslot_off(4 + t); }
     f32x16_t acc[PT][2];
 
     // ---- prologue: halo tile of chunk 0 of the first tile, weights of its clusters 0 .. 7
@@ -188,10 +199,10 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
     halo_src(x0, y0, b);
     wt = wbase(b, nt);
     StaticFor<HPW>::run([&](auto kc_) { constexpr int k = decltype(kc_)::value; dma_buf(hoff[k], rs, 0u, rfl(wm0 + k * 8192)); });
-    StaticFor<8>::run([&](auto cc) { constexpr int c = decltype(cc)::value; dma_lin(wvoff, wt + c * 8192ull, rfl(wm0 + wslot_off(c))); });
+    StaticFor<WAHEAD>::run([&](auto cc) { constexpr int c = decltype(cc)::value; dma_lin(wvoff, wt + c * 8192ull, rfl(wm0 + wslot_off(c))); });
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     if (g == 1) asm volatile("s_barrier" ::: "memory");                 // group 1 runs one phase behind group 0
-    unsigned long long wptr = wt + 8 * 8192ull;                         // weight piece the next request reads (cluster c + 8)
+    unsigned long long wptr = wt + WAHEAD * 8192ull;                    // weight piece the next request reads (cluster c + WAHEAD)
     unsigned hm0 = wm0 + H1_OFF;                                        // this wave's first piece of the halo buffer being FILLED
 
     // One chunk = 9 clusters; ONE instance of this body in the kernel (copies of it at the merge points of the tile loop cost the
@@ -199,9 +210,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
     // final: the workgroup's last chunk (no closing barrier).  wnext0: the piece requested after this chunk's tap-0 request (in a
     // tile's last chunk the stream jumps to the next tile's image); hsoff: channel byte offset of the halo tile requested here.
     auto chunk = [&](int relaxed, bool final, unsigned long long wnext0, unsigned hsoff) {
-        StaticFor<9>::run([&](auto tc) {
+        StaticFor<NTAP>::run([&](auto tc) {
             constexpr int t = decltype(tc)::value;
-            constexpr int dy = t / 3, dx = t % 3;
+            constexpr int dy = T2D ? 1 + t / 2 : t / 3, dx = T2D ? 1 + t % 2 : t % 3;
             // ------------------------------------------------ LOAD phase of cluster c0 + t
             stamp(1);
             uint4 xa[PT][2], wa[2][2];
@@ -209,63 +220,88 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
             for (int i = 0; i < PT; i++)
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) xa[i][ks] = *(const uint4*)(lds + atab[i + dy][dx] + ks * 512);
+            const unsigned wrd = T2D ? wl + wcur[t] : (t < 3 ? wlo + t * 8192 : whi + (t - 3) * 8192);
 #pragma unroll
             for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int ks = 0; ks < 2; ks++)
-                    wa[j][ks] = *(const uint4*)(lds + (t < 3 ? wlo + t * 8192 : whi + (t - 3) * 8192) + j * 2048 + ks * 512);
+                for (int ks = 0; ks < 2; ks++) wa[j][ks] = *(const uint4*)(lds + wrd + j * 2048 + ks * 512);
             __builtin_amdgcn_sched_barrier(0);
             // the weights of the NEXT cluster (and, at the last tap, the next halo tile) have landed - for this wave's pieces;
             // the barrier makes it true for everybody's.  lgkmcnt(0): this phase's reads are done before anyone overwrites.
-            constexpr int VM_N = t == 8 ? VM_T8 : VM_B;
-            if (t < 7 && DG && relaxed == NSTORE + 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE + 4) : "memory");
-            else if (t < 7 && relaxed) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE) : "memory");
+            constexpr int VM_N = t == NTAP - 1 ? VM_T8 : VM_B;
+            if (t < RLX && DG && relaxed == NSTORE + 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE + 4) : "memory");
+            else if (t < RLX && relaxed) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_B + NSTORE) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(VM_N) : "memory");
             stamp(2);
-            if (!(t == 8 && final && g == 1)) asm volatile("s_barrier" ::: "memory");
+            if (!(t == NTAP - 1 && final && g == 1)) asm volatile("s_barrier" ::: "memory");
             stamp(3);
             __builtin_amdgcn_sched_barrier(0);
             // ------------------------------------------------ COMPUTE phase: 16 MFMAs, the cluster's DMA requests in their shadow
+            // halo pieces of the tile the next chunk reads: 9 taps - piece t behind MFMA 3 of taps 0 .. HPW-1; T2D - pieces 2t, 2t + 1
+            // behind MFMAs 3 and 11.  Weight piece of cluster c + WAHEAD behind MFMA 7, into the slot cluster c - 1 was read from.
+            // (macros, not lambdas: clang rejects the captures of a generic lambda nested this deep as inline-asm operands)
+#define PP_HALO_REQ(HPI)                                                                                                            \
+            if (!(DBG && (dbg & 4)))                                                                                                \
+                asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"                         \
+                             :: "v"(hoff[(HPI) < HPW ? (HPI) : 0]), "s"(hm0), "s"(rs), "s"(hsoff), "i"((HPI) * 8192) : "memory", "scc")
+#define PP_W_REQ()                                                                                                                  \
+            do {                                                                                                                    \
+                if (!(DBG && (dbg & 1))) {                                                                                          \
+                    if constexpr (T2D) {                                                                                            \
+                        const unsigned tgt = t == 0 ? (wcur[3] ^ wx[3]) : wcur[t == 0 ? 0 : t - 1];                                 \
+                        asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"                           \
+                                     :: "v"(wvoff), "s"(wm0), "s"(wptr), "s"(tgt) : "memory", "scc");                               \
+                    } else {                                                                                                        \
+                        asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"                           \
+                                     :: "v"(wvoff), "s"(wm0), "s"(wptr), "i"(wslot_off((t + 8) % 9)) : "memory", "scc");            \
+                    }                                                                                                               \
+                }                                                                                                                   \
+                wptr = t == 0 ? wnext0 : wptr + 8192ull;                                                                            \
+            } while (0)
+            constexpr int HP0 = T2D ? 2 * t : t, HP1 = T2D ? 2 * t + 1 : HPW;          // (HPW = none)
             if (!(DBG && (dbg & 2))) {
                 __builtin_amdgcn_s_setprio(1);
                 StaticFor<16>::run([&](auto mc) {
                     constexpr int m = decltype(mc)::value, ks = m >> 3, i = (m >> 1) & (PT - 1), j = m & 1;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wa[j][ks], *(const bf16x8_t*)&xa[i][ks],
                                                                         acc[i][j], 0, 0, 0);
-                    if constexpr (m == 3 && t < HPW) {      // halo piece t of the tile the next chunk reads
+                    if constexpr (m == 3 && HP0 < HPW) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!(DBG && (dbg & 4)))
-                            asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
-                                         :: "v"(hoff[t]), "s"(hm0), "s"(rs), "s"(hsoff), "i"(t * 8192) : "memory");
+                        PP_HALO_REQ(HP0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (m == 7) {                  // weight piece of cluster c + 8 into the slot cluster c - 1 was read from
+                    if constexpr (m == 11 && HP1 < HPW) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!(DBG && (dbg & 1)))
-                            asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                                         :: "v"(wvoff), "s"(wm0), "s"(wptr), "i"(wslot_off((t + 8) % 9)) : "memory");
-                        wptr = t == 0 ? wnext0 : wptr + 8192ull;
+                        PP_HALO_REQ(HP1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (m == 7) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        PP_W_REQ();
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
                 __builtin_amdgcn_s_setprio(0);
             } else {
-                if constexpr (t < HPW)
-                    asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
-                                 :: "v"(hoff[t]), "s"(hm0), "s"(rs), "s"(hsoff), "i"(t * 8192) : "memory");
-                asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                             :: "v"(wvoff), "s"(wm0), "s"(wptr), "i"(wslot_off((t + 8) % 9)) : "memory");
-                wptr = t == 0 ? wnext0 : wptr + 8192ull;
+                if constexpr (HP0 < HPW) { PP_HALO_REQ(HP0); }
+                PP_W_REQ();
+                if constexpr (HP1 < HPW) { PP_HALO_REQ(HP1); }
 #pragma unroll
                 for (int i = 0; i < PT; i++)
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++) asm volatile("" :: "v"(xa[i][ks].x), "v"(xa[i][ks].w), "v"(wa[i & 1][ks].x), "v"(wa[i & 1][ks].w));
             }
+#undef PP_HALO_REQ
+#undef PP_W_REQ
             __builtin_amdgcn_sched_barrier(0);
             stamp(4);
-            if (!(t == 8 && final)) asm volatile("s_barrier" ::: "memory");
+            if (!(t == NTAP - 1 && final)) asm volatile("s_barrier" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         });
+        if constexpr (T2D) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) wcur[t] ^= wx[t];
+        }
         hm0 ^= (unsigned)H1_OFF;                   // the next chunk reads the buffer just filled and fills the other one
 #pragma unroll
         for (int rr = 0; rr < PT + 2; rr++)
@@ -333,6 +369,9 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
         unsigned long long nwt = 0;
         for (int kc = 0; kc < nchunks; kc++) {
             const bool lastc = kc == nchunks - 1;
+            // the chunk whose tap-0 request is the last one into this tile's weight image (9 taps: the request of tap t is for tap
+            // t - 1 of the next chunk; T2D: of the chunk after the next)
+            const bool wjump = T2D ? kc == nchunks - 2 : lastc;
             unsigned long long wnext0 = wptr + 8192ull;
             unsigned hsoff = (unsigned)(kc + 1) * 64u;
             if (P()->s2d) {
@@ -340,14 +379,12 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
                 const int ph = (kc + 1) / p->cpp, wi = (kc + 1) - ph * p->cpp;
                 hsoff = (unsigned)((((ph >> 1) * p->SW + (ph & 1)) * p->SC + wi * 32) * 2);
             }
-            if (lastc && has_next) {           // the stream runs on into the next tile: its halo source, its weight image
-                decode(next, nx0, ny0, nb_, nnt);
-                halo_src(nx0, ny0, nb_);
-                nwt = wbase(nb_, nnt);
-                wnext0 = nwt;
-                hsoff = 0u;
-            } else if (lastc) {                // dummies from here on (own image: valid addresses, slots nobody reads any more)
-                wnext0 = wt;
+            if (wjump) {                       // the weight stream runs on into the next tile's image (none: dummies from its own)
+                if (has_next) { decode(next, nx0, ny0, nb_, nnt); nwt = wbase(nb_, nnt); }
+                wnext0 = has_next ? nwt : wt;
+            }
+            if (lastc) {                       // ... and the halo requests into its first halo tile (none: dummies, slots nobody reads)
+                if (has_next) halo_src(nx0, ny0, nb_);
                 hsoff = 0u;
             }
             chunk(kc == 0 ? relaxed : 0, lastc && !has_next, wnext0, hsoff);
@@ -637,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void conv_pp_kernel(PPParams p_) {
 // written out as the nine 1 KiB pieces of every sample's image.
 __global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int N, int K, float wscale,
                                     const float* __restrict__ in_scale, const float* __restrict__ out_scale, float gain, int nb, int mode,
-                                    int src_rows, int in_period) {
+                                    int src_rows, int in_period, int ntap) {
     __shared__ __attribute__((aligned(16))) float wl[16][9][32 + 4];         // [row][tap][k] (+4: the row / tap strided reads below)
     const int nchunks = K / 32, ntn = N / 128;
     int bid = blockIdx.x;
@@ -671,12 +708,14 @@ __global__ __launch_bounds__(256) void conv_pp_pack_kernel(const float* __restri
         const float on = gain * (out_scale ? out_scale[(size_t)b * N + n0 + r] : 1.f);
 #pragma unroll
         for (int j = 0; j < 8; j++) m[j] = (in_scale ? in_scale[(size_t)b * in_period + (k0 + qd * 8 + j) % in_period] : 1.f) * on;
-        bf16_t* ob = out + ((((size_t)b * ntn + nt) * nchunks + kc) * 9 * 8 + pc) * 512 + (qd * 16 + r) * 8;   // (elements; tap stride 8 * 512)
+        bf16_t* ob = out + ((((size_t)b * ntn + nt) * nchunks + kc) * ntap * 8 + pc) * 512 + (qd * 16 + r) * 8;   // (elements; tap stride 8 * 512)
 #pragma unroll
         for (int ti = 0; ti < 3; ti++) {
             const int t = tq + 4 * ti;
-            if (t < 9) {
-                const float4 a = *(const float4*)&wl[r][t][qd * 8], c = *(const float4*)&wl[r][t][qd * 8 + 4];
+            // ntap == 4 (phase-form adjoint, in_t2d): only the taps (dy, dx) in {1, 2}^2 exist: image tap tt <- source tap 4 + 3 (tt >> 1) + (tt & 1)
+            const int ts = ntap == 4 ? 4 + 3 * (t >> 1) + (t & 1) : t;
+            if (t < ntap) {
+                const float4 a = *(const float4*)&wl[r][ts][qd * 8], c = *(const float4*)&wl[r][ts][qd * 8 + 4];
                 const float v[8] = {a.x * m[0], a.y * m[1], a.z * m[2], a.w * m[3], c.x * m[4], c.y * m[5], c.z * m[6], c.w * m[7]};
                 *(uint4*)(ob + (size_t)t * 8 * 512) = pack16(v, (bf16_t*)nullptr);
             }
@@ -709,20 +748,20 @@ extern "C" int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, fl
     DGE_CHECK(N % 128 == 0 && K % 32 == 0 && nb >= 1 && (mode == 0 || mode == 1), "pack_conv_pp: N=%d must be a multiple of 128, K=%d of 32", N, K);
     DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_conv_pp: per-sample copies need a per-sample scale");
     const long grid = (long)(N / 128) * (K / 32) * 8;
-    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)(grid >= 256 ? (nb + 1) / 2 : nb)), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode, 0, K);
+    hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)(grid >= 256 ? (nb + 1) / 2 : nb)), dim3(256), 0, s, w_oihw, (bf16_t*)out, N, K, wscale, in_scale, out_scale, gain, nb, mode, 0, K, 9);
     DGE_LAUNCH_CHECK("pack_conv_pp");
     return 0;
 }
 
 extern "C" int dge_pack_conv_pp_rows(const float* w_rows, int src_rows, void* out, int N, int K, const float* in_scale, int in_period,
-                                     const float* out_scale, float gain, int nb, hipStream_t s) {
+                                     const float* out_scale, float gain, int nb, int t2d, hipStream_t s) {
     DGE_CHECK(w_rows && out, "pack_conv_pp_rows: null tensor");
     DGE_CHECK(N % 128 == 0 && K % 32 == 0 && nb >= 1 && src_rows >= N, "pack_conv_pp_rows: N=%d must be a multiple of 128 (<= src_rows=%d), K=%d of 32", N, src_rows, K);
     DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_conv_pp_rows: per-sample copies need a per-sample scale");
     DGE_CHECK(!in_scale || (in_period >= 1 && K % in_period == 0), "pack_conv_pp_rows: in_period=%d must divide K=%d", in_period, K);
     const long grid = (long)(N / 128) * (K / 32) * 8;
     hipLaunchKernelGGL(conv_pp_pack_kernel, dim3((unsigned)grid, (unsigned)(grid >= 256 ? (nb + 1) / 2 : nb)), dim3(256), 0, s, w_rows, (bf16_t*)out, N, K, 1.f, in_scale, out_scale, gain, nb, 2,
-                       src_rows, in_scale ? in_period : K);
+                       src_rows, in_scale ? in_period : K, t2d ? 4 : 9);
     DGE_LAUNCH_CHECK("pack_conv_pp_rows");
     return 0;
 }
@@ -743,12 +782,19 @@ extern "C" int dge_conv_pp(const dge_conv_pp_desc* d, hipStream_t s) {
     p.tiles_x = (d->W + 31) / 32; p.tiles_y = (d->H + 15) / 16; p.ntn = d->Cout / 128; p.nchunks = d->Cin / 32;
     p.dbg = dge_env().conv_dbg;
     p.s2d = d->in_s2d ? 1 : 0;
-    if (p.s2d) {
+    p.VH = d->H; p.VW = d->W;
+    DGE_CHECK(!(d->in_s2d && d->in_t2d), "conv_pp: in_s2d and in_t2d exclude each other");
+    if (d->in_t2d) {
+        DGE_CHECK(d->dgrad && d->prep, "conv_pp: in_t2d comes with the data-gradient form and its fused tail backward");
+        DGE_CHECK(d->Cin >= 64, "conv_pp: in_t2d needs at least two K chunks");
+        p.VH = d->H + 1; p.VW = d->W + 1; p.SW = d->W + 1; p.SC = d->Cin; p.cpp = p.nchunks;
+        p.x_bstride = (long long)(d->H + 1) * (d->W + 1) * d->Cin * 2;
+    } else if (p.s2d) {
         DGE_CHECK(d->dgrad, "conv_pp: in_s2d comes with the data-gradient form");
         DGE_CHECK(d->Cin % 128 == 0, "conv_pp: in_s2d needs Cin / 4 = %d channels per phase in whole 32-channel chunks", d->Cin / 4);
         p.SW = 2 * d->W; p.SC = d->Cin / 4; p.cpp = p.SC / 32;
     } else { p.SW = d->W; p.SC = d->Cin; p.cpp = p.nchunks; }
-    p.x_bstride = (long long)d->H * d->W * d->Cin * 2;                 // (space-to-depth: 2H x 2W x Cin/4 - the same bytes)
+    if (!d->in_t2d) p.x_bstride = (long long)d->H * d->W * d->Cin * 2; // (space-to-depth: 2H x 2W x Cin/4 - the same bytes)
     p.out_scale = nullptr; p.dot = nullptr; p.add = nullptr; p.add_scale = 0.f; p.stats = nullptr; p.prep_stats = nullptr; p.stats_slots = 1;
     p.prep = 0; p.mask_relu = 0; p.prep_noise_bstride = 0; p.prep_gain = 1.f; p.prep_noise = nullptr; p.prep_ns = nullptr;
     if (d->dgrad) {
@@ -771,13 +817,19 @@ extern "C" int dge_conv_pp(const dge_conv_pp_desc* d, hipStream_t s) {
     int cus = 256;
     { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount / 8 * 8; }
     const long grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus;
-    dge_note_kernel(d->dgrad ? (d->in_s2d ? (d->prep ? "conv_pp<bf16,16,32,128>+dg+s2d+prep" : "conv_pp<bf16,16,32,128>+dg+s2d")
+    dge_note_kernel(d->in_t2d ? "conv_pp<bf16,16,32,128>+dg+t2d+prep" : d->dgrad ? (d->in_s2d ? (d->prep ? "conv_pp<bf16,16,32,128>+dg+s2d+prep" : "conv_pp<bf16,16,32,128>+dg+s2d")
                                           : (d->prep ? "conv_pp<bf16,16,32,128>+dg+prep" : (d->mask_relu ? "conv_pp<bf16,16,32,128>+dg+mask" : "conv_pp<bf16,16,32,128>+dg")))
                              : "conv_pp<bf16,16,32,128>");
     // EPI 1: noise weight per channel (model/E/E.py:60-62) instead of StyleGAN2's scalar strength; EPI 2: data gradient
     const int epi = d->dgrad ? 2 + 2 * (d->prep ? 0 : (d->mask_relu ? 2 : 1)) + (d->addend ? 1 : 0) : (p.noise_w_stride ? 1 : 0);
 #define PP_GO(E) do { if (p.dbg) hipLaunchKernelGGL((conv_pp_kernel<4, true, E>), dim3((unsigned)grid), dim3(512), 0, s, p); \
                       else hipLaunchKernelGGL((conv_pp_kernel<4, false, E>), dim3((unsigned)grid), dim3(512), 0, s, p); } while (0)
+    if (d->in_t2d) {
+        if (p.dbg) { if (d->addend) hipLaunchKernelGGL((conv_pp_kernel<4, true, 3, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+                     else hipLaunchKernelGGL((conv_pp_kernel<4, true, 2, true>), dim3((unsigned)grid), dim3(512), 0, s, p); }
+        else { if (d->addend) hipLaunchKernelGGL((conv_pp_kernel<4, false, 3, true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+               else hipLaunchKernelGGL((conv_pp_kernel<4, false, 2, true>), dim3((unsigned)grid), dim3(512), 0, s, p); }
+    } else
     switch (epi) {
         case 0: PP_GO(0); break; case 1: PP_GO(1); break; case 2: PP_GO(2); break; case 3: PP_GO(3); break;
         case 4: PP_GO(4); break; case 5: PP_GO(5); break; case 6: PP_GO(6); break; default: PP_GO(7); break;

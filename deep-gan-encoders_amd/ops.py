@@ -439,7 +439,7 @@ def pack_conv_pp(w, wscale=1.0, in_scale=None, out_scale=None, gain=1.0, dgrad=F
     return out
 
 
-def pack_conv_pp_rows(w_rows, N, in_scale=None, in_period=None, out_scale=None, gain=1.0, out=None):
+def pack_conv_pp_rows(w_rows, N, in_scale=None, in_period=None, out_scale=None, gain=1.0, out=None, t2d=False):
     """The conv_pp weight image from an f32 pack_conv_weight copy w_rows [9, Npad, K] (rows 0 .. N-1 are used): the data-gradient
     layouts of the up layers.  in_scale [B, in_period] repeats along K (space-to-depth: the four phases of a channel)."""
     if w_rows.dtype != torch.float32 or w_rows.ndim != 3 or w_rows.shape[0] != 9:
@@ -450,15 +450,15 @@ def pack_conv_pp_rows(w_rows, N, in_scale=None, in_period=None, out_scale=None, 
         if t is not None:
             nb = t.shape[0]
     if out is None:
-        out = torch.empty((nb, 9 * N * K), dtype=torch.bfloat16, device=w_rows.device)
+        out = torch.empty((nb, (4 if t2d else 9) * N * K), dtype=torch.bfloat16, device=w_rows.device)
     per = K if in_period is None else int(in_period)
     check(lib().dge_pack_conv_pp_rows(_f32(w_rows), int(w_rows.shape[1]), _p(out), int(N), int(K), _f32(in_scale), per, _f32(out_scale), float(gain),
-                                      nb, _stream()), "dge_pack_conv_pp_rows")
+                                      nb, 1 if t2d else 0, _stream()), "dge_pack_conv_pp_rows")
     return out
 
 
 def conv_pp(x, w_pp, cout, out_scale=None, bias=None, bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, out=None,
-            dgrad=False, in_s2d=False, dot_src=None, addend=None, add_scale=1.0, stats=None, prep=None, relu_mask=None):
+            dgrad=False, in_s2d=False, dot_src=None, addend=None, add_scale=1.0, stats=None, prep=None, relu_mask=None, in_t2d=False):
     """x [B,H,W,Cin] bf16 -> y [B,H,W,cout]: 3x3 stride-1 conv with the weights of pack_conv_pp (w_pp.shape[0] = 1: shared, = B: per sample).
     dgrad: the data-gradient form (dge_conv_pp_desc.dgrad) with conv2d()'s menu: out_scale applied after the statistics
     stats (SlotStats) += (sum a*dot_src, sum a), addend, prep = dict(gain, noise, ns, stats=SlotStats), relu_mask; in_s2d: x is the fine
@@ -466,9 +466,11 @@ def conv_pp(x, w_pp, cout, out_scale=None, bias=None, bias_scale=1.0, noise=None
     B, H, W, Cin = x.shape
     if in_s2d:
         H, W, Cin = H // 2, W // 2, Cin * 4
+    if in_t2d:            # x is fir_t2d's [B,H+1,W+1,4C]: the conv runs on the H x W grid with the 4 taps of the phase form
+        H, W = H - 1, W - 1
     if out is None:
         out = torch.empty((B, H, W, cout), dtype=x.dtype, device=x.device)
-    if w_pp.shape[0] not in (1, B) or w_pp.shape[1] != 9 * Cin * cout or w_pp.dtype != torch.bfloat16:
+    if w_pp.shape[0] not in (1, B) or w_pp.shape[1] != (4 if in_t2d else 9) * Cin * cout or w_pp.dtype != torch.bfloat16:
         raise DgeError("conv_pp: weight image does not match the launch")
     d = ConvPPDesc()
     d.x, d.w_pp, d.y = _p(x), _p(w_pp), _p(out)
@@ -483,7 +485,7 @@ def conv_pp(x, w_pp, cout, out_scale=None, bias=None, bias_scale=1.0, noise=None
             if dot_src is not None or prep is not None:
                 raise DgeError("conv_pp: relu_mask excludes dot_src / prep")
             dot_src = relu_mask
-        d.dgrad, d.in_s2d, d.mask_relu = 1, 1 if in_s2d else 0, 0 if relu_mask is None else 1
+        d.dgrad, d.in_s2d, d.in_t2d, d.mask_relu = 1, 1 if in_s2d else 0, 1 if in_t2d else 0, 0 if relu_mask is None else 1
         d.dot_src, d.addend, d.add_scale = _p(dot_src), _p(addend), float(add_scale)
         nslot = max(1, min(64, (((H + 15) // 16) * ((W + 31) // 32) * B) // 16))
         if stats is not None:
@@ -499,7 +501,7 @@ def conv_pp(x, w_pp, cout, out_scale=None, bias=None, bias_scale=1.0, noise=None
             d.prep_noise, d.prep_ns = _f32(pn), _f32(prep.get("ns") if pn is not None else None)
             d.prep_noise_batch = 1 if pn is None else pn.shape[0]
             d.prep_stats = _f32(prep["stats"].alloc(nslot))
-    elif in_s2d or dot_src is not None or addend is not None or stats is not None or prep is not None or relu_mask is not None:
+    elif in_s2d or in_t2d or dot_src is not None or addend is not None or stats is not None or prep is not None or relu_mask is not None:
         raise DgeError("conv_pp: in_s2d / dot_src / addend / stats / prep / relu_mask need dgrad=True")
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -507,8 +509,8 @@ def conv_pp(x, w_pp, cout, out_scale=None, bias=None, bias_scale=1.0, noise=None
         check(lib().dge_conv_pp(C.byref(d), _stream()), "dge_conv_pp")
         e1.record()
         abytes = sum(t.numel() * t.element_size() for t in (x, out, w_pp, dot_src, addend) if t is not None)
-        macs = 9.0 * (Cin // 4 if in_s2d else Cin) * cout * H * W         # (a folded up layer's adjoint counts as the 3x3 transposed conv it replaces)
-        PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, 3, False, bool(in_s2d)), abytes))
+        macs = 9.0 * (Cin // 4 if (in_s2d or in_t2d) else Cin) * cout * H * W         # (an up layer's adjoint counts as the 3x3 transposed conv it replaces)
+        PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, 3, False, bool(in_s2d or in_t2d)), abytes))
     else:
         check(lib().dge_conv_pp(C.byref(d), _stream()), "dge_conv_pp")
     return out

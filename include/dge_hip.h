@@ -458,6 +458,7 @@ typedef struct dge_conv_pp_desc {
      * No bias / noise / activation.  in_s2d: x is [B,2H,2W,Cin/4] read space-to-depth (adjoint of the up layer in folded form,
      * weights from dge_pack_conv_weight mode DGE_PACK_UPFOLD_DGRAD in f32 through dge_pack_conv_pp_rows). */
     int dgrad, in_s2d, stats_slots, prep, prep_noise_batch, mask_relu;
+    int in_t2d;               /* x is dge_fir_t2d's [B,H+1,W+1,Cin]; taps (dy,dx) in {1,2}^2 only (weights: dge_pack_conv_pp_rows with t2d = 1); needs prep */
     float add_scale, prep_gain;
     const void* dot_src;      /* [B,H,W,Cout] bf16 */
     const void* addend;       /* [B,H,W,Cout] bf16 */
@@ -470,9 +471,10 @@ int dge_conv_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype);
 int dge_pack_conv_pp(const float* w_oihw, void* out, int N, int K, float wscale, const float* in_scale, const float* out_scale,
                      float gain, int nb, int mode, dge_stream_t stream);
 /* the same LDS image from rows of an f32 dge_pack_conv_weight copy [9][src_rows][K] (any of its modes: the folded up layer's data
- * gradient, ...); in_scale [nb][in_period] repeats along K with period in_period (space-to-depth: the four phases of a channel) */
+ * gradient, ...); in_scale [nb][in_period] repeats along K with period in_period (space-to-depth: the four phases of a channel);
+ * t2d = 1: the 4-tap image of the phase-form adjoint (DGE_PACK_UPT2D_DGRAD rows; 4*N*K elements per copy) */
 int dge_pack_conv_pp_rows(const float* w_rows, int src_rows, void* out, int N, int K, const float* in_scale, int in_period,
-                          const float* out_scale, float gain, int nb, dge_stream_t stream);
+                          const float* out_scale, float gain, int nb, int t2d, dge_stream_t stream);
 int dge_conv_pp(const dge_conv_pp_desc* d, dge_stream_t stream);
 
 /* ---- PGGAN (model/pggan/pggan_generator.py) ------------------------------------------------ */
