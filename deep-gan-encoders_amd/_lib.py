@@ -161,6 +161,7 @@ SIGNATURES = {
     "dge_heads_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],
     "dge_conv_pp_supported": [_I, _I, _I, _I, _I, _I],
     "dge_pack_conv_pp": [_P, _P, _I, _I, _F, _P, _P, _F, _I, _I, _P],
+    "dge_conv_wgrad_dots": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_pack_conv_pp_rows": [_P, _I, _P, _I, _I, _P, _I, _P, _F, _I, _I, _P],
     "dge_conv_pp": [C.POINTER(ConvPPDesc), _P],
 }

@@ -766,7 +766,16 @@ __global__ void head_bwd_param_kernel(const HeadEntry* __restrict__ tab, const f
 #define CHAN_OK(C, ep) ((C) % (ep) == 0 && (C) / (ep) <= 256 && 256 % ((C) / (ep)) == 0)
 
 int dge_wgrad_dma_try(const void* g, const void* x, const float* sc, const float* sh, float* dw, int B, int H, int W, int cout, int cin,
-                      hipStream_t s);       // wgrad_dma.hip: 0 done, 1 shape not covered, < 0 error
+                      const float* wdot, float* dots, int dots_slots, hipStream_t s);       // wgrad_dma.hip: 0 done, 1 shape not covered, < 0 error
+// dge_conv_wgrad + the two per-(sample, input channel) sums of the layer's data gradient (dge_conv_desc.dot_src statistics), taken
+// from the weight-gradient correlations (wgrad_dma.hip).  Returns 1 (nothing launched) where the streaming kernel does not cover
+// the shape: the caller then runs dge_conv_wgrad and lets the data gradient produce the sums.
+extern "C" int dge_conv_wgrad_dots(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, const float* w,
+                                   float* dots, int dots_slots, int B, int H, int W, int cout, int cin, int dtype, hipStream_t s) {
+    DGE_CHECK(g && x && dw && w && dots && in_scale && in_shift && dots_slots >= 1, "conv_wgrad_dots: null tensor");
+    if (dtype != DGE_BF16) return 1;
+    return dge_wgrad_dma_try(g, x, in_scale, in_shift, dw, B, H, W, cout, cin, w, dots, dots_slots, s);
+}
 extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H,
                               int W, int cout, int cin, int ksize, int dtype, hipStream_t s) {
     DGE_CHECK(ksize == 1 || ksize == 3, "conv_wgrad: ksize %d unsupported", ksize);
@@ -774,7 +783,7 @@ extern "C" int dge_conv_wgrad(const void* g, const void* x, const float* in_scal
     DGE_CHECK(cout % ep == 0 && cin % ep == 0, "conv_wgrad: channels must be multiples of %d", ep);
     DGE_CHECK((in_scale == nullptr) == (in_shift == nullptr), "conv_wgrad: in_scale and in_shift go together");
     if (dtype == DGE_BF16 && ksize == 3) {       // the streaming kernel (LDS-DMA ring, affine on the accumulators)
-        const int r = dge_wgrad_dma_try(g, x, in_scale, in_shift, dw, B, H, W, cout, cin, s);
+        const int r = dge_wgrad_dma_try(g, x, in_scale, in_shift, dw, B, H, W, cout, cin, nullptr, nullptr, 1, s);
         if (r <= 0) return r;
     }
     const bool tall = dtype == DGE_BF16 && H >= 16 && !dge_env().wgrad_th8;

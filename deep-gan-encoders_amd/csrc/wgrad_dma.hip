@@ -71,7 +71,8 @@ template <class C>
 __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ X,
                                                                 const float* __restrict__ sc, const float* __restrict__ sh,
                                                                 float* __restrict__ dW, int B, int H, int W, int Co, int Ci,
-                                                                int tiles_x, int tiles_y, int per_group, int gps) {
+                                                                int tiles_x, int tiles_y, int per_group, int gps,
+                                                                const float* __restrict__ Wdot, float* __restrict__ dots, int dots_slots) {
     constexpr int TH = C::TH, GP = C::GP, XP = C::XP, NW = C::NW, NS = C::NS, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     float* gtab = (float*)(lds + C::GTAB_OFF);          // [9 kinds][32 o]: total, top row, bottom row, left col, right col, 4 corners
@@ -288,6 +289,8 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
     //      add to consecutive addresses (see wgrad_flush in enc_bwd_kernels.hip)
     float* red = (float*)lds;
     float* stg = red + NW * 1024;
+    float d_s2 = 0.f, d_s1 = 0.f;          // (every element a thread stages has the same input channel il = tid & 31)
+    static_assert(NT % 64 == 0, "flush: a thread's elements share the input channel");
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         __syncthreads();
@@ -306,12 +309,31 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
                 if (dy != 1) G -= gtab[(dy == 0 ? 32 : 64) + ol];
                 if (dx != 1) G -= gtab[(dx == 0 ? 96 : 128) + ol];
                 if (dy != 1 && dx != 1) G += gtab[160 + 32 * ((dy >> 1) * 2 + (dx >> 1)) + ol];
+                if (dots) {
+                    // the two sums the instance-norm backward of the layer's INPUT needs (model/E/E.py:51-53 differentiated), taken
+                    // here instead of in the data-gradient epilogue: with g_x = conv^T(g, w) (zero padding), sum_p g_x[p,i]*X[p,i] =
+                    // sum_{o,tap} w[o,i,tap] * (raw correlation of this flush) and sum_p g_x[p,i] = sum_{o,tap} w[o,i,tap] * G[o,tap]
+                    // - known BEFORE the data gradient runs, so that its epilogue can apply the backward itself.  w as the data
+                    // gradient reads it: rounded to bf16.
+                    const float wv = (o0 + ol < Co && i0 + il < Ci) ? bf2f(f2bf(Wdot[((size_t)(o0 + ol) * Ci + i0 + il) * 9 + t])) : 0.f;
+                    d_s2 = fmaf(wv, s, d_s2); d_s1 = fmaf(wv, G, d_s1);
+                }
                 s = fmaf(s, sctab[il], ktab[il] * G);
             }
             stg[(ol * 32 + il) * 9 + t] = s;
         }
     }
     __syncthreads();
+    if (dots) {                            // NT / 32 partial pairs per input channel -> one pair of atomics per channel and workgroup
+        red[tid * 2] = d_s2; red[tid * 2 + 1] = d_s1;
+        __syncthreads();
+        if (tid < 64) {
+            const int il = tid & 31, k = tid >> 5;
+            float v = 0.f;
+            for (int j = 0; j < NT / 32; j++) v += red[(il + 32 * j) * 2 + k];
+            if (i0 + il < Ci) atomicAdd(dots + ((size_t)(grp_id % dots_slots) * B * Ci + (size_t)smp * Ci + i0 + il) * 2 + k, v);
+        }
+    }
     const int ni = (Ci - i0 < 32 ? Ci - i0 : 32) * 9;      // valid floats of one o row of this tile (contiguous in dW)
     if (det_on()) {
         const int L = 1024 * 9, nslots = B * gps;
@@ -333,7 +355,7 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
 
 template <class C>
 int launch(const void* g, const void* x, const float* sc, const float* sh, float* dw, int B, int H, int W, int cout, int cin,
-           hipStream_t s) {
+           const float* wdot, float* dots, int dots_slots, hipStream_t s) {
     const int tx = (W + 15) / 16, ty = (H + C::TH - 1) / C::TH;
     const int tps = tx * ty;
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
@@ -363,7 +385,7 @@ int launch(const void* g, const void* x, const float* sc, const float* sh, float
     if (!dge_det_fits(noi, (long long)B * gps, 1024 * 9)) return 1;
     dge_note_kernel("wgrad_dma<%d,%d,%d,%d>", C::TH, C::GP, C::XP, C::NS);
     hipLaunchKernelGGL(kern, dim3(noi, groups8), dim3(C::NW * 64), lds_bytes, s, (const bf16_t*)g, (const bf16_t*)x, sc, sh, dw, B, H, W,
-                       cout, cin, tx, ty, per, gps);
+                       cout, cin, tx, ty, per, gps, wdot, dots, dots_slots < 1 ? 1 : dots_slots);
     DGE_LAUNCH_CHECK("wgrad_dma");
     return 0;
 }
@@ -372,12 +394,15 @@ int launch(const void* g, const void* x, const float* sc, const float* sh, float
 
 // bf16 3x3 weight gradient on the streaming kernel; returns 1 when the shape is not covered (the caller falls back to
 // conv_wgrad_tr_kernel), 0 on success, < 0 on error.
+// dots (optional, with wdot = the layer's weight [cout][cin][3][3] f32): [dots_slots][B][cin][2], pre-zeroed, += (sum g_x*x, sum g_x)
+// of the data gradient g_x of the same (g, w) - see the flush.
 int dge_wgrad_dma_try(const void* g, const void* x, const float* sc, const float* sh, float* dw, int B, int H, int W, int cout, int cin,
-                      hipStream_t s) {
+                      const float* wdot, float* dots, int dots_slots, hipStream_t s) {
     static int off = -1;
     if (off < 0) off = getenv("DGE_NO_WGRAD_DMA") ? 1 : 0;
     if (off) return 1;
     if (cout % 8 || cin % 8) return 1;
+    if (dots && (!sc || !wdot || !dge_det_fits(1LL << 40, 1, 1))) return 1;     // (deterministic mode: the data gradient keeps producing the sums)
     if ((size_t)H * W * cout * 2 >= (1u << 30) || (size_t)H * W * cin * 2 >= (1u << 30)) return 1;      // 32-bit buffer offsets + DEAD
     const int tps = ((W + 15) / 16) * ((H + 15) / 16);
     const int noi = ((cout + 31) / 32) * ((cin + 31) / 32);
@@ -386,8 +411,8 @@ int dge_wgrad_dma_try(const void* g, const void* x, const float* sc, const float
     if (tps < 16 || noi * B > 1024) return 1;
     const bool g32 = cout <= 16, x32 = cin <= 16;
     // ring depth: the deepest that leaves two workgroups per CU
-    if (g32 && x32) return launch<WCfg<16, 32, 32, 4, 3>>(g, x, sc, sh, dw, B, H, W, cout, cin, s);
-    if (!g32 && x32) return launch<WCfg<16, 64, 32, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, s);
-    if (g32 && !x32) return launch<WCfg<16, 32, 64, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, s);
-    return launch<WCfg<16, 64, 64, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, s);
+    if (g32 && x32) return launch<WCfg<16, 32, 32, 4, 3>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
+    if (!g32 && x32) return launch<WCfg<16, 64, 32, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
+    if (g32 && !x32) return launch<WCfg<16, 32, 64, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
+    return launch<WCfg<16, 64, 64, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
 }

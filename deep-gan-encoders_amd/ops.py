@@ -695,6 +695,24 @@ def conv_wgrad(g, x, dw, in_scale=None, in_shift=None):
     return dw
 
 
+def conv_wgrad_dots(g, x, dw, in_scale, in_shift, w, dots):
+    """conv_wgrad that also fills `dots` (SlotStats(B, Cin)) with (sum g_x*x, sum g_x) of the layer's data gradient g_x, where the
+    streaming weight-gradient kernel covers the shape: returns True then; False (nothing launched) otherwise."""
+    B, H, W, Cin = x.shape
+    cout = dw.shape[0]
+    if dw.shape[2] != 3 or is_deterministic():
+        return False
+    nslot = max(1, min(16, (H * W) // 4096))
+    buf = dots.alloc(nslot)
+    r = lib().dge_conv_wgrad_dots(_p(g), _p(x), _f32(in_scale), _f32(in_shift), _f32(dw), _f32(w.detach()), _f32(buf), nslot, B, H, W, cout, Cin,
+                                  dtype_of(x), _stream())
+    if r == 1:
+        dots.buf, dots.nslot = None, 1
+        return False
+    check(r, "dge_conv_wgrad_dots")
+    return True
+
+
 class DeferredSums:
     """Planar slot sums whose results nobody reads before the end of a backward: collected, then run as ONE launch
     (dge_sum_slots_planar_multi) by flush()."""

@@ -303,6 +303,15 @@ int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, dge_stream_t
 /* dw[o][i][tap] (f32, OIHW like the parameter, pre-zeroed) += sum_{b,p} g[b,p,o] * (x*in_scale+in_shift)[b,p+tap,i] */
 int dge_conv_wgrad(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, int B, int H, int W,
                    int cout, int cin, int ksize, int dtype, dge_stream_t stream);
+/* dge_conv_wgrad (3x3, bf16) that also leaves, per (sample, input channel), the two sums of the layer's data gradient g_x =
+ * conv^T(g, w) that the instance-norm backward of the layer's input needs - dots[slot][b][i] += (sum_p g_x*x, sum_p g_x), the
+ * statistics a dge_conv2d data-gradient launch with dot_src = x produces - out of the weight-gradient correlations: they are
+ * known BEFORE the data gradient runs, whose epilogue can then apply that backward itself (dge_conv_desc.in_bwd_coef).
+ * w [cout][cin][3][3] f32: the layer's weight (read rounded to bf16, as the data gradient reads it); dots [dots_slots][B][cin][2]
+ * pre-zeroed.  Returns 1 and launches NOTHING where the streaming weight-gradient kernel does not cover the shape (or in
+ * deterministic mode). */
+int dge_conv_wgrad_dots(const void* g, const void* x, const float* in_scale, const float* in_shift, float* dw, const float* w,
+                        float* dots, int dots_slots, int B, int H, int W, int cout, int cin, int dtype, dge_stream_t stream);
 /* gpre = scale * gup[q(p)] * (a > 0 ? 1 : slope) (q = 2x2 pooling parent when pool);
    red[b,c,red_cols] (PER-SAMPLE partial sums, pre-zeroed: workgroups of different samples never contend on an address; the
    caller adds them over b, e.g. dge_sum_slots) += {sum gpre, sum gpre*noise [, sum over the gup grid of gup]}   (red_cols = 2 or 3; the third column is the
