@@ -23,7 +23,7 @@ class ConvDesc(C.Structure):
         ("prep_stats", C.c_void_p), ("mask_relu", C.c_int), ("in_t2d", C.c_int),
         ("rgb_w", C.c_void_p), ("rgb_style", C.c_void_p), ("rgb_bias", C.c_void_p), ("rgb_out", C.c_void_p), ("rgb_wscale", C.c_float),
         ("rgb_skip_y", C.c_int), ("pool_out", C.c_int), ("pool_mask", C.c_void_p),
-        ("prefetch_w", C.c_void_p), ("prefetch_ntot", C.c_int), ("prefetch_cin", C.c_int),
+        ("prefetch_w", C.c_void_p), ("prefetch_ntot", C.c_int), ("prefetch_cin", C.c_int), ("in_bwd_coef", C.c_void_p),
     ]
 
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "dge_truncation": [_P, _P, _P, _I, _I, _I, _F, _I, _I, _P],
     "dge_torgb": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dge_conv_rgb_supported": [_I, _I, _I, _I, _I, _I, _I],
+    "dge_conv_in_bwd_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_conv_pool_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_rgb_upsample_add": [_P, _P, _I, _I, _I, _P],
     "dge_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],

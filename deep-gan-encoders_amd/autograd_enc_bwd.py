@@ -25,6 +25,10 @@ def _linear_backward(lin, g_w, musig, grads, name):
     return gms
 
 
+import os
+FUSE_IN_BWD = not os.environ.get("DGE_NO_FUSED_IN_BWD")
+
+
 def encoder_backward(E, saved, g_w):
     """Returns gradients for E.parameters() in registration order (None where the reference
     produces none, e.g. the last block's noise_weight_2 / bias_2)."""
@@ -82,6 +86,7 @@ def encoder_backward(E, saved, g_w):
             gms1 = _linear_backward(blk.inver_mod1, g_w1, rec["musig1"], grads, pre + "inver_mod1")
         x, x1 = rec["x"], rec["x1"]
         extra, extra_pool, extra_scale = None, False, 1.0
+        fuse2 = False
         if not last:
             if g_out is None:
                 raise RuntimeError("non-final encoder block without an output gradient")
@@ -91,10 +96,17 @@ def encoder_backward(E, saved, g_w):
             grads[pre + "bias_2"] = red2[0].reshape(1, C2, 1, 1)
             grads[pre + "noise_weight_2"] = red2[1].reshape(1, C2, 1, 1)
             gW2 = ops.zeros(tuple(blk.conv_2.weight.shape), dev)
-            ops.conv_wgrad(g_pre2, x1, gW2, rec["sc2"], rec["sh2"])
-            grads[pre + "conv_2.weight"] = gW2
             dots2 = ops.SlotStats(B, Cc, dev)                 # slot copies are added by in_bwd_coef
-            g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
+            # High-resolution blocks: the two sums the instance-norm backward needs come out of the weight-gradient launch, so the data
+            # gradient can apply that backward (and the activation backward of conv_1's tail) in its epilogue - the in_bwd pass over
+            # g_y2 and x1 below disappears (measured at batch 8: 410 -> 239 us at 1024^2, 212 -> 121 us at 512^2)
+            fuse2 = FUSE_IN_BWD and ops.conv_in_bwd_supported(B, H, H, C2, Cc, dt) and \
+                ops.conv_wgrad_dots(g_pre2, x1, gW2, rec["sc2"], rec["sh2"], blk.conv_2.weight, dots2)
+            if not fuse2:
+                ops.conv_wgrad(g_pre2, x1, gW2, rec["sc2"], rec["sh2"])
+            grads[pre + "conv_2.weight"] = gW2
+            if not fuse2:
+                g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
             if has3:
                 post.append(lambda n=pre + "conv_3.bias", t=red2[2]: grads.__setitem__(n, t * 0.889))
                 gW3 = ops.zeros(tuple(blk.conv_3.weight.shape), dev)
@@ -110,7 +122,13 @@ def encoder_backward(E, saved, g_w):
             g_y2, dots2 = None, None
         coef2 = (dots2, gms2, rec["musig2"], rec["sc2"], rec["sh2"], N)          # computed inside in_bwd (dge_in_bwd_fused)
         red1 = ops.zeros((2, Cc), dev)
-        g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1, planar=True, defer=later)
+        if fuse2:
+            redp = ops.SlotStats(B, Cc, dev)
+            g_pre1 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, dot_src=x1,
+                                in_bwd=dict(coef=ops.in_bwd_coef(*coef2), noise=rec["n1"].reshape(B, H, H), red=redp))
+            ops._sum_planar(redp.buf.view(-1, Cc, 2), red1, later)
+        else:
+            g_pre1 = ops.in_bwd(g_y2, x1, coef2, noise=rec["n1"], act=True, red=red1, planar=True, defer=later)
         grads[pre + "bias_1"] = red1[0].reshape(1, Cc, 1, 1)
         grads[pre + "noise_weight_1"] = red1[1].reshape(1, Cc, 1, 1)
         gW1 = ops.zeros(tuple(blk.conv_1.weight.shape), dev)

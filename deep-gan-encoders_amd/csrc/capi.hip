@@ -77,7 +77,7 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     DGE_CHECK(!(d->up && d->in_s2d), "conv2d: up and in_s2d are exclusive");
     DGE_CHECK(!d->in_up2 || (!d->in_s2d && d->H % 2 == 0 && d->W % 2 == 0), "conv2d: in_up2 needs even H, W and no in_s2d");
     DGE_CHECK(!d->in_s2d || d->Cin % 4 == 0, "conv2d: in_s2d needs Cin %% 4 == 0");
-    DGE_CHECK(!d->dot_src || d->stats || d->mask_relu, "conv2d: dot_src needs a stats buffer");
+    DGE_CHECK(!d->dot_src || d->stats || d->mask_relu || d->in_bwd_coef, "conv2d: dot_src needs a stats buffer");
     DGE_CHECK(!d->mask_relu || (d->dot_src && !d->prep && !d->up), "conv2d: mask_relu needs dot_src and excludes prep / up");
     DGE_CHECK(!d->in_relu || d->in_scale || d->in_shift, "conv2d: in_relu is applied together with the prologue affine");
     DGE_CHECK(d->gain > 0.f, "conv2d: gain must be positive (it is folded through the activation)");
@@ -114,6 +114,12 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
     const bool pf = d->w_layout == 1 && d->prefetch_w && d->prefetch_ntot >= 64 && d->prefetch_ntot % 64 == 0 &&
                     (d->prefetch_cin == 512 || d->prefetch_cin == 256);
     p.pf_w = pf ? d->prefetch_w : nullptr; p.pf_ntot = pf ? d->prefetch_ntot : 0; p.pf_cin = pf ? d->prefetch_cin : 0;
+    p.in_coef = d->in_bwd_coef;
+    if (d->in_bwd_coef) {
+        DGE_CHECK(!dge_get_deterministic(), "conv2d: in_bwd_coef is not offered in deterministic mode; run dge_in_bwd");
+        DGE_CHECK(d->ksize == 3 && !d->up && dge_conv_stream_eligible(p, d->dtype, d->ksize), "conv2d: in_bwd_coef is offered where "
+                  "dge_conv_in_bwd_supported() says so, with dot_src and prep_stats, without stats / prep");
+    }
     if (d->pool_out)
         DGE_CHECK(!d->up && dge_conv_pool_ok(p, d->dtype, d->ksize), "conv2d: the pooled epilogue is offered where dge_conv_pool_supported() "
                   "says so (conv_2 of the first encoder blocks on the streaming kernel)");
@@ -132,6 +138,15 @@ extern "C" int dge_conv_pool_supported(int B, int H, int W, int Cin, int Cout, i
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ntot_valid = Cout; p.Ntot = dge_packed_n(Cout);
     p.in_shift = (const float*)16; p.noise_w_stride = 1;       // (the encoder flavour's work threshold)
     return dge_conv_pool_ok(p, dtype, ksize) ? 1 : 0;
+}
+
+// 1 when a data-gradient launch of this shape may apply the instance-norm backward of its output's layer input in its epilogue
+// (dge_conv_desc.in_bwd_coef)
+extern "C" int dge_conv_in_bwd_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    ConvParams p = {};
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ntot_valid = Cout; p.Ntot = dge_packed_n(Cout);
+    p.dot_src = (const void*)16; p.prep_stats = (float*)16; p.in_coef = (const float*)16;
+    return (ksize == 3 && !dge_get_deterministic() && dge_conv_stream_eligible(p, dtype, ksize)) ? 1 : 0;
 }
 
 // 1 when a plain generator-flavour launch (style scale, demodulation, shared noise plane, bias, activation) of this shape may carry

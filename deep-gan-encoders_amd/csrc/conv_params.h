@@ -60,6 +60,10 @@ struct ConvParams {
     // pulling it from HBM behind a cold miss (measured 22-24 us cold against 13-17 us hot per launch at 4^2 .. 16^2).
     const void* pf_w;
     int pf_ntot, pf_cin;
+    // conv_stream.hip only (FL_DOT_IN): coefficients [B][Cout][3] = (A, Bc, Cc) of the instance-norm backward of the layer's input
+    // x = dot_src (dge_in_bwd_coef): the launch stores g_pre = (A*acc + Bc*x + Cc) * lrelu'(x) and adds (sum g_pre, sum g_pre*noise)
+    // to prep_stats (noise = prep_noise: the plane of the layer that produced x)
+    const float* in_coef;
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);

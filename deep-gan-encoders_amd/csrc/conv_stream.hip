@@ -103,7 +103,12 @@ template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigne
                      "buffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds" : : "v"(voff), "s"(m0v), "s"(rs), "v"(voff1) : "memory");
 }
 
-enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5, FL_ENC_POOL = 6 };
+enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5, FL_ENC_POOL = 6, FL_DOT_IN = 7 };
+// FL_DOT_IN:    data-gradient mode with the instance-norm backward of the layer's input x = dot_src applied in the epilogue
+//               (ConvParams::in_coef, model/E/E.py:51-62 differentiated): y = g_pre = (A*acc + Bc*x + Cc) * lrelu'(x); A is folded into
+//               the weights, Cc is the C operand of the first MFMA; prep_stats (sum g_pre, sum g_pre*noise) = the bias / noise-weight
+//               gradients of the layer that produced x; the noise ring carries that layer's plane (prep_noise).  No dot statistics:
+//               the caller had them from the weight gradient (dge_conv_wgrad_dots) to build the coefficients.
 // FL_ENC_POOL:  FL_ENC with the 2x2 average pool of the result (BEBlock: downscale2d after conv_2, model/E/E.py:75-76) taken in the
 //               epilogue: the full-resolution activation is never stored - only its pooled value and, for the backward, the signs
 // FL_GEN_RGB:   FL_GEN + the toRGB of the result (ConvParams::rgb_*): two more MFMAs per row on the packed output registers
@@ -123,10 +128,10 @@ struct SC {
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
-    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL;
+    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL, INB = FL == FL_DOT_IN;
     static_assert(!RGB || COUT == 32 || (COUT == 64 && TEAM == 2), "fused toRGB: 32 output channels per wave, one wave or a 2-wave team per pixel");
-    static constexpr bool DOT = FL == FL_DOT || PREP, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS || POOL;
-    static constexpr bool NOISE = !DOT || PREP;
+    static constexpr bool DOT = FL == FL_DOT || PREP || INB, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS || POOL;
+    static constexpr bool NOISE = !DOT || PREP || INB;
     static constexpr int NR = 6;                 // ring rows = unroll period
     static constexpr int dot_depth(int nr) { for (int d = 4; d >= 1; d--) if (d <= nr - 3 && nr % (d + 1) == 0) return d; return 1; }
     static constexpr int D = DOT ? dot_depth(6) : 2;            // rows in flight ahead of the newest live row (<= NR - 3)
@@ -154,7 +159,7 @@ struct SC {
     static constexpr int LDS_BYTES = RGBX_OFF + (RGB && TEAM == 2 ? 1024 : 0);
     static constexpr int NEED = 4 * 9 * KS * MTW + 32 * MTW + 16 + (ENC ? 16 * MTW : 0) + (STATS || DOT ? 32 * MTW : 0) + (DOT ? 16 : 0) + (PREP ? 16 : 0) + (RGB ? 11 : 0) + (POOL ? 20 * MTW : 0) + 36;
     // (the 64-channel prep flavour holds 144 weight + 48 sum registers: at two waves per SIMD it spilled 360 B per lane)
-    static constexpr int WPE = (PREP && CIN == 64) ? 1 : (NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2));
+    static constexpr int WPE = ((PREP || INB) && CIN == 64) ? 1 : (NEED <= 128 ? 4 : (NEED <= 168 ? 3 : 2));
     static_assert(D <= NR - 3, "the slot of the row being fetched must be dead");
     static_assert((D - 1) * LPR + 1 < 64, "vmcnt range");
 };
@@ -201,8 +206,8 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     const unsigned xrow_bytes = (unsigned)p.W * C::PXB, yrow_bytes = (unsigned)p.W * C::CPB;
     const unsigned long long Xb = (unsigned long long)p.x + (unsigned long long)b * p.H * xrow_bytes;
     unsigned char* __restrict__ Yb = (unsigned char*)p.y + (size_t)b * p.H * yrow_bytes;
-    const float* __restrict__ nzsrc = C::PREP ? p.prep_noise : p.noise;      // (prep: the plane of the layer whose tail is differentiated)
-    const unsigned long long NZb = nzsrc ? (unsigned long long)(nzsrc + (size_t)b * (C::PREP ? p.prep_noise_bstride : p.noise_bstride)) : Xb;
+    const float* __restrict__ nzsrc = (C::PREP || C::INB) ? p.prep_noise : p.noise;      // (prep: the plane of the layer whose tail is differentiated)
+    const unsigned long long NZb = nzsrc ? (unsigned long long)(nzsrc + (size_t)b * ((C::PREP || C::INB) ? p.prep_noise_bstride : p.noise_bstride)) : Xb;
     const unsigned nzrow_bytes = nzsrc ? (unsigned)p.W * 4 : 0;
     const unsigned long long DOTb = C::DOT ? (unsigned long long)p.dot_src + (unsigned long long)b * p.H * yrow_bytes : Xb;
 
@@ -284,6 +289,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             const bool ov = cl >= 0 && o < COUT;
             float osc = p.gain;
             if (!C::DOT && p.out_scale && ov) osc *= p.out_scale[b * COUT + o];
+            if (C::INB && ov) osc *= p.in_coef[((size_t)b * COUT + o) * 3];
             float tall = 0.f, tleft = 0.f, tright = 0.f;
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
@@ -316,9 +322,10 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 const int e = (mt * 32 + cl) * 16;
                 float bb = (!C::DOT && p.bias) ? p.bias[o] * p.bias_scale * p.gain : 0.f;
                 if constexpr (C::ENC) { TT[e + 9] = tall; TT[e + 10] = tleft; TT[e + 11] = tright; bb += tall; }
+                if constexpr (C::INB) bb = p.in_coef[((size_t)b * COUT + o) * 3 + 2];
                 TT[e + 12] = bb;
                 TT[e + 13] = (C::NOISE && p.noise) ? p.noise_w[o * p.noise_w_stride] * p.gain : 0.f;
-                TT[e + 14] = (C::DOT && p.out_scale) ? p.out_scale[b * COUT + o] : 1.f;
+                TT[e + 14] = C::INB ? p.in_coef[((size_t)b * COUT + o) * 3 + 1] : ((C::DOT && p.out_scale) ? p.out_scale[b * COUT + o] : 1.f);
             }
         }
     }
@@ -405,14 +412,14 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     // output byte offset of this lane inside an image row: pixel, this wave's channels, this lane's first run of 8
     const unsigned yoff = (unsigned)gx * C::CPB + (unsigned)(wave * C::MTW * 32 * 2) + kh * 16;
 
-    float s0[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s1[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s2[C::PREP ? 16 : 1];
+    float s0[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s1[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s2[(C::PREP || C::INB) ? 16 : 1];
     if constexpr (C::STATS || C::DOT) {
 #pragma unroll
         for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; }
     }
-    if constexpr (C::PREP) {
+    if constexpr (C::PREP || C::INB) {
 #pragma unroll
         for (int r = 0; r < 16; r++) s2[r] = 0.f;
     }
@@ -460,7 +467,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             const bf16x8_t bf = *(const bf16x8_t*)&bq[q % PF];
 #pragma unroll
             for (int mt = 0; mt < C::MTW; mt++) {
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[mt][tap][ks], bf, q == 0 ? (C::DOT ? zero16 : biasv[mt]) : acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wf[mt][tap][ks], bf, q == 0 ? ((C::DOT && !C::INB) ? zero16 : biasv[mt]) : acc[mt], 0, 0, 0);
             }
             if constexpr (q + PF < NQ) bq[q % PF] = lds_u4(frag_addr(std::integral_constant<int, q + PF>{}));
         });
@@ -507,6 +514,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const int r = 8 * q + e;
+                        if constexpr (C::INB) {
+                            // v = A*acc + Cc (weights, C operand); oscv = Bc
+                            const float o = fmaf(oscv[r], d[e], v[r]) * (d[e] > 0.f ? 1.f : 0.2f);
+                            s1[mt][r] += o; s2[r] = fmaf(o, nz, s2[r]);
+                            v[r] = o;
+                            continue;
+                        }
                         s0[mt][r] = fmaf(v[r], d[e], s0[mt][r]);
                         if constexpr (C::PREP) {
                             const bool pos = d[e] > 0.f;
@@ -622,15 +636,15 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 
     // ---- statistics: reduce over the 32 pixel lanes, one atomic per channel per wave
     if constexpr (C::STATS || C::DOT) {
-        if (p.stats) {
+        if (p.stats || (C::INB && p.prep_stats)) {
             // lanes right of the image (ragged strips) accumulated values of pixels that do not exist: a lane is one pixel
             // column, so the whole column is dropped here instead of masking every step
 #pragma unroll
             for (int mt = 0; mt < C::MTW; mt++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) { if (!pv) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; if constexpr (C::PREP) s2[r] = 0.f; } }
-            float* __restrict__ ST = p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2;
-            float* __restrict__ PST = (C::PREP && p.prep_stats) ? p.prep_stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2 : nullptr;
+                for (int r = 0; r < 16; r++) { if (!pv) { s0[mt][r] = 0.f; s1[mt][r] = 0.f; if constexpr (C::PREP || C::INB) s2[r] = 0.f; } }
+            float* __restrict__ ST = p.stats ? p.stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2 : nullptr;
+            float* __restrict__ PST = ((C::PREP || C::INB) && p.prep_stats) ? p.prep_stats + (size_t)(blockIdx.x % p.stats_slots) * p.B * COUT * 2 + (size_t)b * COUT * 2 : nullptr;
             // deterministic mode: domain = sample, slot = (segment, strip), the team's waves fill disjoint channel ranges of it
             const bool det = det_on();
             float* dvec = det ? det_slot(b, p.B, seg * nstrips + strip, nseg * nstrips, COUT * 2) : nullptr;
@@ -642,24 +656,26 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 float va = 0.f, vc = 0.f, vt = 0.f;
 #pragma unroll
                 for (int r = 0; r < NREG; r++) {
-                    float a = s0[mt][r], c = s1[mt][r], t2 = C::PREP ? s2[r] : 0.f;
+                    float a = s0[mt][r], c = s1[mt][r], t2 = (C::PREP || C::INB) ? s2[r] : 0.f;
 #pragma unroll
                     for (int m = 1; m < 32; m <<= 1) {
                         a += __shfl_xor(a, m, 64); c += __shfl_xor(c, m, 64);
-                        if constexpr (C::PREP) t2 += __shfl_xor(t2, m, 64);
+                        if constexpr (C::PREP || C::INB) t2 += __shfl_xor(t2, m, 64);
                     }
                     if (n31 == r) { va = a; vc = c; vt = t2; }
                 }
                 if (n31 < NREG) {
                     const int ch = wave * C::MTW * 32 + chan_of_reg(mt, n31);
-                    if constexpr (C::PREP) {        // (the launcher refuses prep in deterministic mode)
+                    if constexpr (C::INB) {         // (sum g_pre, sum g_pre*noise); not offered in deterministic mode
+                        if (PST) { atomicAdd(PST + ch * 2, vc); atomicAdd(PST + ch * 2 + 1, vt); }
+                    } else if constexpr (C::PREP) {        // (the launcher refuses prep in deterministic mode)
                         atomicAdd(ST + ch * 2, va);
                         if (PST) { atomicAdd(PST + ch * 2, vt); atomicAdd(PST + ch * 2 + 1, vc); }
                     } else if (det) { dvec[ch * 2] = va; dvec[ch * 2 + 1] = vc; }
                     else { atomicAdd(ST + ch * 2, va); atomicAdd(ST + ch * 2 + 1, vc); }
                 }
             }
-            if (!C::PREP && det && det_arrive_wave(b, nseg * nstrips * C::TEAM)) {
+            if (!C::PREP && !C::INB && det && det_arrive_wave(b, nseg * nstrips * C::TEAM)) {
                 // last wave of the sample: ordered sum of all slots into copy 0 of the statistics buffer
                 for (int idx = lane; idx < COUT * 2; idx += 64)
                     p.stats[(size_t)b * COUT * 2 + idx] = det_sum(b, nseg * nstrips, COUT * 2, idx);
@@ -697,7 +713,7 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     const int njobs = p.B * nstrips * nseg;
     const int nwg = (njobs + C::TPW - 1) / C::TPW;
     const int jobs_per_xcd = (nwg + 7) / 8;                        // workgroups per XCD
-    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : (FL == FL_GEN_RGB ? "gen_rgb" : "enc_pool")))));
+    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : (FL == FL_GEN_RGB ? "gen_rgb" : (FL == FL_DOT_IN ? "dot_in" : "enc_pool"))))));
     dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
     hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM * C::TPW), C::LDS_BYTES * C::TPW, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
@@ -706,6 +722,11 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
 
 template <int CIN, int COUT>
 int launch_flavour(const ConvParams& p, hipStream_t s) {
+    if (p.in_coef) {
+        if constexpr ((CIN == 32 && COUT == 16) || (CIN == 64 && COUT == 32)) return launch_stream<CIN, COUT, FL_DOT_IN>(p, s);
+        dge_set_error("conv_stream: the instance-norm backward epilogue is built for 32 -> 16 and 64 -> 32 only");
+        return -1;
+    }
     if (p.dot_src) {
         if constexpr (CIN == COUT && CIN >= 32) {        // the generator's stride-1 layers at 512^2 / 1024^2 (64 / 32 channels)
             if (p.prep) return launch_stream<CIN, COUT, FL_DOT_PREP>(p, s);
@@ -751,7 +772,8 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
         }
     }
     if ((long)p.W * p.Cin * 2 >= (1L << 31) || (long)p.H * p.W * 64 * 2 >= (1L << 40)) return false;
-    if (p.dot_src && !p.stats) return false;
+    if (p.dot_src && !p.stats && !p.in_coef) return false;
+    if (p.in_coef && !(p.dot_src && p.prep_stats && !p.prep && !p.stats && ((p.Cin == 32 && p.Cout == 16) || (p.Cin == 64 && p.Cout == 32)))) return false;
     if (p.prep && !(p.Cin == p.Cout && p.Cin >= 32)) return false;
     if (p.Cin == 64 && !p.dot_src && (p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0))) return false;
     if (p.dot_src && (p.bias || p.noise || p.in_shift || p.act != DGE_ACT_NONE)) return false;

@@ -308,7 +308,8 @@ def truncation(w, w_avg, num_layers, psi, layers):
 
 def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, out_scale=None, bias=None,
            bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0, addend=None, add_scale=1.0, stats=None,
-           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None, in_t2d=False, rgb=None, pool_out=False, pool_mask=False):
+           out=None, in_s2d=False, dot_src=None, in_up2=False, in_relu=False, prep=None, relu_mask=None, in_t2d=False, rgb=None, pool_out=False, pool_mask=False,
+           in_bwd=None):
     """x: [B,H,W,Cin] NHWC (bf16 or f32).  Returns y [B,OH,OW,cout].
     `prep`: dict(gain, noise [1|B,OH,OW] or None, ns (device scalar) or None, stats=SlotStats(B, cout)) - the fused tail backward of
     the layer that produced `dot_src` (dge_conv_desc.prep): y is then g_z and prep['stats'] receives (sum g_z*(z - ns*noise), sum g_z).
@@ -316,6 +317,9 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     `rgb`: dict(w [3,cout] f32, style [B,cout], bias [3], wscale, out [B,3,H,W] f32, skip_y=False) - the toRGB of the result written
     by the same launch (dge_conv_desc.rgb_*, where conv_rgb_supported() says so); with skip_y the activation itself is not stored
     and None is returned.
+    `in_bwd`: dict(coef [B,cout,3], noise [B,H,W] or None, red=SlotStats(B, cout)) - the instance-norm + activation backward of the
+    layer input dot_src in the epilogue (dge_conv_desc.in_bwd_coef, where conv_in_bwd_supported() says so): y is g_pre, red receives
+    (sum g_pre, sum g_pre*noise).
     `pool_out`: the launch stores the 2x2 average pool of its result, [B,OH/2,OW/2,cout] (dge_conv_desc.pool_out, where
     conv_pool_supported() says so); with pool_mask the signs of the full-resolution values come back too: returns (y, mask)."""
     B, H, W, Cin = x.shape
@@ -380,6 +384,15 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         d.prep_noise, d.prep_ns = _f32(pn), _f32(prep.get("ns") if pn is not None else None)
         d.prep_noise_batch = 1 if pn is None else pn.shape[0]
         d.prep_stats = _f32(prep["stats"].alloc(nslot))
+    if in_bwd is not None:
+        if dot_src is None or stats is not None or prep is not None:
+            raise DgeError("conv2d: in_bwd needs dot_src and excludes stats / prep")
+        nblk = ((H + 15) // 16) * ((W + 15) // 16) * B
+        d.stats_slots = max(1, min(64, nblk // 16))
+        pn = in_bwd.get("noise")
+        d.in_bwd_coef = _f32(in_bwd["coef"])
+        d.prep_noise, d.prep_noise_batch = _f32(pn), 1 if pn is None else pn.shape[0]
+        d.prep_stats = _f32(in_bwd["red"].alloc(d.stats_slots))
     if rgb is not None:
         d.rgb_w, d.rgb_style, d.rgb_bias, d.rgb_out = _f32(rgb["w"]), _f32(rgb["style"]), _f32(rgb["bias"]), _f32(rgb["out"])
         d.rgb_wscale, d.rgb_skip_y = float(rgb["wscale"]), 1 if rgb.get("skip_y") else 0
@@ -415,6 +428,11 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     if pool_out and pool_mask:
         return out, mask
     return out
+
+
+def conv_in_bwd_supported(B, H, W, cin, cout, dtype):
+    """True when a 3x3 data-gradient launch cin -> cout of this shape may carry the instance-norm backward epilogue (conv2d(in_bwd=...))"""
+    return bool(lib().dge_conv_in_bwd_supported(int(B), int(H), int(W), int(cin), int(cout), 3, int(dtype)))
 
 
 def conv_pp_supported(B, H, W, cin, cout, dtype):

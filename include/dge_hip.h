@@ -119,6 +119,13 @@ typedef struct dge_conv_desc {
      * hint: no effect on results; NULL = none. */
     const void* prefetch_w;
     int prefetch_ntot, prefetch_cin;
+    /* Data-gradient launches where dge_conv_in_bwd_supported() says so (conv_2 of the first encoder blocks, model/E/E.py:50-85
+     * differentiated): the instance-norm backward of the layer's INPUT x = dot_src applied in the epilogue.  in_bwd_coef [B][Cout][3]
+     * = (A, Bc, Cc) from dge_in_bwd_coef_slots (its sums from dge_conv_wgrad_dots, i.e. before this launch); the launch stores
+     * g_pre = (A*acc + Bc*x + Cc) * lrelu'(x) - what dge_in_bwd_fused(act = 1) made of the stored data gradient in a pass of its
+     * own - and adds (sum g_pre, sum g_pre*noise) per (sample, channel) to prep_stats [stats_slots][B][Cout][2] (the bias /
+     * noise-weight gradients of the layer that produced x; noise = prep_noise [prep_noise_batch][H][W]).  stats / prep: none. */
+    const float* in_bwd_coef;
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
@@ -187,6 +194,7 @@ int dge_torgb(const void* x, const float* wrgb, const float* style, const float*
               int B, int H, int W, int cin, float wscale, int dtype, dge_stream_t stream);
 
 int dge_conv_rgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
+int dge_conv_in_bwd_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int dge_conv_pool_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 /* img[b][c][y][x] += up2(prev)[b][c][y][x]: the skip connection of SynthesisModule.forward :517-522 (UpsamplingLayer :603-615:
  * zero-insert, pad (2,1), 4x4 FIR == per-axis taps {.25,.75} / {.75,.25}) for an image whose toRGB term is already in img
