@@ -24,6 +24,7 @@ class ConvDesc(C.Structure):
         ("rgb_w", C.c_void_p), ("rgb_style", C.c_void_p), ("rgb_bias", C.c_void_p), ("rgb_out", C.c_void_p), ("rgb_wscale", C.c_float),
         ("rgb_skip_y", C.c_int), ("pool_out", C.c_int), ("pool_mask", C.c_void_p),
         ("prefetch_w", C.c_void_p), ("prefetch_ntot", C.c_int), ("prefetch_cin", C.c_int), ("in_bwd_coef", C.c_void_p),
+        ("in_bwd_extra", C.c_void_p), ("in_bwd_extra_scale", C.c_float), ("fr_img4", C.c_void_p), ("fr_out", C.c_void_p),
     ]
 
 
@@ -73,11 +74,13 @@ SIGNATURES = {
     "dge_torgb": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dge_conv_rgb_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_conv_in_bwd_supported": [_I, _I, _I, _I, _I, _I, _I],
+    "dge_conv_in_bwd_fromrgb_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_conv_pool_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_rgb_upsample_add": [_P, _P, _I, _I, _I, _P],
     "dge_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dge_nhwc_to_nchw": [_P, _P, _I, _I, _I, _I, _P],
     "dge_fromrgb": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dge_fromrgb2": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dge_stats_finalize": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "dge_stats_finalize_slots": [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P],
     "dge_blend": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],

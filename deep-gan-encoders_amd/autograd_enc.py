@@ -133,8 +133,14 @@ def encoder_forward(E, img, noises=None, save=False):
     zeros = lambda c: ops.SlotStats(B, c, dev)        # statistics slots are added by stats_finalize itself
     fr = E.FromRGB.from_rgb
     stats = zeros(E.startf)
-    x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats.plain())
-    saved = {"img": img, "x0": x, "blocks": []} if save else None
+    # (training: the image also leaves in pixel-major form - the last data gradient of the backward reduces the FromRGB parameter
+    #  gradients against it, autograd_enc_bwd.py)
+    want4 = save and E.startf == 16 and not ops.is_deterministic() and ops.conv_in_bwd_fromrgb_supported(B, R, R, 16, 16, dt)
+    x = ops.fromrgb(img.float(), fr.weight.detach(), fr.bias.detach(), dt, stats.plain(), img4=want4)
+    img4 = None
+    if want4:
+        x, img4 = x
+    saved = {"img": img, "x0": x, "blocks": [], "img4": img4} if save else None
     ws, ni = [], 0
     L = E.layer_count
     lay = heads_layout(E, B, dev)

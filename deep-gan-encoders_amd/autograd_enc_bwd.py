@@ -132,12 +132,27 @@ def encoder_backward(E, saved, g_w):
         grads[pre + "bias_1"] = red1[0].reshape(1, Cc, 1, 1)
         grads[pre + "noise_weight_1"] = red1[1].reshape(1, Cc, 1, 1)
         gW1 = ops.zeros(tuple(blk.conv_1.weight.shape), dev)
-        ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
-        grads[pre + "conv_1.weight"] = gW1
         dots1 = ops.SlotStats(B, Cc, dev)
-        g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
+        # Block 0: the gradient w.r.t. the FromRGB output has one reader, the FromRGB parameter gradients.  With the instance-norm sums
+        # out of the weight-gradient launch, the data gradient of conv_1 reduces them in its epilogue and stores nothing (the
+        # in_bwd_fromrgb pass over g_y1, x0 and the image disappears, and so does the store of g_y1)
+        fuse_fr = FUSE_IN_BWD and j == 0 and saved.get("img4") is not None and ops.conv_in_bwd_fromrgb_supported(B, H, H, Cc, Cc, dt) and \
+            ops.conv_wgrad_dots(g_pre1, x, gW1, rec["sc1"], rec["sh1"], blk.conv_1.weight, dots1)
+        if not fuse_fr:
+            ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
+        grads[pre + "conv_1.weight"] = gW1
         coef1 = (dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
-        if j == 0 and Cc <= 512:
+        if fuse_fr:
+            frh = ops.SlotStats(B, Cc, dev)
+            ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, dot_src=x, out=x.new_empty((1, 1, 1, 1)),
+                       in_bwd=dict(coef=ops.in_bwd_coef(*coef1), fr=frh, img4=saved["img4"], extra=extra if extra_pool else None,
+                                   extra_scale=extra_scale))
+            fr = ops._sum_planar(frh.buf.view(-1, Cc, 4), torch.empty((4, Cc), dtype=torch.float32, device=dev), later)
+        else:
+            g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
+        if fuse_fr:
+            pass
+        elif j == 0 and Cc <= 512:
             # x is the FromRGB output: its gradient has one reader, the FromRGB parameter gradients - reduced in the same launch
             fr = ops.in_bwd_fromrgb(g_y1, x, coef1, saved["img"].float(), extra=extra, extra_pool=extra_pool, extra_scale=extra_scale,
                                     defer=later)

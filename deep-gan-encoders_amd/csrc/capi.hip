@@ -115,6 +115,8 @@ extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
                     (d->prefetch_cin == 512 || d->prefetch_cin == 256);
     p.pf_w = pf ? d->prefetch_w : nullptr; p.pf_ntot = pf ? d->prefetch_ntot : 0; p.pf_cin = pf ? d->prefetch_cin : 0;
     p.in_coef = d->in_bwd_coef;
+    p.in_extra = d->in_bwd_coef ? d->in_bwd_extra : nullptr; p.in_extra_scale = d->in_bwd_extra_scale;
+    p.fr_img4 = d->in_bwd_coef ? d->fr_img4 : nullptr; p.fr_out = d->in_bwd_coef ? d->fr_out : nullptr;
     if (d->in_bwd_coef) {
         DGE_CHECK(!dge_get_deterministic(), "conv2d: in_bwd_coef is not offered in deterministic mode; run dge_in_bwd");
         DGE_CHECK(d->ksize == 3 && !d->up && dge_conv_stream_eligible(p, d->dtype, d->ksize), "conv2d: in_bwd_coef is offered where "
@@ -146,6 +148,13 @@ extern "C" int dge_conv_in_bwd_supported(int B, int H, int W, int Cin, int Cout,
     ConvParams p = {};
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ntot_valid = Cout; p.Ntot = dge_packed_n(Cout);
     p.dot_src = (const void*)16; p.prep_stats = (float*)16; p.in_coef = (const float*)16;
+    return (ksize == 3 && !dge_get_deterministic() && dge_conv_stream_eligible(p, dtype, ksize)) ? 1 : 0;
+}
+// ... and reduce the FromRGB parameter gradients from it instead of storing it (dge_conv_desc.fr_out)
+extern "C" int dge_conv_in_bwd_fromrgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    ConvParams p = {};
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ntot_valid = Cout; p.Ntot = dge_packed_n(Cout);
+    p.dot_src = (const void*)16; p.in_coef = (const float*)16; p.fr_img4 = (const float*)16; p.fr_out = (float*)16;
     return (ksize == 3 && !dge_get_deterministic() && dge_conv_stream_eligible(p, dtype, ksize)) ? 1 : 0;
 }
 

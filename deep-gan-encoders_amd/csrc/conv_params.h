@@ -64,6 +64,9 @@ struct ConvParams {
     // x = dot_src (dge_in_bwd_coef): the launch stores g_pre = (A*acc + Bc*x + Cc) * lrelu'(x) and adds (sum g_pre, sum g_pre*noise)
     // to prep_stats (noise = prep_noise: the plane of the layer that produced x)
     const float* in_coef;
+    // FL_DOT_FR (with in_coef): g_x = A*acc + Bc*x + Cc + in_extra_scale * in_extra[parent pixel] is not stored; fr_out [slots][B][Cout][4]
+    // += sum g_x*lrelu'(x) * (fr_img4[b][p][0..3]);  in_extra [B][H/2][W/2][Cout] bf16 or null, fr_img4 [B][H][W][4] f32
+    const void* in_extra; float in_extra_scale; const float* fr_img4; float* fr_out;
 };
 
 int dge_conv_launch(const ConvParams& p, int dtype, int ksize, hipStream_t s);

@@ -103,7 +103,13 @@ template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigne
                      "buffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds" : : "v"(voff), "s"(m0v), "s"(rs), "v"(voff1) : "memory");
 }
 
-enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5, FL_ENC_POOL = 6, FL_DOT_IN = 7 };
+enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5, FL_ENC_POOL = 6, FL_DOT_IN = 7, FL_DOT_FR = 8 };
+// FL_DOT_FR:    the LAST data gradient of the encoder backward (conv_1 of block 0, 16 -> 16): x = dot_src is the FromRGB output x0 =
+//               lrelu(W img + b) (model/utils/net.py:231-240).  g_x0 = A*acc + Bc*x0 + Cc + extra_scale*extra[parent pixel] (instance
+//               norm backward + the pooled skip gradient, model/E/E.py:77-84 differentiated) has ONE reader, the FromRGB parameter
+//               gradients: it is not stored but reduced in place, fr_out[b][c][0..3] += sum g_pre * (img_r, img_g, img_b, 1), g_pre =
+//               g_x0 * lrelu'(x0).  Two more 512-byte rows ride the DMA stream per step: the pooled extra row and the image row in
+//               pixel-major form [H][W][4] f32 (fr_img4, fourth component 1).
 // FL_DOT_IN:    data-gradient mode with the instance-norm backward of the layer's input x = dot_src applied in the epilogue
 //               (ConvParams::in_coef, model/E/E.py:51-62 differentiated): y = g_pre = (A*acc + Bc*x + Cc) * lrelu'(x); A is folded into
 //               the weights, Cc is the C operand of the first MFMA; prep_stats (sum g_pre, sum g_pre*noise) = the bias / noise-weight
@@ -128,10 +134,10 @@ struct SC {
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
-    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL, INB = FL == FL_DOT_IN;
+    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL, FRB = FL == FL_DOT_FR, INB = FL == FL_DOT_IN || FRB;
     static_assert(!RGB || COUT == 32 || (COUT == 64 && TEAM == 2), "fused toRGB: 32 output channels per wave, one wave or a 2-wave team per pixel");
     static constexpr bool DOT = FL == FL_DOT || PREP || INB, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS || POOL;
-    static constexpr bool NOISE = !DOT || PREP || INB;
+    static constexpr bool NOISE = !DOT || PREP || (INB && !FRB);
     static constexpr int NR = 6;                 // ring rows = unroll period
     static constexpr int dot_depth(int nr) { for (int d = 4; d >= 1; d--) if (d <= nr - 3 && nr % (d + 1) == 0) return d; return 1; }
     static constexpr int D = DOT ? dot_depth(6) : 2;            // rows in flight ahead of the newest live row (<= NR - 3)
@@ -144,7 +150,7 @@ struct SC {
     static constexpr int DROWB = 32 * DCH * 16, DPIECES = DROWB / 1024;
     static_assert(!DOT || MTW == 1, "data-gradient mode: one M tile per wave");
     static constexpr int XPW = TEAM == 2 ? (PIECES + 1) / 2 : PIECES;           // x loads per wave per row
-    static constexpr int LPR = XPW + (DOT ? DPIECES : 0);                       // loads per wave per step (+ 1 noise piece when I == 0)
+    static constexpr int LPR = XPW + (DOT ? DPIECES : 0) + (FRB ? 2 : 0);       // loads per wave per step (+ 1 noise piece when I == 0)
     static constexpr int X_OFF = 0;
     static constexpr int XRING = NR * RB;
     static constexpr int N_OFF = (XRING + 1023) / 1024 * 1024;                  // per wave: two noise buffers of 8 rows x 32 pixels f32
@@ -152,7 +158,10 @@ struct SC {
     static_assert(NR <= 8, "a noise piece holds 8 rows");
     static constexpr int D_OFF = N_OFF + TEAM * NRING;                           // per wave: dot ring DR x DROWB
     static constexpr int DRING = DOT ? DR * DROWB : 0;
-    static constexpr int T_OFF = D_OFF + TEAM * DRING;                           // per wave: T table [32*MTW][12] f32 + epilogue constants [3][32*MTW]
+    static constexpr int E_OFF = D_OFF + TEAM * DRING;                           // FRB: extra ring and image ring, DR rows of 512 B each
+    static constexpr int ERING = FRB ? 2 * DR * 512 : 0;
+    static_assert(!FRB || (CIN == 16 && COUT == 16 && TEAM == 1), "FromRGB reduction flavour: 16 -> 16");
+    static constexpr int T_OFF = E_OFF + TEAM * ERING;                           // per wave: T table [32*MTW][12] f32 + epilogue constants [3][32*MTW]
     static constexpr int TBYTES = 32 * MTW * 16 * 4;
     static constexpr int DUMMY_OFF = T_OFF + TEAM * TBYTES;
     static constexpr int RGBX_OFF = DUMMY_OFF + (TEAM == 2 ? 1024 : 0);             // fused toRGB of a team: wave 1's partial sums, [2 row parities][3][32] f32
@@ -232,6 +241,11 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
         dvoff1 = (unsigned)((x0 + px + PPP) * C::CPB + ((chunk0 + (cs ^ chunk_swz<C::LOGDCH>(px + PPP))) << 4)) - 1024u;
     }
     const rsrc_t rs_null = make_rsrc(Xb, 0);
+    // FRB: rows of the pooled skip gradient [B][H/2][W/2][16] bf16 and of the pixel-major image [B][H][W][4] f32
+    const unsigned exrow_bytes = C::FRB ? (unsigned)(p.W >> 1) * 32u : 0u, imrow_bytes = C::FRB ? (unsigned)p.W * 16u : 0u;
+    const unsigned long long EXb = (C::FRB && p.in_extra) ? (unsigned long long)p.in_extra + (unsigned long long)b * (p.H >> 1) * exrow_bytes : Xb;
+    const unsigned long long IMb = C::FRB ? (unsigned long long)p.fr_img4 + (unsigned long long)b * p.H * imrow_bytes : Xb;
+    const unsigned evoff = (unsigned)((x0 >> 1) * 32 + (lane & 31) * 16), ivoff = (unsigned)((x0 + (lane & 31)) * 16);
 
     // ---- issue of (x halo row h, noise row h-2, dot row h-2) into ring slot `slot` / `slot2`
     // row pointers of the NEXT row to fetch (advance one image row per issue; rows outside the image are never dereferenced:
@@ -250,6 +264,16 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             const rsrc_t rd = make_rsrc(dptr, ov ? yrow_bytes : 0u);
             dptr += yrow_bytes;
             dma_dot<C::DPIECES>(dvoff, dvoff1, rd, lds0 + C::D_OFF + wave * C::DRING + slot_d * C::DROWB);
+        }
+        if constexpr (C::FRB) {
+            // output row gy - 1: its pooled parent row of `extra` (16 pixels x 32 B of this strip) and its image row (32 pixels x 16 B)
+            const int oy = gy - 1;
+            const rsrc_t re = make_rsrc(EXb + (unsigned long long)(ov ? (oy >> 1) : 0) * exrow_bytes, (ov && p.in_extra) ? exrow_bytes : 0u);
+            const rsrc_t ri = make_rsrc(IMb + (unsigned long long)(ov ? oy : 0) * imrow_bytes, ov ? imrow_bytes : 0u);
+            unsigned long long keep;
+            asm volatile(DGE_MASK(0xffffffff) "s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\t"
+                         "s_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %5, %6, 0 offen lds\n\t" DGE_UNMASK
+                         : "=&s"(keep) : "v"(evoff), "s"(lds0 + C::E_OFF + slot_d * 512), "s"(re), "s"(lds0 + C::E_OFF + C::DR * 512 + slot_d * 512), "v"(ivoff), "s"(ri) : "memory");
         }
     };
     // noise rows q .. q+7 of the segment (one piece; NR of them are used) into buffer `buf_off` (0 / 1024)
@@ -429,6 +453,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     // prep: x = lrelu(z)*gain of the layer below -> g_z = g * gain * lrelu'(x), z = x / (gain * lrelu'(x))
     const float pg_pos = p.prep_gain, pg_neg = 0.2f * p.prep_gain, pz_pos = 1.f / p.prep_gain, pz_neg = 1.f / (0.2f * p.prep_gain);
     const float pns = (C::PREP && p.prep_noise && p.prep_ns) ? p.prep_ns[0] : 0.f;
+    const float fr_es = C::FRB ? p.in_extra_scale : 0.f;
 
     // ---- one output row.  I = position in the ring period (compile time): halo rows in slots I, I+1, I+2 (mod NR)
 #define DGE_T(k)
@@ -507,6 +532,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 dd[0] = lds_u4(doff[0] + (I % C::DR) * C::DROWB);
                 if constexpr (NREG == 16) dd[1] = lds_u4(doff[1] + (I % C::DR) * C::DROWB);
                 const float nzs = C::PREP ? pns * nz : 0.f;
+                float exf[8];
+                float4 fr_im = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (C::FRB) {
+                    unpack16(lds_u4(lds0 + C::E_OFF + (I % C::DR) * 512 + (n31 >> 1) * 32 + kh * 16), exf, (bf16_t*)nullptr);
+                    const uint4 t4 = lds_u4(lds0 + C::E_OFF + C::DR * 512 + (I % C::DR) * 512 + n31 * 16);
+                    fr_im = make_float4(__uint_as_float(t4.x), __uint_as_float(t4.y), __uint_as_float(t4.z), __uint_as_float(t4.w));
+                }
 #pragma unroll
                 for (int q = 0; q < NREG / 8; q++) {
                     float d[8];
@@ -514,6 +546,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const int r = 8 * q + e;
+                        if constexpr (C::FRB) {
+                            // v = A*acc + Cc; oscv = Bc; the four sums of channel r live in s0[0][r], s0[0][8 + r], s1[0][r], s1[0][8 + r]
+                            const float gp = (fmaf(oscv[r], d[e], v[r]) + fr_es * exf[e]) * (d[e] > 0.f ? 1.f : 0.2f);
+                            s0[0][r] = fmaf(gp, fr_im.x, s0[0][r]); s0[0][8 + r] = fmaf(gp, fr_im.y, s0[0][8 + r]);
+                            s1[0][r] = fmaf(gp, fr_im.z, s1[0][r]); s1[0][8 + r] += gp;
+                            continue;
+                        }
                         if constexpr (C::INB) {
                             // v = A*acc + Cc (weights, C operand); oscv = Bc
                             const float o = fmaf(oscv[r], d[e], v[r]) * (d[e] > 0.f ? 1.f : 0.2f);
@@ -585,6 +624,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 }
                 continue;
             }
+            if constexpr (C::FRB) continue;                    // nothing is stored: the gradient w.r.t. x0 has been reduced
             uint4 o0 = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
             uint4 o1 = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
             unsigned char* dst = yrow + yoff + mt * 64;
@@ -635,6 +675,22 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- statistics: reduce over the 32 pixel lanes, one atomic per channel per wave
+    if constexpr (C::FRB) {
+        // 32 sums per lane (8 channels x 4 components) over the 32 pixel lanes; lane n31 < 16 keeps channel 8 kh + (n31 & 7),
+        // components n31 >> 3 (from s0) and 2 + (n31 >> 3) (from s1): two atomic instructions per wave
+        float va = 0.f, vc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float a = pv ? s0[0][r] : 0.f, c = pv ? s1[0][r] : 0.f;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) { a += __shfl_xor(a, m, 64); c += __shfl_xor(c, m, 64); }
+            if (n31 == r) { va = a; vc = c; }
+        }
+        if (n31 < 16) {
+            float* __restrict__ FR = p.fr_out + ((size_t)(blockIdx.x % p.stats_slots) * p.B + b) * COUT * 4 + (8 * kh + (n31 & 7)) * 4 + (n31 >> 3);
+            atomicAdd(FR, va); atomicAdd(FR + 2, vc);
+        }
+    } else
     if constexpr (C::STATS || C::DOT) {
         if (p.stats || (C::INB && p.prep_stats)) {
             // lanes right of the image (ragged strips) accumulated values of pixels that do not exist: a lane is one pixel
@@ -713,7 +769,7 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     const int njobs = p.B * nstrips * nseg;
     const int nwg = (njobs + C::TPW - 1) / C::TPW;
     const int jobs_per_xcd = (nwg + 7) / 8;                        // workgroups per XCD
-    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : (FL == FL_GEN_RGB ? "gen_rgb" : (FL == FL_DOT_IN ? "dot_in" : "enc_pool"))))));
+    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : (FL == FL_GEN_RGB ? "gen_rgb" : (FL == FL_DOT_IN ? "dot_in" : (FL == FL_DOT_FR ? "dot_fromrgb" : "enc_pool")))))));
     dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
     hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM * C::TPW), C::LDS_BYTES * C::TPW, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
@@ -722,6 +778,11 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
 
 template <int CIN, int COUT>
 int launch_flavour(const ConvParams& p, hipStream_t s) {
+    if (p.in_coef && p.fr_out) {
+        if constexpr (CIN == 16 && COUT == 16) return launch_stream<CIN, COUT, FL_DOT_FR>(p, s);
+        dge_set_error("conv_stream: the FromRGB reduction epilogue is built for 16 -> 16 only");
+        return -1;
+    }
     if (p.in_coef) {
         if constexpr ((CIN == 32 && COUT == 16) || (CIN == 64 && COUT == 32)) return launch_stream<CIN, COUT, FL_DOT_IN>(p, s);
         dge_set_error("conv_stream: the instance-norm backward epilogue is built for 32 -> 16 and 64 -> 32 only");
@@ -773,7 +834,8 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     }
     if ((long)p.W * p.Cin * 2 >= (1L << 31) || (long)p.H * p.W * 64 * 2 >= (1L << 40)) return false;
     if (p.dot_src && !p.stats && !p.in_coef) return false;
-    if (p.in_coef && !(p.dot_src && p.prep_stats && !p.prep && !p.stats && ((p.Cin == 32 && p.Cout == 16) || (p.Cin == 64 && p.Cout == 32)))) return false;
+    if (p.in_coef && !p.fr_out && !(p.dot_src && p.prep_stats && !p.prep && !p.stats && ((p.Cin == 32 && p.Cout == 16) || (p.Cin == 64 && p.Cout == 32)))) return false;
+    if (p.fr_out && !(p.in_coef && p.dot_src && p.fr_img4 && !p.prep && !p.stats && p.Cin == 16 && p.Cout == 16 && p.H % 2 == 0 && p.W % 2 == 0)) return false;
     if (p.prep && !(p.Cin == p.Cout && p.Cin >= 32)) return false;
     if (p.Cin == 64 && !p.dot_src && (p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0))) return false;
     if (p.dot_src && (p.bias || p.noise || p.in_shift || p.act != DGE_ACT_NONE)) return false;

@@ -10,7 +10,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void fromrgb_kernel(const float* __restrict__ img, const float* __restrict__ W,
                                                        const float* __restrict__ bias, T* __restrict__ y,
-                                                       float* __restrict__ stats, int HW, int C) {
+                                                       float* __restrict__ stats, int HW, int C, float4* __restrict__ img4) {
     constexpr int EP = Elem<T>::PER16;
     __shared__ float red[256 * 2 * EP];
     const int b = blockIdx.y;
@@ -28,6 +28,7 @@ __global__ __launch_bounds__(256) void fromrgb_kernel(const float* __restrict__ 
         const int p = p0 + slot;
         if (slot < ppi && p < HW) {
             const float r = ib[p], g = ib[HW + p], bl = ib[2 * HW + p];
+            if (img4 && chunk == 0) img4[(size_t)b * HW + p] = make_float4(r, g, bl, 1.f);      // pixel-major copy for the backward (dge_conv_desc.fr_img4)
             float f[EP];
 #pragma unroll
             for (int e = 0; e < EP; e++) {
@@ -265,14 +266,20 @@ __global__ __launch_bounds__(256) void pixelnorm_nhwc_bwd_kernel(const T* __rest
 
 // =================================================================== C ABI
 
+extern "C" int dge_fromrgb2(const float* img, const float* w, const float* bias, void* y, float* stats, float* img4, int B, int HW,
+                            int C, int dtype, hipStream_t s);
 extern "C" int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, float* stats, int B, int HW,
                            int C, int dtype, hipStream_t s) {
+    return dge_fromrgb2(img, w, bias, y, stats, nullptr, B, HW, C, dtype, s);
+}
+extern "C" int dge_fromrgb2(const float* img, const float* w, const float* bias, void* y, float* stats, float* img4, int B, int HW,
+                            int C, int dtype, hipStream_t s) {
     const int ep = dtype == DGE_BF16 ? 8 : 4;
     DGE_CHECK(C % ep == 0 && C / ep <= 256 && 256 % (C / ep) == 0, "fromrgb: unsupported channel count %d", C);
     const int ppi = 256 / (C / ep);
     dim3 grid(dge_stream_grid(HW, ppi, B), B);
-    if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_kernel<bf16_t>, grid, dim3(256), 0, s, img, w, bias, (bf16_t*)y, stats, HW, C);
-    else hipLaunchKernelGGL(fromrgb_kernel<float>, grid, dim3(256), 0, s, img, w, bias, (float*)y, stats, HW, C);
+    if (dtype == DGE_BF16) hipLaunchKernelGGL(fromrgb_kernel<bf16_t>, grid, dim3(256), 0, s, img, w, bias, (bf16_t*)y, stats, HW, C, (float4*)img4);
+    else hipLaunchKernelGGL(fromrgb_kernel<float>, grid, dim3(256), 0, s, img, w, bias, (float*)y, stats, HW, C, (float4*)img4);
     DGE_LAUNCH_CHECK("fromrgb");
     return 0;
 }

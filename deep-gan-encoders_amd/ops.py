@@ -392,7 +392,12 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
         pn = in_bwd.get("noise")
         d.in_bwd_coef = _f32(in_bwd["coef"])
         d.prep_noise, d.prep_noise_batch = _f32(pn), 1 if pn is None else pn.shape[0]
-        d.prep_stats = _f32(in_bwd["red"].alloc(d.stats_slots))
+        if in_bwd.get("fr") is not None:          # FromRGB reduction flavour: nothing is stored, fr = SlotStats-like holder of [slots,B,cout,4]
+            d.fr_img4, d.in_bwd_extra, d.in_bwd_extra_scale = _f32(in_bwd["img4"]), _p(in_bwd.get("extra")), float(in_bwd.get("extra_scale", 1.0))
+            in_bwd["fr"].buf = zeros((d.stats_slots, B, cout, 4), x.device)
+            d.fr_out = _f32(in_bwd["fr"].buf)
+        else:
+            d.prep_stats = _f32(in_bwd["red"].alloc(d.stats_slots))
     if rgb is not None:
         d.rgb_w, d.rgb_style, d.rgb_bias, d.rgb_out = _f32(rgb["w"]), _f32(rgb["style"]), _f32(rgb["bias"]), _f32(rgb["out"])
         d.rgb_wscale, d.rgb_skip_y = float(rgb["wscale"]), 1 if rgb.get("skip_y") else 0
@@ -433,6 +438,10 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
 def conv_in_bwd_supported(B, H, W, cin, cout, dtype):
     """True when a 3x3 data-gradient launch cin -> cout of this shape may carry the instance-norm backward epilogue (conv2d(in_bwd=...))"""
     return bool(lib().dge_conv_in_bwd_supported(int(B), int(H), int(W), int(cin), int(cout), 3, int(dtype)))
+
+
+def conv_in_bwd_fromrgb_supported(B, H, W, cin, cout, dtype):
+    return bool(lib().dge_conv_in_bwd_fromrgb_supported(int(B), int(H), int(W), int(cin), int(cout), 3, int(dtype)))
 
 
 def conv_pp_supported(B, H, W, cin, cout, dtype):
@@ -558,13 +567,15 @@ def nhwc_to_nchw(src):
 
 
 # ------------------------------------------------------------------ encoder streaming ops
-def fromrgb(img, w, bias, dtype, stats=None):
+def fromrgb(img, w, bias, dtype, stats=None, img4=False):
+    """img4: also return the image in pixel-major form [B,H,W,4] f32 = (r, g, b, 1) (the backward's fused FromRGB reduction reads it)"""
     B, _, H, W = img.shape
     Cc = w.shape[0]
     y = torch.empty((B, H, W, Cc), dtype=tdtype(dtype), device=img.device)
-    check(lib().dge_fromrgb(_f32(img.contiguous()), _f32(w.reshape(Cc, 3)), _f32(bias), _p(y), _f32(stats), B, H * W, Cc,
-                            dtype, _stream()), "dge_fromrgb")
-    return y
+    i4 = torch.empty((B, H, W, 4), dtype=torch.float32, device=img.device) if img4 else None
+    check(lib().dge_fromrgb2(_f32(img.contiguous()), _f32(w.reshape(Cc, 3)), _f32(bias), _p(y), _f32(stats), _f32(i4), B, H * W, Cc,
+                             dtype, _stream()), "dge_fromrgb")
+    return (y, i4) if img4 else y
 
 
 def stats_finalize(stats, npix, eps=1e-8, musig_out=None):

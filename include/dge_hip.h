@@ -126,6 +126,16 @@ typedef struct dge_conv_desc {
      * own - and adds (sum g_pre, sum g_pre*noise) per (sample, channel) to prep_stats [stats_slots][B][Cout][2] (the bias /
      * noise-weight gradients of the layer that produced x; noise = prep_noise [prep_noise_batch][H][W]).  stats / prep: none. */
     const float* in_bwd_coef;
+    /* The last data gradient of the encoder backward (conv_1 of block 0; where dge_conv_in_bwd_fromrgb_supported() says so), with
+     * in_bwd_coef: x = dot_src is the FromRGB output (model/utils/net.py:231-240).  g_x = A*acc + Bc*x + Cc + in_bwd_extra_scale *
+     * in_bwd_extra[parent pixel] (in_bwd_extra [B][H/2][W/2][Cout] bf16 or NULL: the pooled skip gradient, E.py:77-84) is NOT stored (y
+     * is ignored): fr_out [stats_slots][B][Cout][4] (pre-zeroed) += sum_p g_x*lrelu'(x) * fr_img4[b][p][0..3] - the FromRGB weight /
+     * bias gradients per sample, what dge_in_bwd_fromrgb computed in a pass of its own.  fr_img4 [B][H][W][4] f32 = (r, g, b, 1) per
+     * pixel (dge_fromrgb's optional second output).  prep_stats / prep_noise unused. */
+    const void* in_bwd_extra;
+    float in_bwd_extra_scale;
+    const float* fr_img4;
+    float* fr_out;
 } dge_conv_desc;
 int dge_conv2d(const dge_conv_desc* d, dge_stream_t stream);
 /* 1 when a 3x3 stride-1 launch of this shape runs on the low-resolution kernel (csrc/conv_small.hip) and therefore wants its
@@ -195,6 +205,7 @@ int dge_torgb(const void* x, const float* wrgb, const float* style, const float*
 
 int dge_conv_rgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int dge_conv_in_bwd_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
+int dge_conv_in_bwd_fromrgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int dge_conv_pool_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 /* img[b][c][y][x] += up2(prev)[b][c][y][x]: the skip connection of SynthesisModule.forward :517-522 (UpsamplingLayer :603-615:
  * zero-insert, pad (2,1), 4x4 FIR == per-axis taps {.25,.75} / {.75,.25}) for an image whose toRGB term is already in img
@@ -208,6 +219,10 @@ int dge_nhwc_to_nchw(const void* src, float* dst, int B, int C, int HW, int dtyp
  * w [C][3], y NHWC dtype; optional per-(b,c) (sum, sumsq) of y into stats [B,C,2] (pre-zeroed). */
 int dge_fromrgb(const float* img, const float* w, const float* bias, void* y, float* stats, int B, int HW, int C,
                 int dtype, dge_stream_t stream);
+/* the same, plus (img4 != NULL) the image in pixel-major form [B][HW][4] f32 = (r, g, b, 1): the operand of the fused FromRGB
+ * parameter-gradient reduction of the backward (dge_conv_desc.fr_img4) */
+int dge_fromrgb2(const float* img, const float* w, const float* bias, void* y, float* stats, float* img4, int B, int HW, int C,
+                 int dtype, dge_stream_t stream);
 /* (sum, sumsq) -> musig [B,2C] = [mean | biased std] (E.py:51-53,64-66) and the instance-norm
  * affine sc = rsqrt(var+eps), sh = -mean*sc (nn.InstanceNorm2d eps=1e-8, E.py:57,68). */
 int dge_stats_finalize(const float* stats, float* musig, float* sc, float* sh, int B, int C, int npix, float eps,

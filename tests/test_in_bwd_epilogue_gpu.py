@@ -66,3 +66,51 @@ def test_fused_against_separate_passes_and_oracle(B, H, W, c2, cc):
         # A is folded into the bf16 weights (one operand rounding: 2^-9 relative per term, averaged over 9*c2 terms) + the output rounding
         viol = ((gotb - want).abs() - 2.0 ** -8 * want.abs() - 2.0 ** -9 * (A.abs() * gx.abs()).amax()).max().item()
         assert viol <= 0, (b, viol)
+
+
+@pytest.mark.parametrize("B,H,W,with_extra", [(8, 1024, 1024, True), (3, 136, 200, True), (4, 128, 160, False)])
+def test_fromrgb_reduction_in_the_last_data_gradient(B, H, W, with_extra):
+    """conv_1 of block 0 (16 -> 16): its data gradient, the backward of instance norm 1, the pooled skip gradient and the FromRGB
+    parameter gradients (model/utils/net.py:231-240 differentiated) in one launch, against the chain it replaces (data gradient with
+    dot statistics, then dge_in_bwd_fromrgb)"""
+    from dge_amd import ops
+    from dge_amd._lib import last_kernel
+    cc = 16
+    gen = torch.Generator(device=DEV).manual_seed(6100 + H)
+    g = torch.randn(B, H, W, cc, device=DEV, generator=gen).to(torch.bfloat16)                      # g_pre1
+    img = torch.rand(B, 3, H, W, device=DEV, generator=gen) * 2 - 1
+    wfr = torch.randn(cc, 3, device=DEV, generator=gen)
+    bfr = 0.1 * torch.randn(cc, device=DEV, generator=gen)
+    x0, img4 = ops.fromrgb(img, wfr, bfr, ops.BF16, img4=True)
+    assert torch.equal(img4[..., :3], img.permute(0, 2, 3, 1)) and bool((img4[..., 3] == 1).all())
+    w = torch.randn(cc, cc, 3, 3, device=DEV, generator=gen) / math.sqrt(9 * cc)
+    sc = 0.5 + torch.rand(B, cc, device=DEV, generator=gen)
+    sh = 0.3 * torch.randn(B, cc, device=DEV, generator=gen)
+    musig = torch.cat([0.3 * torch.randn(B, cc, device=DEV, generator=gen), 0.5 + torch.rand(B, cc, device=DEV, generator=gen)], 1)
+    gms = torch.randn(B, 2 * cc, device=DEV, generator=gen)
+    extra = torch.randn(B, H // 2, W // 2, cc, device=DEV, generator=gen).to(torch.bfloat16) if with_extra else None
+    wp = ops.pack_conv_weight(w, ops.PACK_DGRAD, ops.BF16, 1.0)
+    N = H * W
+    dots0 = ops.SlotStats(B, cc, DEV)
+    gy = ops.conv2d(g, wp, cc, 3, stats=dots0, dot_src=x0)
+    ref = ops.in_bwd_fromrgb(gy, x0, (dots0, gms, musig, sc, sh, N), img, extra=extra, extra_pool=True, extra_scale=0.25)     # [4, cc]
+    assert ops.conv_in_bwd_fromrgb_supported(B, H, W, cc, cc, ops.BF16)
+    dw = ops.zeros((cc, cc, 3, 3), DEV)
+    dots = ops.SlotStats(B, cc, DEV)
+    assert ops.conv_wgrad_dots(g, x0, dw, sc, sh, w, dots)
+    coef = ops.in_bwd_coef(dots, gms, musig, sc, sh, N)
+    frh = ops.SlotStats(B, cc, DEV)
+    ops.conv2d(g, wp, cc, 3, dot_src=x0, out=x0.new_empty((1, 1, 1, 1)), in_bwd=dict(coef=coef, fr=frh, img4=img4, extra=extra, extra_scale=0.25))
+    assert last_kernel() == "conv_stream<bf16,16,16,dot_fromrgb>"
+    got = frh.buf.sum((0, 1)).t()                      # [4, cc]
+    # sums with heavy cancellation: judged against the sums of absolute terms, taken from the separate passes' operands
+    coef_ = coef[:, None, None, :, :]
+    gx = coef_[..., 0] * gy.float() + coef_[..., 1] * x0.float() + coef_[..., 2]
+    if with_extra:
+        gx = gx + 0.25 * extra.float().repeat_interleave(2, 1).repeat_interleave(2, 2)
+    gp = gx * torch.where(x0.float() > 0, 1.0, 0.2)
+    absum = torch.stack([(gp.abs() * img4[..., k:k + 1].abs()).sum((0, 1, 2)) for k in range(4)])
+    want = torch.stack([(gp.double() * img4[..., k:k + 1].double()).sum((0, 1, 2)) for k in range(4)])
+    e_ref = ((ref.double() - want).abs() / absum).max().item()
+    e_got = ((got.double() - want).abs() / absum).max().item()
+    assert e_ref < 1e-4 and e_got < 1e-4, (e_ref, e_got)

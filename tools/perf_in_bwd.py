@@ -60,3 +60,39 @@ for B, H, c2, cc in [(8, 1024, 32, 16), (8, 512, 64, 32)]:
     m = {k: statistics.median(v) for k, v in r.items()}
     print(f"B={B} conv_2 {cc}->{c2} @{H}^2: wgrad {m['wg_old']:.1f} -> {m['wg_new']:.1f} us (+dots) | dgrad {m['dg_old']:.1f} + in_bwd {m['in_bwd']:.1f} = "
           f"{m['dg_old'] + m['in_bwd']:.1f} -> fused {m['dg_new']:.1f} us", flush=True)
+
+
+# the last data gradient: conv_1 of block 0 + in_bwd_fromrgb against the fused reduction
+B, H, cc = 8, 1024, 16
+gen = torch.Generator(device="cuda").manual_seed(2)
+g = torch.randn(B, H, H, cc, device="cuda", generator=gen).bfloat16()
+img = torch.rand(B, 3, H, H, device="cuda", generator=gen) * 2 - 1
+x0, img4 = ops.fromrgb(img, torch.randn(cc, 3, device="cuda", generator=gen), torch.zeros(cc, device="cuda"), ops.BF16, img4=True)
+w = torch.randn(cc, cc, 3, 3, device="cuda", generator=gen) / 12
+sc = 0.5 + torch.rand(B, cc, device="cuda", generator=gen); sh = 0.3 * torch.randn(B, cc, device="cuda", generator=gen)
+musig = torch.cat([0.3 * torch.randn(B, cc, device="cuda", generator=gen), 0.5 + torch.rand(B, cc, device="cuda", generator=gen)], 1)
+gms = torch.randn(B, 2 * cc, device="cuda", generator=gen)
+extra = torch.randn(B, H // 2, H // 2, cc, device="cuda", generator=gen).bfloat16()
+wp = ops.pack_conv_weight(w, ops.PACK_DGRAD, ops.BF16, 1.0)
+N = H * H
+d0 = ops.SlotStats(B, cc, "cuda")
+gy = ops.conv2d(g, wp, cc, 3, stats=d0, dot_src=x0)
+dw = ops.zeros((cc, cc, 3, 3), "cuda")
+dn = ops.SlotStats(B, cc, "cuda"); ops.conv_wgrad_dots(g, x0, dw, sc, sh, w, dn)
+tiny = x0.new_empty((1, 1, 1, 1))
+fs = dict(
+    fromrgb=lambda: ops.fromrgb(img, torch.zeros(cc, 3, device="cuda"), torch.zeros(cc, device="cuda"), ops.BF16),
+    fromrgb4=lambda: ops.fromrgb(img, torch.zeros(cc, 3, device="cuda"), torch.zeros(cc, device="cuda"), ops.BF16, img4=True),
+    dg_old=lambda: ops.conv2d(g, wp, cc, 3, stats=ops.SlotStats(B, cc, "cuda"), dot_src=x0),
+    in_bwd_fr=lambda: ops.in_bwd_fromrgb(gy, x0, (d0, gms, musig, sc, sh, N), img, extra=extra, extra_pool=True, extra_scale=0.25),
+    fused=lambda: ops.conv2d(g, wp, cc, 3, dot_src=x0, out=tiny, in_bwd=dict(coef=ops.in_bwd_coef(dn, gms, musig, sc, sh, N), fr=ops.SlotStats(B, cc, "cuda"), img4=img4, extra=extra, extra_scale=0.25)))
+for f in fs.values():
+    for _ in range(3):
+        f()
+r = {k: [] for k in fs}
+for _ in range(5):
+    for k, f in fs.items():
+        r[k].append(timed(f))
+m = {k: statistics.median(v) for k, v in r.items()}
+print(f"B={B} conv_1 16->16 @{H}^2 (block 0): fromrgb {m['fromrgb']:.1f} -> {m['fromrgb4']:.1f} us (+img4) | dgrad {m['dg_old']:.1f} + in_bwd_fromrgb {m['in_bwd_fr']:.1f} = "
+      f"{m['dg_old'] + m['in_bwd_fr']:.1f} -> fused {m['fused']:.1f} us", flush=True)
