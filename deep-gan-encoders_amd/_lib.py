@@ -75,6 +75,7 @@ SIGNATURES = {
     "dge_conv_rgb_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_conv_in_bwd_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_conv_in_bwd_fromrgb_supported": [_I, _I, _I, _I, _I, _I, _I],
+    "dge_conv_in_bwd_x_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_conv_pool_supported": [_I, _I, _I, _I, _I, _I, _I],
     "dge_rgb_upsample_add": [_P, _P, _I, _I, _I, _P],
     "dge_nchw_to_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],

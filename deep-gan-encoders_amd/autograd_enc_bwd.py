@@ -138,7 +138,11 @@ def encoder_backward(E, saved, g_w):
         # in_bwd_fromrgb pass over g_y1, x0 and the image disappears, and so does the store of g_y1)
         fuse_fr = FUSE_IN_BWD and j == 0 and saved.get("img4") is not None and ops.conv_in_bwd_fromrgb_supported(B, H, H, Cc, Cc, dt) and \
             ops.conv_wgrad_dots(g_pre1, x, gW1, rec["sc1"], rec["sh1"], blk.conv_1.weight, dots1)
-        if not fuse_fr:
+        # Blocks 1, 2: the same for the block input (instance-norm backward + pooled skip gradient, no activation) - the data gradient
+        # stores the block's input gradient itself
+        fuse_x = FUSE_IN_BWD and not fuse_fr and j > 0 and (extra is None or extra_pool) and ops.conv_in_bwd_x_supported(B, H, H, Cc, Cc, dt) and \
+            ops.conv_wgrad_dots(g_pre1, x, gW1, rec["sc1"], rec["sh1"], blk.conv_1.weight, dots1)
+        if not (fuse_fr or fuse_x):
             ops.conv_wgrad(g_pre1, x, gW1, rec["sc1"], rec["sh1"])
         grads[pre + "conv_1.weight"] = gW1
         coef1 = (dots1, gms1, rec["musig1"], rec["sc1"], rec["sh1"], N)
@@ -148,9 +152,12 @@ def encoder_backward(E, saved, g_w):
                        in_bwd=dict(coef=ops.in_bwd_coef(*coef1), fr=frh, img4=saved["img4"], extra=extra if extra_pool else None,
                                    extra_scale=extra_scale))
             fr = ops._sum_planar(frh.buf.view(-1, Cc, 4), torch.empty((4, Cc), dtype=torch.float32, device=dev), later)
+        elif fuse_x:
+            g_out = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, dot_src=x,
+                               in_bwd=dict(coef=ops.in_bwd_coef(*coef1), extra=extra, extra_scale=extra_scale))
         else:
             g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
-        if fuse_fr:
+        if fuse_fr or fuse_x:
             pass
         elif j == 0 and Cc <= 512:
             # x is the FromRGB output: its gradient has one reader, the FromRGB parameter gradients - reduced in the same launch

@@ -150,6 +150,13 @@ extern "C" int dge_conv_in_bwd_supported(int B, int H, int W, int Cin, int Cout,
     p.dot_src = (const void*)16; p.prep_stats = (float*)16; p.in_coef = (const float*)16;
     return (ksize == 3 && !dge_get_deterministic() && dge_conv_stream_eligible(p, dtype, ksize)) ? 1 : 0;
 }
+// ... in its block-input form (no activation, pooled skip gradient added: dge_conv_desc.in_bwd_extra, no prep_stats)
+extern "C" int dge_conv_in_bwd_x_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    ConvParams p = {};
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Ntot_valid = Cout; p.Ntot = dge_packed_n(Cout);
+    p.dot_src = (const void*)16; p.in_coef = (const float*)16;
+    return (ksize == 3 && !dge_get_deterministic() && dge_conv_stream_eligible(p, dtype, ksize)) ? 1 : 0;
+}
 // ... and reduce the FromRGB parameter gradients from it instead of storing it (dge_conv_desc.fr_out)
 extern "C" int dge_conv_in_bwd_fromrgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype) {
     ConvParams p = {};

@@ -103,7 +103,10 @@ template <int NP> __device__ __forceinline__ void dma_dot(unsigned voff, unsigne
                      "buffer_load_dwordx4 %3, %2, 0 offen offset:1024 lds" : : "v"(voff), "s"(m0v), "s"(rs), "v"(voff1) : "memory");
 }
 
-enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5, FL_ENC_POOL = 6, FL_DOT_IN = 7, FL_DOT_FR = 8 };
+enum { FL_GEN = 0, FL_ENC = 1, FL_ENC_STATS = 2, FL_DOT = 3, FL_DOT_PREP = 4, FL_GEN_RGB = 5, FL_ENC_POOL = 6, FL_DOT_IN = 7, FL_DOT_FR = 8, FL_DOT_INX = 9 };
+// FL_DOT_INX:   the block-input form of FL_DOT_IN (conv_1 of an encoder block, Cin = Cout): y = A*acc + Bc*x + Cc + extra_scale *
+//               extra[parent pixel] - instance-norm backward of the block input plus the pooled skip gradient (model/E/E.py:77-84
+//               differentiated), no activation, no reductions; the pooled row rides the DMA stream (1 KB per wave and step).
 // FL_DOT_FR:    the LAST data gradient of the encoder backward (conv_1 of block 0, 16 -> 16): x = dot_src is the FromRGB output x0 =
 //               lrelu(W img + b) (model/utils/net.py:231-240).  g_x0 = A*acc + Bc*x0 + Cc + extra_scale*extra[parent pixel] (instance
 //               norm backward + the pooled skip gradient, model/E/E.py:77-84 differentiated) has ONE reader, the FromRGB parameter
@@ -134,10 +137,10 @@ struct SC {
     static constexpr int MTW = MT / TEAM;                                      // M tiles per wave
     static constexpr int HW = 34, RB = HW * PXB;
     static constexpr int PIECES = (RB + 1023) / 1024;
-    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL, FRB = FL == FL_DOT_FR, INB = FL == FL_DOT_IN || FRB;
+    static constexpr bool PREP = FL == FL_DOT_PREP, RGB = FL == FL_GEN_RGB, POOL = FL == FL_ENC_POOL, FRB = FL == FL_DOT_FR, INX = FL == FL_DOT_INX, INB = FL == FL_DOT_IN || FRB || INX;
     static_assert(!RGB || COUT == 32 || (COUT == 64 && TEAM == 2), "fused toRGB: 32 output channels per wave, one wave or a 2-wave team per pixel");
     static constexpr bool DOT = FL == FL_DOT || PREP || INB, STATS = FL == FL_ENC_STATS, ENC = FL == FL_ENC || FL == FL_ENC_STATS || POOL;
-    static constexpr bool NOISE = !DOT || PREP || (INB && !FRB);
+    static constexpr bool NOISE = !DOT || PREP || (INB && !FRB && !INX);
     static constexpr int NR = 6;                 // ring rows = unroll period
     static constexpr int dot_depth(int nr) { for (int d = 4; d >= 1; d--) if (d <= nr - 3 && nr % (d + 1) == 0) return d; return 1; }
     static constexpr int D = DOT ? dot_depth(6) : 2;            // rows in flight ahead of the newest live row (<= NR - 3)
@@ -150,7 +153,7 @@ struct SC {
     static constexpr int DROWB = 32 * DCH * 16, DPIECES = DROWB / 1024;
     static_assert(!DOT || MTW == 1, "data-gradient mode: one M tile per wave");
     static constexpr int XPW = TEAM == 2 ? (PIECES + 1) / 2 : PIECES;           // x loads per wave per row
-    static constexpr int LPR = XPW + (DOT ? DPIECES : 0) + (FRB ? 2 : 0);       // loads per wave per step (+ 1 noise piece when I == 0)
+    static constexpr int LPR = XPW + (DOT ? DPIECES : 0) + (FRB ? 2 : 0) + (INX ? 1 : 0);       // loads per wave per step (+ 1 noise piece when I == 0)
     static constexpr int X_OFF = 0;
     static constexpr int XRING = NR * RB;
     static constexpr int N_OFF = (XRING + 1023) / 1024 * 1024;                  // per wave: two noise buffers of 8 rows x 32 pixels f32
@@ -159,7 +162,8 @@ struct SC {
     static constexpr int D_OFF = N_OFF + TEAM * NRING;                           // per wave: dot ring DR x DROWB
     static constexpr int DRING = DOT ? DR * DROWB : 0;
     static constexpr int E_OFF = D_OFF + TEAM * DRING;                           // FRB: extra ring and image ring, DR rows of 512 B each
-    static constexpr int ERING = FRB ? 2 * DR * 512 : 0;
+    static constexpr int ERING = FRB ? 2 * DR * 512 : (INX ? DR * 1024 : 0);      // (INX: per wave, 16 pooled pixels x 32 channels per row)
+    static_assert(!INX || (CIN == COUT && CIN >= 32), "block-input flavour: 32 -> 32, 64 -> 64");
     static_assert(!FRB || (CIN == 16 && COUT == 16 && TEAM == 1), "FromRGB reduction flavour: 16 -> 16");
     static constexpr int T_OFF = E_OFF + TEAM * ERING;                           // per wave: T table [32*MTW][12] f32 + epilogue constants [3][32*MTW]
     static constexpr int TBYTES = 32 * MTW * 16 * 4;
@@ -242,10 +246,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     }
     const rsrc_t rs_null = make_rsrc(Xb, 0);
     // FRB: rows of the pooled skip gradient [B][H/2][W/2][16] bf16 and of the pixel-major image [B][H][W][4] f32
-    const unsigned exrow_bytes = C::FRB ? (unsigned)(p.W >> 1) * 32u : 0u, imrow_bytes = C::FRB ? (unsigned)p.W * 16u : 0u;
-    const unsigned long long EXb = (C::FRB && p.in_extra) ? (unsigned long long)p.in_extra + (unsigned long long)b * (p.H >> 1) * exrow_bytes : Xb;
+    const unsigned exrow_bytes = (C::FRB || C::INX) ? (unsigned)(p.W >> 1) * C::CPB : 0u, imrow_bytes = C::FRB ? (unsigned)p.W * 16u : 0u;
+    const unsigned long long EXb = ((C::FRB || C::INX) && p.in_extra) ? (unsigned long long)p.in_extra + (unsigned long long)b * (p.H >> 1) * exrow_bytes : Xb;
     const unsigned long long IMb = C::FRB ? (unsigned long long)p.fr_img4 + (unsigned long long)b * p.H * imrow_bytes : Xb;
-    const unsigned evoff = (unsigned)((x0 >> 1) * 32 + (lane & 31) * 16), ivoff = (unsigned)((x0 + (lane & 31)) * 16);
+    // (INX: lane = (pooled pixel, 16-byte chunk of this wave's 32 channels), chunk swizzled like the other rings)
+    const unsigned evoff = C::INX ? (unsigned)(((x0 >> 1) + (lane >> 2)) * C::CPB + wave * 64 + (((lane & 3) ^ chunk_swz<2>(lane >> 2)) << 4))
+                                  : (unsigned)((x0 >> 1) * 32 + (lane & 31) * 16);
+    const unsigned ivoff = (unsigned)((x0 + (lane & 31)) * 16);
 
     // ---- issue of (x halo row h, noise row h-2, dot row h-2) into ring slot `slot` / `slot2`
     // row pointers of the NEXT row to fetch (advance one image row per issue; rows outside the image are never dereferenced:
@@ -264,6 +271,11 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             const rsrc_t rd = make_rsrc(dptr, ov ? yrow_bytes : 0u);
             dptr += yrow_bytes;
             dma_dot<C::DPIECES>(dvoff, dvoff1, rd, lds0 + C::D_OFF + wave * C::DRING + slot_d * C::DROWB);
+        }
+        if constexpr (C::INX) {
+            const int oy = gy - 1;
+            const rsrc_t re = make_rsrc(EXb + (unsigned long long)(ov ? (oy >> 1) : 0) * exrow_bytes, (ov && p.in_extra) ? exrow_bytes : 0u);
+            dma_piece(evoff, re, lds0 + C::E_OFF + wave * C::ERING + slot_d * 1024);
         }
         if constexpr (C::FRB) {
             // output row gy - 1: its pooled parent row of `extra` (16 pixels x 32 B of this strip) and its image row (32 pixels x 16 B)
@@ -453,7 +465,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     // prep: x = lrelu(z)*gain of the layer below -> g_z = g * gain * lrelu'(x), z = x / (gain * lrelu'(x))
     const float pg_pos = p.prep_gain, pg_neg = 0.2f * p.prep_gain, pz_pos = 1.f / p.prep_gain, pz_neg = 1.f / (0.2f * p.prep_gain);
     const float pns = (C::PREP && p.prep_noise && p.prep_ns) ? p.prep_ns[0] : 0.f;
-    const float fr_es = C::FRB ? p.in_extra_scale : 0.f;
+    const float fr_es = (C::FRB || C::INX) ? p.in_extra_scale : 0.f;
 
     // ---- one output row.  I = position in the ring period (compile time): halo rows in slots I, I+1, I+2 (mod NR)
 #define DGE_T(k)
@@ -532,7 +544,12 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 dd[0] = lds_u4(doff[0] + (I % C::DR) * C::DROWB);
                 if constexpr (NREG == 16) dd[1] = lds_u4(doff[1] + (I % C::DR) * C::DROWB);
                 const float nzs = C::PREP ? pns * nz : 0.f;
-                float exf[8];
+                float exf[8], exx[C::INX ? 2 : 1][8];
+                if constexpr (C::INX) {
+#pragma unroll
+                    for (int q = 0; q < NREG / 8; q++)
+                        unpack16(lds_u4(lds0 + C::E_OFF + wave * C::ERING + (I % C::DR) * 1024 + (n31 >> 1) * 64 + (((2 * q + kh) ^ chunk_swz<2>(n31 >> 1)) << 4)), exx[q], (bf16_t*)nullptr);
+                }
                 float4 fr_im = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (C::FRB) {
                     unpack16(lds_u4(lds0 + C::E_OFF + (I % C::DR) * 512 + (n31 >> 1) * 32 + kh * 16), exf, (bf16_t*)nullptr);
@@ -546,6 +563,10 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
                         const int r = 8 * q + e;
+                        if constexpr (C::INX) {
+                            v[r] = fmaf(fr_es, exx[C::INX ? q : 0][e], fmaf(oscv[r], d[e], v[r]));      // v = A*acc + Cc; oscv = Bc
+                            continue;
+                        }
                         if constexpr (C::FRB) {
                             // v = A*acc + Cc; oscv = Bc; the four sums of channel r live in s0[0][r], s0[0][8 + r], s1[0][r], s1[0][8 + r]
                             const float gp = (fmaf(oscv[r], d[e], v[r]) + fr_es * exf[e]) * (d[e] > 0.f ? 1.f : 0.2f);
@@ -769,7 +790,7 @@ int launch_stream(const ConvParams& p0, hipStream_t s) {
     const int njobs = p.B * nstrips * nseg;
     const int nwg = (njobs + C::TPW - 1) / C::TPW;
     const int jobs_per_xcd = (nwg + 7) / 8;                        // workgroups per XCD
-    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : (FL == FL_GEN_RGB ? "gen_rgb" : (FL == FL_DOT_IN ? "dot_in" : (FL == FL_DOT_FR ? "dot_fromrgb" : "enc_pool")))))));
+    const char* fl = FL == FL_GEN ? "gen" : (FL == FL_ENC ? "enc" : (FL == FL_ENC_STATS ? "enc_stats" : (FL == FL_DOT ? "dot" : (FL == FL_DOT_PREP ? "dot_prep" : (FL == FL_GEN_RGB ? "gen_rgb" : (FL == FL_DOT_IN ? "dot_in" : (FL == FL_DOT_FR ? "dot_fromrgb" : (FL == FL_DOT_INX ? "dot_inx" : "enc_pool"))))))));
     dge_note_kernel("conv_stream<bf16,%d,%d,%s>", CIN, COUT, fl);
     hipLaunchKernelGGL(kern, dim3((unsigned)(jobs_per_xcd * 8)), dim3(64 * C::TEAM * C::TPW), C::LDS_BYTES * C::TPW, s, p, nstrips, nseg, seg_rows, njobs, jobs_per_xcd);
     DGE_LAUNCH_CHECK("conv_stream");
@@ -781,6 +802,11 @@ int launch_flavour(const ConvParams& p, hipStream_t s) {
     if (p.in_coef && p.fr_out) {
         if constexpr (CIN == 16 && COUT == 16) return launch_stream<CIN, COUT, FL_DOT_FR>(p, s);
         dge_set_error("conv_stream: the FromRGB reduction epilogue is built for 16 -> 16 only");
+        return -1;
+    }
+    if (p.in_coef && !p.prep_stats) {
+        if constexpr (CIN == COUT && CIN >= 32) return launch_stream<CIN, COUT, FL_DOT_INX>(p, s);
+        dge_set_error("conv_stream: the block-input instance-norm backward epilogue is built for 32 -> 32 and 64 -> 64 only");
         return -1;
     }
     if (p.in_coef) {
@@ -834,7 +860,8 @@ bool dge_conv_stream_eligible(const ConvParams& p, int dtype, int ksize) {
     }
     if ((long)p.W * p.Cin * 2 >= (1L << 31) || (long)p.H * p.W * 64 * 2 >= (1L << 40)) return false;
     if (p.dot_src && !p.stats && !p.in_coef) return false;
-    if (p.in_coef && !p.fr_out && !(p.dot_src && p.prep_stats && !p.prep && !p.stats && ((p.Cin == 32 && p.Cout == 16) || (p.Cin == 64 && p.Cout == 32)))) return false;
+    if (p.in_coef && !p.fr_out && p.prep_stats && !(p.dot_src && !p.prep && !p.stats && ((p.Cin == 32 && p.Cout == 16) || (p.Cin == 64 && p.Cout == 32)))) return false;
+    if (p.in_coef && !p.fr_out && !p.prep_stats && !(p.dot_src && !p.prep && !p.stats && p.Cin == p.Cout && p.Cin >= 32 && p.H % 2 == 0 && p.W % 2 == 0)) return false;
     if (p.fr_out && !(p.in_coef && p.dot_src && p.fr_img4 && !p.prep && !p.stats && p.Cin == 16 && p.Cout == 16 && p.H % 2 == 0 && p.W % 2 == 0)) return false;
     if (p.prep && !(p.Cin == p.Cout && p.Cin >= 32)) return false;
     if (p.Cin == 64 && !p.dot_src && (p.stats || p.in_shift || (p.noise && p.noise_w_stride != 0))) return false;

@@ -396,8 +396,11 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
             d.fr_img4, d.in_bwd_extra, d.in_bwd_extra_scale = _f32(in_bwd["img4"]), _p(in_bwd.get("extra")), float(in_bwd.get("extra_scale", 1.0))
             in_bwd["fr"].buf = zeros((d.stats_slots, B, cout, 4), x.device)
             d.fr_out = _f32(in_bwd["fr"].buf)
-        else:
+        elif in_bwd.get("red") is not None:
             d.prep_stats = _f32(in_bwd["red"].alloc(d.stats_slots))
+        else:                                     # block-input form: no activation / reductions, pooled skip gradient added
+            d.prep_noise = None
+            d.in_bwd_extra, d.in_bwd_extra_scale = _p(in_bwd.get("extra")), float(in_bwd.get("extra_scale", 1.0))
     if rgb is not None:
         d.rgb_w, d.rgb_style, d.rgb_bias, d.rgb_out = _f32(rgb["w"]), _f32(rgb["style"]), _f32(rgb["bias"]), _f32(rgb["out"])
         d.rgb_wscale, d.rgb_skip_y = float(rgb["wscale"]), 1 if rgb.get("skip_y") else 0
@@ -438,6 +441,10 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
 def conv_in_bwd_supported(B, H, W, cin, cout, dtype):
     """True when a 3x3 data-gradient launch cin -> cout of this shape may carry the instance-norm backward epilogue (conv2d(in_bwd=...))"""
     return bool(lib().dge_conv_in_bwd_supported(int(B), int(H), int(W), int(cin), int(cout), 3, int(dtype)))
+
+
+def conv_in_bwd_x_supported(B, H, W, cin, cout, dtype):
+    return bool(lib().dge_conv_in_bwd_x_supported(int(B), int(H), int(W), int(cin), int(cout), 3, int(dtype)))
 
 
 def conv_in_bwd_fromrgb_supported(B, H, W, cin, cout, dtype):

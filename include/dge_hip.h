@@ -124,7 +124,9 @@ typedef struct dge_conv_desc {
      * = (A, Bc, Cc) from dge_in_bwd_coef_slots (its sums from dge_conv_wgrad_dots, i.e. before this launch); the launch stores
      * g_pre = (A*acc + Bc*x + Cc) * lrelu'(x) - what dge_in_bwd_fused(act = 1) made of the stored data gradient in a pass of its
      * own - and adds (sum g_pre, sum g_pre*noise) per (sample, channel) to prep_stats [stats_slots][B][Cout][2] (the bias /
-     * noise-weight gradients of the layer that produced x; noise = prep_noise [prep_noise_batch][H][W]).  stats / prep: none. */
+     * noise-weight gradients of the layer that produced x; noise = prep_noise [prep_noise_batch][H][W]).  stats / prep: none.
+     * Without prep_stats (where dge_conv_in_bwd_x_supported() says so: conv_1 of a block, Cin = Cout): the block-input form, y = A*acc +
+     * Bc*x + Cc + in_bwd_extra_scale * in_bwd_extra[parent pixel] (dge_in_bwd_fused(act = 0) with the pooled skip gradient, E.py:77-84). */
     const float* in_bwd_coef;
     /* The last data gradient of the encoder backward (conv_1 of block 0; where dge_conv_in_bwd_fromrgb_supported() says so), with
      * in_bwd_coef: x = dot_src is the FromRGB output (model/utils/net.py:231-240).  g_x = A*acc + Bc*x + Cc + in_bwd_extra_scale *
@@ -206,6 +208,7 @@ int dge_torgb(const void* x, const float* wrgb, const float* style, const float*
 int dge_conv_rgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int dge_conv_in_bwd_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int dge_conv_in_bwd_fromrgb_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
+int dge_conv_in_bwd_x_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 int dge_conv_pool_supported(int B, int H, int W, int Cin, int Cout, int ksize, int dtype);
 /* img[b][c][y][x] += up2(prev)[b][c][y][x]: the skip connection of SynthesisModule.forward :517-522 (UpsamplingLayer :603-615:
  * zero-insert, pad (2,1), 4x4 FIR == per-axis taps {.25,.75} / {.75,.25}) for an image whose toRGB term is already in img

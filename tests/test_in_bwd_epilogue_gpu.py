@@ -114,3 +114,48 @@ def test_fromrgb_reduction_in_the_last_data_gradient(B, H, W, with_extra):
     e_ref = ((ref.double() - want).abs() / absum).max().item()
     e_got = ((got.double() - want).abs() / absum).max().item()
     assert e_ref < 1e-4 and e_got < 1e-4, (e_ref, e_got)
+
+
+@pytest.mark.parametrize("B,H,W,cc,with_extra", [(8, 512, 512, 32, True), (8, 256, 256, 64, True), (3, 136, 200, 32, True), (5, 128, 160, 64, False)])
+def test_block_input_form(B, H, W, cc, with_extra):
+    """conv_1 of an encoder block (cc -> cc): data gradient + instance-norm backward of the block input + pooled skip gradient in one
+    launch, against data gradient with dot statistics followed by dge_in_bwd_fused(act = 0)"""
+    from dge_amd import ops
+    from dge_amd._lib import last_kernel
+    gen = torch.Generator(device=DEV).manual_seed(6200 + H + cc)
+    g = torch.randn(B, H, W, cc, device=DEV, generator=gen).to(torch.bfloat16)
+    x = (1.5 * torch.randn(B, H, W, cc, device=DEV, generator=gen) + 0.3).to(torch.bfloat16)
+    w = torch.randn(cc, cc, 3, 3, device=DEV, generator=gen) / math.sqrt(9 * cc)
+    sc = 0.5 + torch.rand(B, cc, device=DEV, generator=gen)
+    sh = 0.3 * torch.randn(B, cc, device=DEV, generator=gen)
+    musig = torch.cat([0.3 * torch.randn(B, cc, device=DEV, generator=gen), 0.5 + torch.rand(B, cc, device=DEV, generator=gen)], 1)
+    gms = torch.randn(B, 2 * cc, device=DEV, generator=gen)
+    extra = torch.randn(B, H // 2, W // 2, cc, device=DEV, generator=gen).to(torch.bfloat16) if with_extra else None
+    wp = ops.pack_conv_weight(w, ops.PACK_DGRAD, ops.BF16, 1.0)
+    N = H * W
+    dots0 = ops.SlotStats(B, cc, DEV)
+    gy = ops.conv2d(g, wp, cc, 3, stats=dots0, dot_src=x)
+    ref = ops.in_bwd(gy, x, (dots0, gms, musig, sc, sh, N), extra=extra, extra_pool=True, extra_scale=0.25)
+    assert ops.conv_in_bwd_x_supported(B, H, W, cc, cc, ops.BF16)
+    dw = ops.zeros((cc, cc, 3, 3), DEV)
+    dots = ops.SlotStats(B, cc, DEV)
+    assert ops.conv_wgrad_dots(g, x, dw, sc, sh, w, dots)
+    coef = ops.in_bwd_coef(dots, gms, musig, sc, sh, N)
+    got = ops.conv2d(g, wp, cc, 3, dot_src=x, in_bwd=dict(coef=coef, extra=extra, extra_scale=0.25))
+    assert last_kernel() == f"conv_stream<bf16,{cc},{cc},dot_inx>"
+    scale = (sc.abs().amax() * gy.float().abs().amax()).item()
+    assert ((got.float() - ref.float()).abs().max().item()) < 2.0 ** -7 * scale
+    # exact arithmetic on the same operands, two samples
+    wq = CR.bf16_round(w.cpu())
+    coef_c = coef.cpu().double()
+    for b in sorted({0, B - 1}):
+        gb = g[b:b + 1].float().permute(0, 3, 1, 2).cpu().double()
+        xb = x[b:b + 1].float().permute(0, 3, 1, 2).cpu().double()
+        gx = CR.conv_dgrad(gb, wq.double())
+        A, Bc, Cc = (coef_c[b, :, k][None, :, None, None] for k in range(3))
+        want = A * gx + Bc * xb + Cc
+        if with_extra:
+            want = want + 0.25 * extra[b:b + 1].float().permute(0, 3, 1, 2).cpu().double().repeat_interleave(2, 2).repeat_interleave(2, 3)
+        gotb = got[b:b + 1].float().permute(0, 3, 1, 2).cpu().double()
+        viol = ((gotb - want).abs() - 2.0 ** -8 * want.abs() - 2.0 ** -9 * (A.abs() * gx.abs()).amax()).max().item()
+        assert viol <= 0, (b, viol)

@@ -96,3 +96,34 @@ for _ in range(5):
 m = {k: statistics.median(v) for k, v in r.items()}
 print(f"B={B} conv_1 16->16 @{H}^2 (block 0): fromrgb {m['fromrgb']:.1f} -> {m['fromrgb4']:.1f} us (+img4) | dgrad {m['dg_old']:.1f} + in_bwd_fromrgb {m['in_bwd_fr']:.1f} = "
       f"{m['dg_old'] + m['in_bwd_fr']:.1f} -> fused {m['fused']:.1f} us", flush=True)
+
+
+# block-input form: conv_1 of blocks 1 / 2
+for B, H, cc in [(8, 512, 32), (8, 256, 64)]:
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    g = torch.randn(B, H, H, cc, device="cuda", generator=gen).bfloat16()
+    x = (1.5 * torch.randn(B, H, H, cc, device="cuda", generator=gen) + 0.3).bfloat16()
+    w = torch.randn(cc, cc, 3, 3, device="cuda", generator=gen) / math.sqrt(9 * cc)
+    sc = 0.5 + torch.rand(B, cc, device="cuda", generator=gen); sh = 0.3 * torch.randn(B, cc, device="cuda", generator=gen)
+    musig = torch.cat([0.3 * torch.randn(B, cc, device="cuda", generator=gen), 0.5 + torch.rand(B, cc, device="cuda", generator=gen)], 1)
+    gms = torch.randn(B, 2 * cc, device="cuda", generator=gen)
+    extra = torch.randn(B, H // 2, H // 2, cc, device="cuda", generator=gen).bfloat16()
+    wp = ops.pack_conv_weight(w, ops.PACK_DGRAD, ops.BF16, 1.0)
+    N = H * H
+    d0 = ops.SlotStats(B, cc, "cuda")
+    gy = ops.conv2d(g, wp, cc, 3, stats=d0, dot_src=x)
+    dw = ops.zeros((cc, cc, 3, 3), "cuda")
+    dn = ops.SlotStats(B, cc, "cuda"); ops.conv_wgrad_dots(g, x, dw, sc, sh, w, dn)
+    fs = dict(
+        dg_old=lambda: ops.conv2d(g, wp, cc, 3, stats=ops.SlotStats(B, cc, "cuda"), dot_src=x),
+        in_bwd=lambda: ops.in_bwd(gy, x, (d0, gms, musig, sc, sh, N), extra=extra, extra_pool=True, extra_scale=0.25),
+        fused=lambda: ops.conv2d(g, wp, cc, 3, dot_src=x, in_bwd=dict(coef=ops.in_bwd_coef(dn, gms, musig, sc, sh, N), extra=extra, extra_scale=0.25)))
+    for f in fs.values():
+        for _ in range(3):
+            f()
+    r = {k: [] for k in fs}
+    for _ in range(5):
+        for k, f in fs.items():
+            r[k].append(timed(f))
+    m = {k: statistics.median(v) for k, v in r.items()}
+    print(f"B={B} conv_1 {cc}->{cc} @{H}^2 (block input): dgrad {m['dg_old']:.1f} + in_bwd {m['in_bwd']:.1f} = {m['dg_old'] + m['in_bwd']:.1f} -> fused {m['fused']:.1f} us", flush=True)
