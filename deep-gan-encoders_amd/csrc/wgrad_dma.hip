@@ -410,9 +410,20 @@ int dge_wgrad_dma_try(const void* g, const void* x, const float* sc, const float
     // more workgroups than four resident sets (512 -> 512 @ 32^2: 131 us here against 72 us on conv_wgrad_tr_kernel)
     if (tps < 16 || noi * B > 1024) return 1;
     const bool g32 = cout <= 16, x32 = cin <= 16;
+    {   // tuning builds (tools/perf_wgrad.py): alternative tile heights / ring depths for the 16- / 32-channel layers
+        static const int cfg = getenv("DGE_WGRAD_CFG") ? atoi(getenv("DGE_WGRAD_CFG")) : 0;
+#define WTRY(...) return launch<WCfg<__VA_ARGS__>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s)
+        if (cfg == 1) { if (g32 && x32) WTRY(8, 32, 32, 4, 5); if (!g32 && x32) WTRY(8, 64, 32, 4, 4); if (!g32 && !x32) WTRY(8, 64, 64, 4, 4); }
+        if (cfg == 2) { if (g32 && x32) WTRY(16, 32, 32, 4, 4); if (!g32 && x32) WTRY(16, 64, 32, 4, 3); if (!g32 && !x32) WTRY(16, 64, 64, 4, 3); }
+        if (cfg == 3) { if (g32 && x32) WTRY(8, 32, 32, 4, 3); if (!g32 && x32) WTRY(8, 64, 32, 4, 3); if (!g32 && !x32) WTRY(8, 64, 64, 4, 3); }
+#undef WTRY
+    }
     // ring depth: the deepest that leaves two workgroups per CU
     if (g32 && x32) return launch<WCfg<16, 32, 32, 4, 3>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
     if (!g32 && x32) return launch<WCfg<16, 64, 32, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
     if (g32 && !x32) return launch<WCfg<16, 32, 64, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
+    // 32 input channels (half-empty 64-byte x pixels): 8-row tiles with a 3-deep ring (measured at 512^2, batch 8: 32 -> 32 98 -> 77 us,
+    // 32 -> 64 113 -> 108; 64 -> 64 @256^2 does not gain: 61 -> 63.5)
+    if (cin <= 32 && cout <= 64) return launch<WCfg<8, 64, 64, 4, 3>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
     return launch<WCfg<16, 64, 64, 4, 2>>(g, x, sc, sh, dw, B, H, W, cout, cin, wdot, dots, dots_slots, s);
 }
