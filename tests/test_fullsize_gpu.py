@@ -462,7 +462,7 @@ WGRADS = [
     # (cin, cout, R, B, k, affine, kernel)
     (16, 16, 1024, 8, 3, True, "wgrad_dma<16,32,32,3>"),           # encoder block 0 conv_1
     (16, 32, 1024, 8, 3, True, "wgrad_dma<16,64,32,2>"),           # block 0 conv_2
-    (32, 32, 512, 8, 3, True, "wgrad_dma<16,64,64,2>"),
+    (32, 32, 512, 8, 3, True, "wgrad_dma<8,64,64,3>"),
     (128, 128, 128, 8, 3, True, "wgrad_dma<16,64,64,2>"),          # block 3 conv_1 (16 (o, i) tiles share every pixel tile)
     (256, 512, 64, 8, 3, True, "wgrad_dma<16,64,64,2>"),           # block 4 conv_2 (one workgroup per sample and (o, i) tile)
     (512, 512, 16, 8, 3, True, "conv_wgrad_tr<3,16>"),
