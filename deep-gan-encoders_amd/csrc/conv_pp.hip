@@ -799,6 +799,7 @@ extern "C" int dge_conv_pp(const dge_conv_pp_desc* d, hipStream_t s) {
     p.prep = 0; p.mask_relu = 0; p.prep_noise_bstride = 0; p.prep_gain = 1.f; p.prep_noise = nullptr; p.prep_ns = nullptr;
     if (d->dgrad) {
         DGE_CHECK(!d->bias && !d->noise && d->act == DGE_ACT_NONE, "conv_pp: the data-gradient form has no bias / noise / activation");
+        DGE_CHECK(!((d->stats || d->prep) && dge_get_deterministic()), "conv_pp: the statistics of the data-gradient form are f32 atomics: not offered in deterministic mode (run dge_conv2d)");
         DGE_CHECK(!d->prep || (d->dot_src && d->prep_stats && d->prep_gain > 0.f), "conv_pp: prep needs dot_src, prep_stats and a positive gain");
         DGE_CHECK(!d->mask_relu || (d->dot_src && !d->prep), "conv_pp: mask_relu needs dot_src and excludes prep");
         DGE_CHECK(!d->stats || d->dot_src, "conv_pp: statistics are (sum a*dot_src, sum a): dot_src missing");

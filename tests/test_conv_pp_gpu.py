@@ -85,6 +85,8 @@ def _dg_case(B, R, cof, cif, seed, up=False, with_add=False, mode="prep", sample
     from dge_amd import ops
     from dge_amd._lib import last_kernel
     from oracle import elem_ref as ER
+    if ops.is_deterministic() and mode != "mask":
+        pytest.skip("the statistics of conv_pp's data-gradient form are f32 atomics: refused in deterministic mode")
     H, W = R, (Rw or R)
     g = torch.Generator(device=DEV).manual_seed(seed)
     gain = math.sqrt(2.0)
