@@ -40,6 +40,11 @@ class ConvPPDesc(C.Structure):
     ]
 
 
+class DenseLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("I", C.c_int), ("O", C.c_int), ("wscale", C.c_float), ("bscale", C.c_float),
+                ("add", C.c_float), ("act", C.c_int), ("gain", C.c_float)]
+
+
 class S2GradEntry(C.Structure):
     _fields_ = [("P", C.c_void_p), ("st", C.c_void_p), ("d", C.c_void_p), ("s", C.c_void_p), ("bias", C.c_void_p), ("wsq", C.c_void_p),
                 ("gs", C.c_void_p), ("wstyle", C.c_void_p),
@@ -166,6 +171,7 @@ SIGNATURES = {
     "dge_heads_fwd": [_P, _I, _P, _P, _I, _I, _I, _P],
     "dge_conv_pp_supported": [_I, _I, _I, _I, _I, _I],
     "dge_pack_conv_pp": [_P, _P, _I, _I, _F, _P, _P, _F, _I, _I, _P],
+    "dge_dense_chain": [_P, _I, C.POINTER(DenseLayer), _I, _P, _I, _I, _I, _F, _P],
     "dge_conv_wgrad_dots": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_pack_conv_pp_rows": [_P, _I, _P, _I, _I, _P, _I, _P, _F, _I, _I, _P],
     "dge_conv_pp": [C.POINTER(ConvPPDesc), _P],

@@ -235,6 +235,52 @@ __global__ void linear_kernel(const float* __restrict__ x, int ldx, const float*
     }
 }
 
+// A chain of dense layers in ONE launch (the mapping network: pixel norm + 8 DenseBlocks of 512, :199-278 / :925-996; 16 launches of
+// ~5.6 us per generator forward before).  One workgroup per sample, 16 waves; the activations ping-pong through LDS; wave v computes
+// outputs v, v + 16, ... with exactly linear_kernel's arithmetic (lane-strided partial sums, wave_sum, scale / bias / act / gain), so
+// the result is bit-identical to the per-layer launches.
+struct DenseChain { const float* w[8]; const float* bias[8]; int I[8], O[8], act[8]; float wscale[8], bscale[8], add[8], gain[8]; int n; };
+__global__ __launch_bounds__(1024) void dense_chain_kernel(const float* __restrict__ x, int ldx, DenseChain c, float* __restrict__ y, int ldy,
+                                                           int pixelnorm, float eps) {
+    __shared__ float buf[2][1024];
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int I0 = c.I[0];
+    if (pixelnorm) {                               // dge_pixelnorm's arithmetic (one wave: lane-strided sum of squares, wave_sum)
+        if (wave == 0) {
+            float s = 0.f;
+            for (int i = lane; i < I0; i += 64) { const float v = x[(size_t)b * ldx + i]; s += v * v; }
+            s = wave_sum(s);
+            const float r = rsqrtf(s / I0 + eps);
+            for (int i = lane; i < I0; i += 64) buf[0][i] = x[(size_t)b * ldx + i] * r;
+        }
+    } else {
+        for (int i = tid; i < I0; i += 1024) buf[0][i] = x[(size_t)b * ldx + i];
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int l = 0; l < c.n; l++) {
+        const int I = c.I[l], O = c.O[l];
+        const float* __restrict__ W = c.w[l];
+        const float* __restrict__ bias = c.bias[l];
+        const bool last = l == c.n - 1;
+        for (int o = wave; o < O; o += 16) {
+            const float* wr = W + (size_t)o * I;
+            float s = 0.f;
+            for (int i = lane; i < I; i += 64) s += buf[cur][i] * wr[i];
+            s = wave_sum(s);
+            if (lane == 0) {
+                float v = s * c.wscale[l] + (bias ? bias[o] * c.bscale[l] : 0.f) + c.add[l];
+                if (c.act[l] == LIN_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+                else if (c.act[l] == LIN_ACT_RELU) v = v > 0.f ? v : 0.f;
+                v *= c.gain[l];
+                if (last) y[(size_t)b * ldy + o] = v; else buf[cur ^ 1][o] = v;
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // All style vectors of a synthesis pass in ONE launch (17 modulated convs + 9 toRGB at 1024^2 = 26 dense layers,
 // :858-864 / :990-996): row r of the concatenated weight matrix belongs to one layer and reads that layer's latent row
 // x[b, row_xoff[r] .. +K); results are written per layer as contiguous [B, C_layer] blocks (the conv prologue indexes
@@ -563,6 +609,24 @@ extern "C" int dge_linear(const float* x, int ldx, const float* w, const float* 
 extern "C" int dge_pixelnorm(const float* x, float* y, int B, int D, float eps, hipStream_t s) {
     hipLaunchKernelGGL(pixelnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x, y, B, D, eps);
     DGE_LAUNCH_CHECK("pixelnorm");
+    return 0;
+}
+
+extern "C" int dge_dense_chain(const float* x, int ldx, const dge_dense_layer* layers, int n, float* y, int ldy, int B, int pixelnorm,
+                               float eps, hipStream_t s) {
+    DGE_CHECK(x && y && layers && n >= 1 && n <= 8 && B >= 1, "dense_chain: 1 .. 8 layers");
+    DenseChain c;
+    c.n = n;
+    for (int l = 0; l < n; l++) {
+        const dge_dense_layer& L = layers[l];
+        DGE_CHECK(L.w && L.I >= 1 && L.I <= 1024 && L.O >= 1 && L.O <= 1024 && (l == 0 || L.I == layers[l - 1].O), "dense_chain: layer %d: widths up to 1024, I = previous O", l);
+        DGE_CHECK(L.act == DGE_ACT_NONE || L.act == DGE_ACT_LRELU || L.act == DGE_ACT_RELU, "dense_chain: activation %d", L.act);
+        c.w[l] = L.w; c.bias[l] = L.bias; c.I[l] = L.I; c.O[l] = L.O;
+        c.act[l] = L.act == DGE_ACT_LRELU ? LIN_ACT_LRELU : (L.act == DGE_ACT_RELU ? LIN_ACT_RELU : LIN_ACT_NONE);
+        c.wscale[l] = L.wscale; c.bscale[l] = L.bscale; c.add[l] = L.add; c.gain[l] = L.gain;
+    }
+    hipLaunchKernelGGL(dense_chain_kernel, dim3(B), dim3(1024), 0, s, x, ldx, c, y, ldy, pixelnorm ? 1 : 0, eps);
+    DGE_LAUNCH_CHECK("dense_chain");
     return 0;
 }
 

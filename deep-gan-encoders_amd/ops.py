@@ -291,6 +291,24 @@ def linear(x, w, bias=None, wscale=1.0, bscale=1.0, add=0.0, act=ACT_NONE, gain=
     return out
 
 
+def dense_chain(x, layers, pixelnorm=False, eps=1e-8):
+    """x [B, I] f32 through a chain of up to 8 dense layers in one launch (dge_dense_chain; bit-identical to the per-layer linear()
+    calls).  layers: objects with weight [O, I], bias, wscale, bscale, additional_bias, act, gain (DenseBlock)."""
+    from ._lib import DenseLayer
+    B = x.shape[0]
+    arr = (DenseLayer * len(layers))()
+    for e, L in zip(arr, layers):
+        e.w, e.bias = _p(L.weight.detach()), _p(L.bias.detach())
+        e.O, e.I = L.weight.shape
+        e.wscale, e.bscale, e.add, e.act, e.gain = float(L.wscale), float(L.bscale), float(L.additional_bias), int(L.act), float(L.gain)
+    y = torch.empty((B, layers[-1].weight.shape[0]), dtype=torch.float32, device=x.device)
+    if not x.is_cuda or x.stride(1) != 1:
+        raise DgeError("dense_chain: x must be a CUDA tensor with unit inner stride")
+    check(lib().dge_dense_chain(_f32(x), x.stride(0), arr, len(layers), _p(y), y.stride(0), B, 1 if pixelnorm else 0, float(eps), _stream()),
+          "dge_dense_chain")
+    return y
+
+
 def pixelnorm(x, eps=1e-8):
     y = torch.empty_like(x)
     check(lib().dge_pixelnorm(_f32(x), _p(y), x.shape[0], x.shape[1], eps, _stream()), "dge_pixelnorm")

@@ -196,6 +196,12 @@ int dge_weight_sumsq(const float* w_oihw, float* wsq, int cout, int cin, int ksi
 int dge_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int I, int O,
                float wscale, float bscale, float add, int act, float gain, int square_input, dge_stream_t stream);
 int dge_pixelnorm(const float* x, float* y, int B, int D, float eps, dge_stream_t stream);          /* :550-553 */
+/* A chain of up to 8 dense layers (dge_linear's arithmetic, bit for bit) in one launch, optionally behind dge_pixelnorm: the mapping
+ * network z -> w (MappingModule.forward :262-278: pixel norm + 8 DenseBlocks).  Layer l: y = act((x W^T)*wscale + bias*bscale + add)*gain,
+ * w [O][I] f32, I of layer l = O of layer l - 1, widths <= 1024.  x [B] rows of stride ldx, y [B] rows of stride ldy. */
+typedef struct dge_dense_layer { const float* w; const float* bias; int I, O; float wscale, bscale, add; int act; float gain; } dge_dense_layer;
+int dge_dense_chain(const float* x, int ldx, const dge_dense_layer* layers, int n, float* y, int ldy, int B, int pixelnorm, float eps,
+                    dge_stream_t stream);
 int dge_truncation(const float* w, const float* w_avg, float* wp, int B, int L, int D, float psi, int layers,
                    int w_is_wp, dge_stream_t stream);                                                /* :311-333 */
 

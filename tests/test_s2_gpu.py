@@ -169,3 +169,26 @@ def test_grouped_weight_pack_equals_the_single_tensor_pack():
     assert scratch2 is scratch
     for w, a, (_, _, _, m, dt) in zip(ws, outs, cases):
         assert torch.equal(a.view(torch.uint8), ops.pack_conv_weight(w, m, dt, 0.7).view(torch.uint8))
+
+
+@pytest.mark.gpu
+def test_dense_chain_is_bit_identical_to_the_per_layer_launches():
+    """dge_dense_chain (the mapping network's 8 DenseBlocks in one launch, stylegan2_generator.py:262-278) against dge_pixelnorm +
+    8 x dge_linear: same arithmetic, same bits"""
+    import torch
+    from dge_amd import ops
+    from dge_amd.stylegan2_generator import MappingModule
+    torch.manual_seed(3)
+    M = MappingModule().cuda()
+    with torch.no_grad():
+        for p in M.parameters():
+            p.copy_(torch.randn_like(p) * (1.0 if p.ndim == 2 else 0.1))
+    z = torch.randn(5, 512, device="cuda")
+    zn = ops.pixelnorm(z)
+    w = zn
+    for i in range(M.num_layers):
+        w = getattr(M, f"dense{i}")(w)
+    got = M(z)["w"]
+    assert torch.equal(got, w)
+    got2 = ops.dense_chain(z, [getattr(M, f"dense{i}") for i in range(M.num_layers)], pixelnorm=True)
+    assert torch.equal(got2, w)
