@@ -42,6 +42,10 @@ class _Lin(nn.Module):
         self.model.add_module("1", conv)
 
 
+import os as _os
+_PP_LPIPS = not _os.environ.get("DGE_NO_PP_LPIPS")
+
+
 class LPIPS(nn.Module):
     def __init__(self, net="vgg", compute_dtype="bf16"):
         super().__init__()
@@ -176,7 +180,7 @@ class LPIPS(nn.Module):
                 continue
             conv = self.convs[ci]
             Bc, Hc, Wc, Cc = cur.shape
-            if Cc >= 64 and ops.conv_pp_supported(Bc, Hc, Wc, Cc, item[1], dt):
+            if Cc >= 64 and _PP_LPIPS and ops.conv_pp_supported(Bc, Hc, Wc, Cc, item[1], dt):
                 # the MFMA-bound VGG layers (>= 128 output channels on a grid that fills the chip): ping-pong implicit GEMM
                 cur = ops.conv_pp(cur, self._packed_pp(ci), item[1], bias=conv.bias.detach(), act=ops.ACT_RELU)
             else:
