@@ -66,7 +66,10 @@ static void env_load() {
     g_env.up_dbg = env_int("DGE_UP_DBG", 0);
     g_env_loaded = true;
 }
-const DgeEnv& dge_env() { if (!g_env_loaded) env_load(); return g_env; }
+// (first use from several host threads - autograd's backward thread next to the caller's - loads the switches exactly once)
+#include <mutex>
+static std::once_flag g_env_once;
+const DgeEnv& dge_env() { std::call_once(g_env_once, [] { if (!g_env_loaded) env_load(); }); return g_env; }
 extern "C" void dge_env_reload(void) { env_load(); }
 
 extern "C" int dge_conv2d(const dge_conv_desc* d, hipStream_t s) {
