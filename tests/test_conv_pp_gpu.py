@@ -171,7 +171,7 @@ def test_synthesis_data_gradients_fullsize(cof, cif, R, B, up, with_add):
 
 
 @pytest.mark.parametrize("B,H,W,cof,cif,up,mode,with_add", [(40, 50, 70, 64, 128, False, "prep", True), (12, 33, 97, 96, 256, False, "stats", True),
-                                                           (48, 44, 44, 128, 128, False, "mask", False), (24, 70, 50, 32, 128, True, "prep", False),
+                                                           (48, 44, 44, 128, 128, False, "mask", False), (40, 50, 70, 96, 128, False, "mask", True), (24, 70, 50, 32, 128, True, "prep", False),
                                                            (16, 129, 63, 160, 128, False, "stats", False)])
 def test_data_gradient_ragged_and_modes(B, H, W, cof, cif, up, mode, with_add):
     """partial tiles in y and x, 2 - 5 K chunks (4 x 1 under space-to-depth), the three epilogue flavours, with and without addend"""
