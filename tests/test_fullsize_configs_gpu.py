@@ -242,3 +242,31 @@ def test_encoder_blur1024_fullsize():
     #  their statistics differs from run to run; the f32 run of the same formulas is in tests/test_encvar.py)
     c = _enc_case(E, P, img, noises, lambda Pr, im, nz: O.enc_blur_forward(Pr, im, nz, fused), B, "E_Blur-1024", 8e-2, 0.75)
     c.check(BLUR1024_KERNELS)
+
+
+def test_benchmarked_step_runs_on_the_round4_kernel_forms():
+    """config 3 as bench.py runs it (StyleGAN2-1024, E.BE startf 16, bf16, batch 8): the kernels this round put on the path are the ones
+    that run - asserted by name (dge_last_kernel) over one complete two-phase step.  Values: tests/test_step_gpu.py (same step
+    against the CPU oracle) and the per-launch suites."""
+    from dge_amd.e_align import EAlignStep, build_models
+    dev = torch.device("cuda", 0)
+    G, E, LP = build_models(1024, 16, "bf16", dev, seed=0)
+    G.train()
+    st = EAlignStep(G, E, LP, batch_size=8)
+    st.step(0)                                   # (fills the pack caches; the first LPIPS call stays on one stream)
+    Census.NAMES = Census.NAMES + ("conv_wgrad_dots",)
+    try:
+        with Census() as c:
+            st.step(1)
+    finally:
+        Census.NAMES = Census.NAMES[:-1]
+    torch.cuda.synchronize()
+    want = {"conv_pp<bf16,16,32,128>",                                                   # generator layers 8 / 10 / 12, LPIPS conv2_x / conv3_x
+            "conv_pp<bf16,16,32,128>+dg+prep", "conv_pp<bf16,16,32,128>+dg+s2d+prep",    # synthesis backward: layers 12 / 10 / 8, 13
+            "conv_pp<bf16,16,32,128>+dg+t2d+prep",                                       # ... 11 / 9 in phase form
+            "conv_stream<bf16,32,16,dot_in>", "conv_stream<bf16,64,32,dot_in>",          # encoder backward: conv_2 of blocks 0 / 1
+            "conv_stream<bf16,32,32,dot_inx>", "conv_stream<bf16,64,64,dot_inx>",        # conv_1 of blocks 1 / 2
+            "conv_stream<bf16,16,16,dot_fromrgb>"}                                       # conv_1 of block 0 + FromRGB gradients
+    assert want <= c.seen, sorted(want - c.seen)
+    gone = {"conv_stream<bf16,16,16,dot>", "conv_stream<bf16,32,32,dot>", "conv_stream<bf16,32,16,dot>", "conv_stream<bf16,64,32,dot>"}
+    assert not (gone & c.seen), sorted(gone & c.seen)
