@@ -12,6 +12,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _not_in_deterministic_mode():
+    """the epilogue forms reduce with f32 atomics: refused in deterministic mode (the separate dge_in_bwd passes run there)"""
+    from dge_amd import ops
+    if ops.is_deterministic():
+        pytest.skip("instance-norm backward epilogues are not offered in deterministic mode")
+
+
 @pytest.mark.parametrize("B,H,W,c2,cc", [(8, 1024, 1024, 32, 16), (8, 512, 512, 64, 32), (3, 136, 200, 32, 16), (5, 128, 160, 64, 32)])
 def test_fused_against_separate_passes_and_oracle(B, H, W, c2, cc):
     """conv_2 of an encoder block: cc -> c2 channels; its data gradient c2 -> cc followed by the backward of instance norm 2 and of
