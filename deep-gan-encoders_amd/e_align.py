@@ -381,7 +381,7 @@ class EAlignStep:
         # the re-pack of the encoder's conv weights (stale since the last optimizer step) beside the generator's first pass:
         # an HBM-bound copy next to small-grid low-resolution layers; joined in front of the encoder
         pack_side = None
-        if (self.dev.type == "cuda" and _SIDE_STREAMS and not ops.is_deterministic() and E.__dict__.get("_pack_cache")
+        if (self.dev.type == "cuda" and _SIDE_STREAMS and _PACK_STREAM and not ops.is_deterministic() and E.__dict__.get("_pack_cache")
                 and (B * imgs_px(G) >= (4 << 20) or torch.cuda.is_current_stream_capturing())):
             from .autograd_enc import refresh_packs
             if getattr(self, "_pack_stream", None) is None:
@@ -430,6 +430,9 @@ class EAlignStep:
 
 
 _SIDE_STREAMS = os.environ.get("DGE_SIDE_STREAMS", "1") != "0"
+# the early weight re-pack beside the generator's first pass: - 0.13 ms in round 3, + 0.08 ms against this round's kernels (three
+# same-box pairs, 24.08 vs 24.17 ms): opt-in
+_PACK_STREAM = os.environ.get("DGE_PACK_STREAM", "0") == "1"
 
 
 def imgs_px(G):
