@@ -36,6 +36,10 @@ def _dt(compute_dtype):
     raise ValueError(f"compute_dtype must be 'bf16' or 'f32', got {compute_dtype!r}")
 
 
+import os as _os
+_PP_GEN = not _os.environ.get("DGE_NO_PP_GEN")
+
+
 class DenseBlock(nn.Module):
     """Equalised-lr dense layer (reference :925-996)."""
 
@@ -189,7 +193,7 @@ class ModulateConvBlock(nn.Module):
             return ops.upconv_fir(x, wu, self.out_c, in_scale=s, out_scale=d, bias=self.bias, bias_scale=self.bscale,
                                   noise=noise, noise_w=nw, act=self.act, gain=self.gain)
         B, H, W, _ = x.shape
-        if (rgb is None and not self.up and d is not None and s is not None and self.ksize == 3
+        if (rgb is None and not self.up and d is not None and s is not None and self.ksize == 3 and _PP_GEN
                 and ops.conv_pp_supported(B, H, W, self.in_c, self.out_c, dt)):
             # MFMA-bound layers (>= 128 channels at 64^2 .. 256^2): the reference's fused modulation (:858-875) - style, demodulation
             # and gain folded into one weight image per sample - feeding the ping-pong implicit GEMM (csrc/conv_pp.hip)
