@@ -731,7 +731,8 @@ extern "C" int dge_dbg_pp_prof(long long* host_out) {
 }
 
 extern "C" int dge_conv_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype) {
-    if (dtype != DGE_BF16 || getenv("DGE_NO_PP")) return 0;
+    static const bool off = getenv("DGE_NO_PP") != nullptr;          // read once: this is called several times per layer
+    if (dtype != DGE_BF16 || off) return 0;
     if (Cin % 32 != 0 || Cout % 128 != 0 || Cin < 64) return 0;
     if ((long long)H * W * Cin * 2 >= (1ll << 31)) return 0;
     // one workgroup per CU and no overlap between tiles: the grid must fill the chip
@@ -816,7 +817,17 @@ extern "C" int dge_conv_pp(const dge_conv_pp_desc* d, hipStream_t s) {
     const long tiles = (long)p.tiles_x * p.tiles_y * p.B * p.ntn;
     // one workgroup per CU (160 KB of LDS each), 32 per XCD; each walks its share of its XCD's tile range
     int cus = 256;
-    { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) cus = pr.multiProcessorCount / 8 * 8; }
+    {   // CU count per device, queried once (hipGetDeviceProperties fills a multi-KB struct: not on the launch path)
+        static int cu_of_dev[64] = {0};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (cu_of_dev[dev] == 0) {
+                int n = 0;
+                cu_of_dev[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n / 8 * 8 : 256;
+            }
+            cus = cu_of_dev[dev];
+        }
+    }
     const long grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus;
     dge_note_kernel(d->in_t2d ? "conv_pp<bf16,16,32,128>+dg+t2d+prep" : d->dgrad ? (d->in_s2d ? (d->prep ? "conv_pp<bf16,16,32,128>+dg+s2d+prep" : "conv_pp<bf16,16,32,128>+dg+s2d")
                                           : (d->prep ? "conv_pp<bf16,16,32,128>+dg+prep" : (d->mask_relu ? "conv_pp<bf16,16,32,128>+dg+mask" : "conv_pp<bf16,16,32,128>+dg")))

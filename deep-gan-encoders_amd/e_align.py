@@ -267,13 +267,15 @@ class EAlignStep:
         return None if self.exact_ddp else torch.full((1,), 1.0 / self.world, device=self.dev)
 
     # ------------------------------------------------------------------ hipGraph replay of the iteration
-    def capture(self, warmup=2):
+    def capture(self, warmup=2, start=0):
         """Captures one iteration into a hipGraph (single-GPU runs; the ≈1300 launches of a step cost ≈18 ms of host time,
         which bounds the step at the reference's default batch of 2).  Host-side decisions of an iteration become device
         inputs: z (static buffer), the style-mixing mask (StyleGAN2 train mode, same np.random draw order as the
         reference) and Adam's sqrt(1 - beta2^t) factors.  Encoder / StyleGAN1 noise comes from torch's graph-safe
         device generator.  `warmup` real iterations run inside this call (plus one eager iteration in front of them in the legacy
-        stage-1 form); the captured iteration itself is only recorded."""
+        stage-1 form); the captured iteration itself is only recorded.  The real iterations are numbered `start`, `start` + 1, ...
+        (the number seeds z and the mixing mask, training_utils.py:46-52); `self._g_iter` is the number of the NEXT iteration when
+        this returns - a training loop continues there (train() below) instead of repeating the warm-up's iterations."""
         if self.dist_on:
             raise RuntimeError("hipGraph capture is offered for single-process runs only (collectives are not captured)")
         # Capturing after EAGER steps of the same encoder used to end in a segmentation fault inside capture_end (round 2:
@@ -299,10 +301,11 @@ class EAlignStep:
         # zero_grad form (tick() + step()), where the tick is skipped while no parameter has state yet: one eager iteration
         # first gives every parameter its state, so that every captured / replayed iteration makes the same number of calls
         calls = 2 if (self.stage == 2 or not self.zero_grad_to_none) else 1
+        self._g_iter = int(start)
         if self.stage == 1 and not self.zero_grad_to_none and not any(len(st) for st in self.opt.state.values()):
-            self.step(0)
+            self.step(self._g_iter)
+            self._g_iter += 1
         self.opt.graph_begin(calls, self.dev)
-        self._g_iter = 0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -605,9 +608,15 @@ def train(tensor_writer=None, args=None):
     mode = getattr(args, "launch", "auto")
     use_graph = mode == "graph" or (mode == "auto" and not st.dist_on and args.batch_size <= 2 and args.mtype != 4
                                     and not getattr(args, "deterministic", False))
+    first = 0
     if use_graph:
-        st.capture()
-    for iteration in range(args.iterations):
+        r = st.capture()
+        first = st._g_iter           # capture() ran iterations 0 .. first - 1 for real (its warm-up): the loop continues behind them,
+        # so that `--launch graph` and `--launch eager` make the same number of encoder updates on the same z / mask sequence
+        print("ep_0_iter_0 .. %d ran inside the graph capture (warm-up)" % (first - 1))
+        if getattr(args, "experiment_dir", None):
+            torch.save(E.state_dict(), "%s/E_model_ep0_iter0.pth" % args.experiment_dir)       # the reference's iteration-0 dump
+    for iteration in range(first, args.iterations):
         r = st.replay(iteration) if use_graph else st.step(iteration)
         if iteration % 100 == 0:
             print("ep_%d_iter_%d" % (iteration // 30000, iteration % 30000), "loss_tsa", float(r["loss_tsa"]),

@@ -81,6 +81,16 @@ class EmbedStep:
         self._noise_it += 1
         ops.noise_seed(self._noise_base + self._noise_it)
 
+    def set_image(self, imgs1):
+        """Makes `imgs1` the image group the captured iteration works on (the graph reads the static buffer capture() cloned
+        the FIRST group into; every later group has to be copied there before its replays)."""
+        if getattr(self, "_graph", None) is None:
+            raise RuntimeError("EmbedStep.set_image: no captured iteration (call capture() first)")
+        if tuple(imgs1.shape) != tuple(self._g_imgs1.shape) or imgs1.dtype != self._g_imgs1.dtype or imgs1.device != self._g_imgs1.device:
+            raise ValueError(f"EmbedStep.set_image: the captured iteration works on {tuple(self._g_imgs1.shape)} {self._g_imgs1.dtype} on "
+                             f"{self._g_imgs1.device}, got {tuple(imgs1.shape)} {imgs1.dtype} on {imgs1.device}; re-capture for a new geometry")
+        self._g_imgs1.copy_(imgs1.detach())
+
     def replay(self):
         self._graph_inputs()
         self._graph.replay()
@@ -123,6 +133,8 @@ def invert(st, imgs1, iterations=1500, launch="graph"):
             warm = 1
             st.capture(imgs1, warmup=warm)          # the warm-up iteration is a real iteration of the loop
             done = warm
+        else:
+            st.set_image(imgs1)                     # later image groups: into the static input of the captured iteration
         run = st.replay
     else:
         run = lambda: st.step(imgs1)

@@ -38,6 +38,7 @@ def _dt(compute_dtype):
 
 import os as _os
 _PP_GEN = not _os.environ.get("DGE_NO_PP_GEN")
+_DENSE_CHAIN = _os.environ.get("DGE_DENSE_CHAIN") == "1"
 
 
 class DenseBlock(nn.Module):
@@ -80,8 +81,11 @@ class MappingModule(nn.Module):
                              f"equals to {self.input_space_dim}!\nBut `{z.shape}` is received!")
         zn = ops.pixelnorm(z.float().contiguous())
         layers = [getattr(self, f"dense{i}") for i in range(self.num_layers)]
-        if self.num_layers <= 8 and all(max(L.weight.shape) <= 1024 for L in layers):
-            w = ops.dense_chain(zn, layers)           # the 8 dense layers in one launch, bit-identical to the per-layer calls
+        if _DENSE_CHAIN and self.num_layers <= 8 and all(max(L.weight.shape) <= 1024 for L in layers):
+            # the 8 dense layers in one launch, bit-identical to the per-layer calls.  OFF by default: one workgroup per sample
+            # leaves a 256-CU part idle behind a latency-bound chain (round 4: +0.8 ms per mapping pass at batch 8 against
+            # ~45 us for the eight chip-wide launches it replaces); DGE_DENSE_CHAIN=1 turns it on for launch-bound hosts at batch 1
+            w = ops.dense_chain(zn, layers)
         else:
             w = zn
             for L in layers:

@@ -480,7 +480,7 @@ typedef struct dge_conv_pp_desc {
     const void* x;            /* [B,H,W,Cin] bf16 */
     const void* w_pp;         /* dge_pack_conv_pp */
     void* y;                  /* [B,H,W,Cout] bf16 */
-    long long w_bstride;      /* elements between the samples' weight copies (9*Cin*Cout), 0 = one shared copy */
+    long long w_bstride;      /* bf16 ELEMENTS between the samples' weight copies (9*Cin*Cout; the image is always bf16), 0 = one shared copy */
     const float* out_scale;   /* optional [B,Cout] */
     const float* bias;        /* optional [Cout] */
     const float* noise;       /* optional [noise_batch,H,W] */

@@ -134,3 +134,40 @@ def test_graph_replay_equals_eager_iterations():
     for (k, pa), (_, pb) in zip(a.E.named_parameters(), b.E.named_parameters()):
         # 8 optimiser steps of at most lr * 10 each (sign-like): parameters may differ by a few such steps
         assert float((pb.detach() - pa.detach()).abs().max()) < 0.02, k
+
+
+def test_invert_second_image_group_is_inverted_against_its_own_image():
+    """embedding.invert() over TWO image groups with the hipGraph launch (embedding_img.py:74-84: the loop re-loads the encoder and
+    runs on the next image): the captured iteration reads a static input buffer, so the second group has to be copied into it
+    (EmbedStep.set_image).  One iteration from the checkpoint: w1 = E_ckpt(image), so the replayed result must equal the eager
+    one on the SAME image and differ from the first image's."""
+    import dge_amd.stylegan1 as S
+    from dge_amd.encoder_variants import BlurBE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.embedding import EmbedStep, invert
+    L = 5
+
+    def make():
+        torch.manual_seed(1)
+        Gs = S.Generator(startf=16, maxf=64, layer_count=L, latent_size=512, compute_dtype="f32").cuda()
+        for p in Gs.parameters():
+            p.requires_grad_(False)
+        E = BlurBE(startf=16, maxf=64, layer_count=L, compute_dtype="f32").cuda()
+        LP = LPIPS(compute_dtype="f32").cuda()
+        LP.load_state_dict(LR.seeded_params(0))
+        return EmbedStep(Gs, E, LP, lr=0.002)
+
+    g = golden("embed_sg1.npz")
+    img_a = torch.as_tensor(g["imgs1"]).cuda()
+    img_b = (R.randn("embed.second_image", tuple(img_a.shape), 3, 0.4)).cuda().clamp(-1, 1)
+    e = make()
+    wa_e = invert(e, img_a, iterations=1, launch="eager")["w1"].clone()
+    wb_e = invert(e, img_b, iterations=1, launch="eager")["w1"].clone()
+    s = make()
+    wa_g = invert(s, img_a, iterations=2, launch="graph")["w1"].clone()      # captures (1 warm-up iteration) + 1 replay
+    wb_g = invert(s, img_b, iterations=1, launch="graph")["w1"].clone()      # replay on the second image from the checkpoint
+    torch.cuda.synchronize()
+    assert relerr(wb_e, wa_e.cpu().numpy()) > 1e-2                           # the two images give different codes ...
+    assert relerr(wb_g, wb_e.cpu().numpy()) < 1e-4, relerr(wb_g, wb_e.cpu().numpy())      # ... and the replay follows the image
+    with pytest.raises(ValueError):
+        s.set_image(img_b[:, :, :16])

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import golden, ROOT
+from tests.conftest import golden, ROOT, with_fixture_params
 from tests.golden import recipe as R
 from oracle import ref_torch as O
 
@@ -93,7 +93,7 @@ def test_s2_grad_wp():
 
 def enc_small_params():
     from tests.helpers import enc_shapes
-    return R.fill_encoder(enc_shapes(16, 64, 4), seed=21)
+    return with_fixture_params(R.fill_encoder(enc_shapes(16, 64, 4), seed=21), golden("enc_small.npz"))
 
 
 def test_encoder_forward_backward():

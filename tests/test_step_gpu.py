@@ -397,8 +397,10 @@ def test_graph_replay_of_stage1_equals_eager_iterations(legacy):
     for _ in range(3):
         b.replay()
     ntot = n0 + 1 + 3
-    # eager twin: the same z sequence - capture / replay number their iterations from 0, the eager pre-iteration used 0 as well
-    seq = ([0] if legacy else []) + [0, 1, 2, 3]
+    # eager twin: the same z sequence - capture numbers every real iteration it runs (the legacy form's eager pre-iteration
+    # included) consecutively from 0 and the replays continue behind them
+    seq = list(range(ntot))
+    assert b._g_iter == ntot
     for it in seq:
         a.step(it)
     assert len(seq) == ntot
@@ -713,3 +715,24 @@ FULLSIZE_STEP_BOUNDS = {
     "grad2_l2_max": 0.16,       # 0.079 (decode_block.2.conv_3.weight)
     "grad2_l2_all": 0.029,      # 0.0142
 }
+
+
+def test_train_loop_makes_the_same_updates_in_graph_and_eager_launch_modes(capsys):
+    """e_align.train() (E_align_s2.py:102-221 as a loop): `--launch graph` runs its warm-up iterations inside capture() as REAL
+    iterations 0, 1 and continues the loop behind them, so that both launch modes make the same number of encoder updates
+    (2 optimizer calls per iteration) on the same z / style-mixing sequence.  The first iteration draws no encoder noise that
+    matters yet (noise weights start at zero), so w_avg after the run - a function of the z sequence only - must agree."""
+    from dge_amd import e_align
+    common = ["--mtype", "2", "--img_size", "64", "--fmaps_base", "2048", "--fmaps_max", "128", "--enc_maxf", "64", "--start_features", "16",
+              "--batch_size", "2", "--iterations", "5", "--allow_standin_lpips", "--compute_dtype", "f32"]
+    out = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        st = e_align.main(common + ["--launch", mode])
+        t = max(s["step"] for s in st.opt.state.values() if len(s))
+        out[mode] = (int(t), st.G.truncation.w_avg.detach().cpu().clone())
+        if mode == "graph":
+            assert st._g_iter == 5
+    assert out["eager"][0] == out["graph"][0] == 10, (out["eager"][0], out["graph"][0])
+    # w_avg: EMA over the batch mean of mapping(z_it), it = 0 .. 4 (stylegan2_generator.py:177-181) - identical z sequence in both modes
+    assert relerr(out["graph"][1], out["eager"][1].numpy()) < 1e-5

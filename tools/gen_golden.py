@@ -202,6 +202,102 @@ class _NoiseFeeder:
         torch.randn = self.orig
 
 
+class _LreluTap:
+    """Records the input of every F.leaky_relu call of a reference forward, in call order (the reference modules call
+    `F.leaky_relu` through the torch.nn.functional module object, so replacing the attribute reaches all of them)."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self.F, self.orig, self.inputs = F, F.leaky_relu, []
+        F.leaky_relu = self
+        return self
+
+    def __call__(self, x, *a, **kw):
+        self.inputs.append(x.detach().clone())
+        return self.orig(x, *a, **kw)
+
+    def __exit__(self, *a):
+        self.F.leaky_relu = self.orig
+
+
+KINK_MARGIN = 1e-4      # gradient fixtures: no leaky-relu pre-activation within KINK_MARGIN * max|pre-activation| of zero
+
+
+def clear_kinks(runs, owners, names, margin=KINK_MARGIN):
+    """Gradient parity at 1e-3 is meaningless when a pre-activation of the fixture sits within rounding distance of the leaky-relu
+    kink: the slope (0.2 <-> 1) of that element is then decided by the last bit of whoever computes it, and a 64-element
+    bias / noise-weight gradient moves by ~1e-2 per flipped element.  The reference adds a per-channel bias right in front of
+    every leaky-relu (model/E/E.py:61-62,74-75; E_PG.py:83-84,97-102; E_BIG.py:142-143,157-158; stylegan1/net.py:150-152,162-164;
+    model/utils/net.py:238-239), so the fixture's parameters are chosen such that this cannot happen: layer by layer, in forward order, each channel's
+    bias is moved by the smallest amount (a few 1e-4 of the activation scale) that leaves every pre-activation of the channel
+    at least 2 * margin * max away from zero.
+
+    runs   : callables, each performs one reference forward (all of them see every nudge; call k of every run shares owners[k])
+    owners : per leaky-relu call, the bias Parameter in front of it (None: the call re-applies lrelu to an lrelu output - same kink)
+    names  : state_dict key of each owner (None for None)
+    Returns ({key: nudged bias tensor}, achieved margin = min over calls of min|x| / max|x|)."""
+    changed = {}
+
+    def tap_all():
+        recs = []
+        for run in runs:
+            with _LreluTap() as tap, torch.no_grad():
+                run()
+            assert len(tap.inputs) <= len(owners), (len(tap.inputs), len(owners))
+            recs.append(tap.inputs)
+        return recs
+
+    for k, own in enumerate(owners):
+        if own is None:
+            continue
+        xs = [r[k] for r in tap_all() if len(r) > k]
+        C = own.numel()
+        assert all(x.shape[1] == C for x in xs), (k, names[k], [tuple(x.shape) for x in xs], C)
+        mx = max(float(x.abs().max()) for x in xs)
+        mt = 2.0 * margin * mx
+        v = torch.cat([x.transpose(0, 1).reshape(C, -1) for x in xs], dim=1).double().numpy()      # [C, values]
+        delta = np.zeros(C)
+        for c in range(C):
+            u = np.sort(v[c])
+            if np.min(np.abs(u)) > mt:
+                continue
+            # p = -delta must be >= mt away from every u: pick the admissible point closest to zero
+            cand = [u[0] - mt, u[-1] + mt]
+            gaps = np.nonzero(u[1:] - u[:-1] >= 2 * mt)[0]
+            for i in gaps:
+                lo, hi = u[i] + mt, u[i + 1] - mt
+                cand.append(min(max(0.0, lo), hi))
+            p = min(cand, key=abs)
+            delta[c] = -p
+        if np.any(delta != 0):
+            with torch.no_grad():
+                own.view(-1).add_(torch.from_numpy(delta).to(own.dtype))
+            changed[names[k]] = own.detach().clone()
+    # the assertion of the generator: every call of every run clears the margin with the final parameters
+    worst = 1.0
+    for r in tap_all():
+        for k, x in enumerate(r):
+            if owners[k] is None:
+                continue
+            rel = float(x.abs().min()) / float(x.abs().max())
+            assert rel > margin, (k, names[k], rel)
+            worst = min(worst, rel)
+    print(f"  clear_kinks: {len(changed)} bias tensors nudged, min |pre-activation| / max = {worst:.2e} (margin {margin:g})")
+    return changed, worst
+
+
+def enc_kink_owners(E, second_attr, third=False):
+    """leaky-relu call order of the reference encoders: FromRGB, then per block bias_1 [, bias_2 [, a second lrelu on x (E_BIG.py:163)]]"""
+    owners, names = [E.FromRGB.from_rgb.bias], ["FromRGB.from_rgb.bias"]
+    for j, b in enumerate(E.decode_block):
+        owners.append(b.bias_1); names.append(f"decode_block.{j}.bias_1")
+        if getattr(b, second_attr):
+            owners.append(b.bias_2); names.append(f"decode_block.{j}.bias_2")
+            if third and b.inputs != b.outputs:
+                owners.append(None); names.append(None)
+    return owners, names
+
+
 def gen_enc():
     import model.E.E as EE
     keys = {}
@@ -220,6 +316,11 @@ def gen_enc():
     E.load_state_dict(sd)
     img = R.randn("enc.img", (2, 3, 32, 32), 9, 0.5)
     img.requires_grad_(True)
+
+    def run():
+        with _NoiseFeeder("enc", 9):
+            E(img)
+    nudged, margin = clear_kinks([run], *enc_kink_owners(E, "has_last_conv"))
     feats = {}
     hooks = [E.decode_block[j].register_forward_hook(
         lambda m, i, o, j=j: feats.__setitem__(j, [t.detach().clone() for t in o])) for j in range(4)]
@@ -238,7 +339,9 @@ def gen_enc():
             out["grad:" + k] = p.grad
         else:
             out["nograd:" + k] = np.zeros(1)
-    out["state_checksum"] = np.array(R.checksum(sd))
+    out["state_checksum"] = np.array(R.checksum({k: v.detach() for k, v in E.state_dict().items()}))      # with the nudged biases
+    out["kink_margin"] = np.array(margin)
+    out.update({"param:" + k: v for k, v in nudged.items()})
     save_npz("enc_small.npz", **out)
 
 
@@ -634,10 +737,24 @@ def gen_sg1grad():
             sd[k] = R.randn("sg1.const", tuple(sd[k].shape), 41)
     G.load_state_dict(sd)
     out = {}
-    for tag, lod, prefix in (("", 5, "sg1"), ("_lod3", 3, "sg1b")):
+    cases = (("", 5, "sg1"), ("_lod3", 3, "sg1b"))
+
+    def runner(lod, prefix):
+        def run():
+            with _NoiseFeeder(prefix, 6):
+                return G.forward(R.randn("sg1.styles", (2, 12, 512), 6), lod)
+        return run
+    owners, names = [], []
+    for j, b in enumerate(G.decode_block):          # DecodeBlock.forward: lrelu behind bias_1 and behind bias_2 (stylegan1/net.py:150-152,162-164)
+        owners += [b.bias_1, b.bias_2]; names += [f"decode_block.{j}.bias_1", f"decode_block.{j}.bias_2"]
+    nudged, margin = clear_kinks([runner(lod, prefix) for _, lod, prefix in cases], owners, names)
+    out["kink_margin"] = np.array(margin)
+    out.update({"param:" + k: v for k, v in nudged.items()})
+    for tag, lod, prefix in cases:
         styles = R.randn("sg1.styles", (2, 12, 512), 6).requires_grad_(True)
         with _NoiseFeeder(prefix, 6):
             img = G.forward(styles, lod)
+        out["image" + tag] = img.detach()
         gimg = R.randn("sg1.gimg" + tag, tuple(img.shape), 7)
         (img * gimg).sum().backward()
         out["g_styles" + tag] = styles.grad
@@ -740,12 +857,17 @@ def gen_encblurgrad():
             sd[k] = E.state_dict()[k].clone()
     E.load_state_dict(sd)
     img = R.randn("eb.img", (2, 3, 128, 128), 61, 0.5).requires_grad_(True)
-    with _NoiseFeeder("eb", 61):
-        x, w = E(img)
+
+    def run():
+        with _NoiseFeeder("eb", 61):
+            return E(img)
+    nudged, margin = clear_kinks([run], *enc_kink_owners(E, "has_last_conv"))
+    x, w = run()
     gx, gw = R.randn("eb.gx", tuple(x.shape), 63), R.randn("eb.gw", tuple(w.shape), 63)
     loss = (x * gx).sum() + (w * gw).sum()
     loss.backward()
-    out = {"loss": loss.detach(), "g_img": img.grad}
+    out = {"loss": loss.detach(), "g_img": img.grad, "x": x.detach(), "w": w.detach(),
+           "kink_margin": np.array(margin), **{"param:" + k: v for k, v in nudged.items()}}
     for k, p_ in E.named_parameters():
         if p_.grad is None:
             continue
@@ -863,15 +985,19 @@ def gen_encpggrad():
             sd[k] = R.randn("pg." + k, tuple(sd[k].shape), 62, 0.2, 1.0)
     E.load_state_dict(sd)
     img = R.randn("ep.img", (2, 3, 64, 64), 62, 0.5)
+
+    def run():
+        with _NoiseFeeder("ep", 62):
+            E(img)
+    nudged, margin = clear_kinks([run], *enc_kink_owners(E, "has_second_conv"))
     feats = {}
     h = E.new_final.register_forward_hook(lambda m_, i, o: feats.__setitem__("head", o))
-    with _NoiseFeeder("ep", 62):
-        E(img)
+    run()
     h.remove()
     z = feats["head"]
     loss = (z * R.randn("ep.gz", tuple(z.shape), 64)).sum()
     loss.backward()
-    out = {"loss": loss.detach()}
+    out = {"loss": loss.detach(), "kink_margin": np.array(margin), **{"param:" + k: v for k, v in nudged.items()}}
     for k, p_ in E.named_parameters():
         if p_.grad is None:
             continue
@@ -985,11 +1111,23 @@ def gen_encbiggrad():
     E.train()
     img = R.randn("ebg.img", (2, 3, 64, 64), 81, 0.5)
     cond = R.randn("ebg.cond", (2, 256), 81, 0.5)
-    with _NoiseFeeder("ebg", 81):
-        c_v, z = E(img, cond)
+    # every train-mode forward runs one spectral-norm power iteration IN PLACE on weight_u / weight_v: the buffers are put back
+    # before each pass so that the nudging passes and the recorded pass all see the fixture's state (= one iteration from it)
+    uv = {k: v.clone() for k, v in E.state_dict().items() if k.endswith(("weight_u", "weight_v"))}
+
+    def run():
+        with torch.no_grad():
+            for k, v in E.state_dict().items():
+                if k in uv:
+                    v.copy_(uv[k])
+        with _NoiseFeeder("ebg", 81):
+            return E(img, cond)
+    nudged, margin = clear_kinks([run], *enc_kink_owners(E, "has_second_conv", third=True))
+    c_v, z = run()
     loss = (z * R.randn("ebg.gz", tuple(z.shape), 82)).sum() + (c_v * R.randn("ebg.gcv", tuple(c_v.shape), 82)).sum()
     loss.backward()
-    out = {"loss": loss.detach(), "c_v": c_v.detach(), "z": z.detach()}
+    out = {"loss": loss.detach(), "c_v": c_v.detach(), "z": z.detach(),
+           "kink_margin": np.array(margin), **{"param:" + k: v for k, v in nudged.items()}}
     for k, p_ in E.named_parameters():
         if p_.grad is None:
             continue
