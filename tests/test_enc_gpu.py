@@ -81,13 +81,13 @@ def test_encoder_backward_vs_reference_golden(cd):
             if cd == "f32":
                 e = ((a - b).abs().max() / b.abs().max()).item()
                 worst_f32 = max(worst_f32, e)
-                if not e < 2e-3:
+                if not e < 1e-4:          # (measured 4.9e-6: kink-free fixture, deterministic run)
                     bad[k] = e
             else:
                 l2 = ((a - b).norm() / b.norm()).item()
                 cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
                 worst[0], worst[1] = max(worst[0], l2), min(worst[1], cos)
-                if not (l2 < 0.15 and cos > 0.99):
+                if not (l2 < 0.145 and cos > 0.994):      # (deterministic run: worst tensor L2 0.096, cosine 0.9962; bounds 1.5x)
                     bad[k] = (l2, cos)
         else:
             assert p.grad is None, f"{k} must not receive a gradient (reference leaves it None)"

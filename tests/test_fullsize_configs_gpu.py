@@ -12,6 +12,7 @@ import math
 
 import numpy as np
 import pytest
+from tests.conftest import meas
 import torch
 
 from tests.golden import recipe as R
@@ -192,13 +193,15 @@ def _enc_case(E, P, img, noises, fwd_ref, B, tag, tol_out, tol_l2, extra_in=None
     if only_w:
         routs = routs[-1:]
     assert len(routs) == len(outs)
-    for o, r in zip(outs, routs):
+    for i, (o, r) in enumerate(zip(outs, routs)):
         e = relerr(_two(o, B), r)
+        meas(f"fullsize_cfg_out[{tag}-{B}-{i}]", err=e, bound=tol_out)
         assert e < tol_out, (tag, e)
     sum((r * _two(g, B)).sum() for r, g in zip(routs, gws)).backward()
     cos_min, l2_max = _grad_report({k: p.grad for k, p in E.named_parameters() if p.grad is not None},
                                    {k: v.grad for k, v in Pr.items() if v.requires_grad and v.grad is not None})
     print(f"{tag} B={B}: grad cos_min {cos_min:.4f} l2_max {l2_max:.3e}", sorted(c.seen))
+    meas(f"fullsize_cfg_grad[{tag}-{B}]", cos_min=cos_min, l2_max=l2_max, bound_l2=tol_l2)
     assert cos_min > 1 - tol_l2 / 2.5 and l2_max < tol_l2, (tag, cos_min, l2_max)
     return c
 

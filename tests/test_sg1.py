@@ -158,16 +158,17 @@ def test_hip_style_gradient_vs_reference_golden(cd):
         cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item()
         meas("sg1_style_grad", cd=cd, lod=lod, l2=err, cos=cos)
         if cd == "f32":
-            # 2e-3 at both lods: the fixture's biases keep every pre-activation >= 1e-4 * max away from the leaky-relu kink
-            # (tools/gen_golden.py: clear_kinks; before, ONE pre-activation of block 2 within f32 rounding of zero moved the
-            # lod-3 gradient by 1.7 %)
-            assert err < 2e-3 and cos > 0.9995, (tag, cos, err)
+            # 1e-4 at both lods (measured 2.1e-6 / 3.4e-6): the fixture's biases keep every pre-activation >= 1e-4 * max away from
+            # the leaky-relu kink (tools/gen_golden.py: clear_kinks) and the run is deterministic (tests/conftest.py).  Before, ONE
+            # pre-activation of block 2 within f32 rounding of zero moved the lod-3 gradient by 1.7 %.
+            assert err < 1e-4 and cos > 0.999999, (tag, cos, err)
         else:
             # bf16 activations: the forward itself deviates by a few % of the image range (12 convs + 12 instance norms on
             # bf16-rounded activations), so the gradient is taken at a slightly different point (leaky-relu masks flip for
             # ~0.5 % of the elements per layer).  Top style row 1.7 %, lower rows 15-22 % L2, cosine 0.98 overall; judged
             # on direction and norm.  The f32 run above is the parity check of the backward formulas.
-            assert cos > 0.97 and err < 0.25, (tag, cos, err)
+            # (deterministic run: lod 5 L2 0.227 / cosine 0.974, lod 3 0.150 / 0.989; bounds 1.5x)
+            assert cos > (0.96 if lod == 5 else 0.984) and err < (0.34 if lod == 5 else 0.225), (tag, cos, err)
         # layers above the decoded level receive no gradient
         if 2 * (lod + 1) < got.shape[1]:
             assert float(got[:, 2 * (lod + 1):].abs().max()) == 0.0

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import golden
+from tests.conftest import golden, meas as record_meas
 from tests.golden import recipe as R
 from tests.helpers import s2_shapes, enc_shapes
 from oracle import ref_torch as O
@@ -640,6 +640,19 @@ def test_fullsize_step_bf16_matches_cpu_oracle(mode, B, cd):
     LP = LPIPS(compute_dtype=cd).cuda()
     LP.load_state_dict(PL)
     st = EAlignStep(G, E, LP, lr=0.0015, batch_size=B)
+    # the f32 attribution run is a parity run against the (reference-pinned) oracle: deterministic mode, like every other
+    # reference-parity test (tests/conftest.py) - its scalars sit at a few f32 epsilons, where the order of f32 atomics would
+    # otherwise decide the last digits.  The bf16 cases run the library's default mode: they are the benchmarked configuration.
+    from dge_amd import ops
+    ops.set_deterministic(cd == "f32")
+    try:
+        _fullsize_step_body(st, E, G, PG, PE0, PL, z, noises, train, it, mode, B, cd)
+    finally:
+        ops.set_deterministic(False)
+
+
+def _fullsize_step_body(st, E, G, PG, PE0, PL, z, noises, train, it, mode, B, cd):
+    from oracle import step_ref
     got_grads = []
     opt_step = st.opt.step
 
@@ -680,6 +693,7 @@ def test_fullsize_step_bf16_matches_cpu_oracle(mode, B, cd):
             tot_num += ((g - gr) ** 2).sum().item(); tot_den += (gr ** 2).sum().item()
         meas[f"{key}_cos_min"], meas[f"{key}_l2_max"], meas[f"{key}_l2_all"] = cos_min, l2_max, (tot_num / tot_den) ** 0.5
     print(f"full-size {cd} step ({mode}, batch {B}) vs CPU oracle:", {k: f"{v:.3e}" for k, v in meas.items()}, worst)
+    record_meas(f"fullsize_step[{mode}-{B}-{cd}]", **meas)
     for k, bound in (FULLSIZE_STEP_BOUNDS if cd == "bf16" else FULLSIZE_STEP_BOUNDS_F32).items():
         v = meas[k]
         assert (v > bound) if k.endswith("cos_min") else (v < bound), (k, v, bound)
