@@ -175,6 +175,9 @@ SIGNATURES = {
     "dge_conv_wgrad_dots": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dge_pack_conv_pp_rows": [_P, _I, _P, _I, _I, _P, _I, _P, _F, _I, _I, _P],
     "dge_conv_pp": [C.POINTER(ConvPPDesc), _P],
+    "dge_up_pp_supported": [_I, _I, _I, _I, _I, _I],
+    "dge_pack_up_pp": [_P, _P, _I, _I, _P, _P, _F, _I, _P],
+    "dge_up_pp": [_P, _P, C.c_longlong, _P, _P, _I, _P, _P, _F, _F, _I, _I, _I, _I, _I, _I, _P],
 }
 
 _lib = None

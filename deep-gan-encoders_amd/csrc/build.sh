@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libdge_hip.so
-SRCS="capi.hip conv_pp.hip conv_igemm.hip conv_igemm_f32.hip conv_stream.hip upconv_stream.hip conv_pw.hip conv_small.hip wgrad_dma.hip s2_kernels.hip $(ls *_kernels.hip | grep -v s2_kernels.hip || true)"
+SRCS="capi.hip conv_pp.hip up_pp.hip conv_igemm.hip conv_igemm_f32.hip conv_stream.hip upconv_stream.hip conv_pw.hip conv_small.hip wgrad_dma.hip s2_kernels.hip $(ls *_kernels.hip | grep -v s2_kernels.hip || true)"
 mkdir -p build
 objs=""
 pids=""

@@ -1,0 +1,485 @@
+// up_pp: the StyleGAN2 up layer (conv_transpose2d stride 2 + 4x4 FIR, model/stylegan2_generator.py:879-896, :603-615; demodulation,
+// noise, bias, lrelu * sqrt 2 :908-921) for the MFMA-bound layers (Cin >= 128: layers 7 / 9 / 11 / 13 of the 1024^2 generator) as a
+// ping-pong implicit GEMM on the skeleton of conv_pp.hip, with the FIR taken in registers the way upconv_stream.hip takes it.
+//
+// Math: the transposed-conv result t ((2H+1)^2) in phase form, t[2m+py][2n+px] for input position (m, n):
+//   ee = x[m][n] W(2,2) + x[m-1][n] W(0,2) + x[m][n-1] W(2,0) + x[m-1][n-1] W(0,0)      eo = x[m][n] W(2,1) + x[m-1][n] W(0,1)
+//   oe = x[m][n] W(1,2) + x[m][n-1] W(1,0)                                               oo = x[m][n] W(1,1)
+// = 9 (phase, tap) units per input position (dge_pack_upconv_weight's unit order), then y[o] = sum_j F[j] t[o + j - 1] per axis with
+// F = [1,3,3,1] / 4, + noise * strength + bias, lrelu * sqrt 2.  Style, demodulation and gain are folded into one weight image per
+// sample (the reference's own fused form, :858-875; dge_pack_up_pp), as conv_pp / upconv_stream do.
+//
+// Why not upconv_fir_kernel: its workgroup is one serial pipeline (halo through registers, a barrier per stage): the K loop alone
+// runs at ~0.33 of the matrix pipe and the FIR phase of a workgroup overlaps nothing.  Here:
+//   * 8 waves = two groups of four (waves w and w + 4 share a SIMD); in every phase one group issues the MFMAs of a cluster while
+//     the other reads the fragments of its next cluster from LDS; one s_barrier per phase (conv_pp.hip's choreography).
+//   * a wave holds 2 input rows x 32 columns x 32 output channels x ALL FOUR phases (8 accumulator blocks = 128 registers): the
+//     activation fragments are shared by the phases, and the nine units of a 32-channel K chunk are three clusters:
+//     A = tap (m, n) -> ee eo oe oo (16 MFMAs, 12 fragment reads), B = taps (m-1, n) -> ee eo and (m-1, n-1) -> ee (12 / 14),
+//     C = tap (m, n-1) -> ee oe (8 / 8): 36 MFMAs per wave and chunk, none of them on zero blocks.
+//   * workgroup tile = 16 input rows x 32 columns x 32 channels; everything arrives by LDS-DMA: the halo tile (17 x 33 pixels x
+//     64 B, 36 one-KiB pieces, part-major: conflict-free ds_read_b128) of chunk c + 1 during cluster A of chunk c (two buffers), the
+//     18 KiB weight block of chunk c + 2 during cluster B (three slots), arrival counted with s_waitcnt vmcnt(N).
+//   * epilogue in registers: a lane (column n, K half) ends with both column phases of 16 channels -> bf16x2 words (t is rounded to
+//     bf16 exactly where upconv_fir / upconv_stream round it), neighbour columns by DPP wave shifts, horizontal FIR as
+//     v_dot2_f32_bf16, the three boundary t rows a wave needs from its neighbours go through LDS once (96 KiB, the drained
+//     operand buffers), vertical FIR + noise + bias + lrelu, 16-byte stores.  The FIR needs one t column / row before and two
+//     after: tiles advance by 14 input rows and 30 columns (28 x 60 finished outputs per tile).
+#include <type_traits>
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/dge_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) unsigned rsrc_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+typedef __attribute__((ext_vector_type(2))) float f2_t;
+
+namespace {
+
+struct UPParams {
+    const bf16_t* x; const bf16_t* w; bf16_t* y;
+    long long w_bstride;                      // bytes between the samples' weight images (0 = shared)
+    const float* bias; const float* noise; const float* noise_w;
+    int B, H, W, Cin, Cout;
+    int noise_bstride, act;
+    float bias_scale, gain;
+    int tiles_x, tiles_y, ntn, nchunks;
+    int dbg;
+};
+
+__device__ __forceinline__ unsigned rfl(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+__device__ __forceinline__ rsrc_t make_rsrc(unsigned long long base, unsigned bytes) {
+    rsrc_t r;
+    r[0] = rfl((unsigned)base); r[1] = rfl((unsigned)(base >> 32) & 0xffffu); r[2] = rfl(bytes); r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void dma_buf(unsigned voff, rsrc_t rs, unsigned soff, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" : : "v"(voff), "s"(m0v), "s"(rs), "s"(soff) : "memory");
+}
+__device__ __forceinline__ int tr_chan_of_row(int m) {
+    const int j = m >> 3, k = (m >> 2) & 1, i = m & 3;
+    return 16 * (j >> 1) + 8 * k + 4 * (j & 1) + i;
+}
+
+// tile geometry
+constexpr int TR = 16, TC = 32;                      // input positions per tile (rows, columns)
+constexpr int HR = TR + 1, HC = TC + 1, HPIX = HR * HC;        // halo tile 17 x 33
+constexpr int HPIECES = (HPIX + 15) / 16;            // 36
+constexpr int HPW = (HPIECES + 7) / 8;               // 5 halo requests per wave and chunk
+constexpr int WPIECES = 18, WPW = 3;                 // weight block of a chunk: 9 units x 2 pieces; 3 requests per wave (6 of 24 out of range)
+constexpr int WBLK = WPIECES * 1024;                 // 18,432 B per (sample, channel tile, chunk)
+// LDS map: halo 0 | weight slot 0 | halo 1 (at 64 KiB: the buffer toggle is one XOR) | weight slots 1, 2
+constexpr int H1_OFF = 65536, W0_OFF = 36864, W1_OFF = 102400, W2_OFF = 126976, UP_LDS = 163840;
+static_assert(HPW * 8 * 1024 <= W0_OFF + 4096 && W0_OFF + 24576 <= H1_OFF && W2_OFF + 24576 <= UP_LDS, "LDS map");
+constexpr int EXCH_BYTES = 8 * 4 * 64 * 64;          // epilogue: the 4 t rows x 16 words per lane of every wave = 128 KiB from offset 0
+static_assert(EXCH_BYTES <= UP_LDS, "exchange area");
+// slot-local unit order of a chunk's weight block: A = ee eo oe oo of tap (m, n) | B = ee eo of (m-1, n), ee of (m-1, n-1) | C = ee oe of (m, n-1)
+// -> dge_pack_upconv_weight's q (phase (0,0): q = 2a + b; (0,1): 4 + a; (1,0): 6 + b; (1,1): 8; a / b = row / column shift)
+__host__ __device__ constexpr int unit_q(int u) { return u == 0 ? 0 : u == 1 ? 4 : u == 2 ? 6 : u == 3 ? 8 : u == 4 ? 2 : u == 5 ? 5 : u == 6 ? 3 : u == 7 ? 1 : 7; }
+
+template <bool DBG>
+__global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[UP_LDS];
+    const unsigned lds0 = lds_off(lds);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = rfl(tid >> 6), g = wave >> 2;
+    typedef const __attribute__((address_space(4))) UPParams* kparg_t;
+    const kparg_t kp = (kparg_t)__builtin_amdgcn_kernarg_segment_ptr();
+    auto P = [&]() { kparg_t r = kp; asm volatile("" : "+s"(r)); return r; };
+    const int nchunks = p_.nchunks;
+    const int dbg = DBG ? p_.dbg : 0;
+
+    // tiles of this workgroup (XCD-aware: workgroup i lives on XCD i % 8 and walks a contiguous range of that XCD's tiles,
+    // channel tiles innermost: the workgroups that share a halo tile run side by side on one L2)
+    const int ntiles = p_.tiles_x * p_.tiles_y * p_.B * p_.ntn;
+    const int per_xcd = (ntiles + 7) >> 3, stride = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    int tile = xcd * per_xcd + (blockIdx.x >> 3);
+    const int tile_end = min((xcd + 1) * per_xcd, ntiles);
+    if (tile >= tile_end) return;
+
+    // fragment addresses.  Halo pixel (hr, hc) -> linear index hp = hr * 33 + hc, byte (hp >> 4) KiB + (hp & 15) * 16 + part * 256,
+    // part = 2 ks + kh (ks: +512 as an immediate).  Rows hr = 2 w' + 0 .. 2 (w' = wave: input rows 2 w', 2 w' + 1 and the one above),
+    // columns hc = l31 + 1 - b (b = column shift of the tap).
+    unsigned xat[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const int hp = (2 * wave + r) * HC + l31 + 1 - b;
+            xat[r][b] = (unsigned)((hp >> 4) * 1024 + (hp & 15) * 16 + kh * 256);
+        }
+    unsigned wl;
+    {
+        const int n = tr_chan_of_row(l31);
+        wl = (unsigned)((n >> 4) * 1024 + (n & 15) * 16 + kh * 256);
+    }
+    // DMA lane constants: this wave's halo pieces (P = wave + 8 k) and weight pieces (P = wave + 8 j; P >= 18: out of range = no traffic)
+    const unsigned wm0 = rfl(lds0 + wave * 1024);
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; j++) wvoff[j] = (wave + 8 * j) < WPIECES ? (unsigned)((wave + 8 * j) * 1024 + lane * 16) : 0x80000000u;
+
+    f32x16_t acc[2][4];                         // [input row of the wave][phase 2 py + px]
+    for (;;) {
+        // ---------------------------------------------------------------- tile
+        int x0, y0, b, nt;
+        {
+            const auto p = P();
+            int id = tile;
+            nt = id % p->ntn; id /= p->ntn;
+            x0 = (id % p->tiles_x) * 30 - 1; id /= p->tiles_x;             // first input column / row of the tile (-1: the zero border)
+            y0 = (id % p->tiles_y) * 14 - 1; b = id / p->tiles_y;
+        }
+        rsrc_t rs, rw;
+        unsigned hoff[HPW];
+        {
+            const auto p = P();
+            const unsigned xbytes = (unsigned)(p->H * p->W) * (unsigned)p->Cin * 2u;
+            rs = make_rsrc((unsigned long long)p->x + (unsigned long long)b * xbytes, xbytes);
+            // (the SGPR offset of a buffer access takes no part in the range check: the weight descriptor spans ONE chunk block, the chunk
+            //  is the scalar offset; a lane's offset beyond the block = a piece that does not exist = no traffic)
+            rw = make_rsrc((unsigned long long)p->w + (unsigned long long)b * (unsigned long long)p->w_bstride +
+                           (unsigned long long)nt * nchunks * (unsigned long long)WBLK, (unsigned)WBLK);
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+#pragma unroll
+            for (int k = 0; k < HPW; k++) {
+                const int hp = (wave + 8 * k) * 16 + (lane_o & 15), qd = lane_o >> 4;
+                const int hr = hp / HC, hc = hp - hr * HC;
+                const int gy = y0 - 1 + hr, gx = x0 - 1 + hc;
+                const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->H) & ((unsigned)gx < (unsigned)p->W);
+                hoff[k] = ok ? (unsigned)(((gy * p->W + gx) * p->Cin + qd * 8) * 2) : 0x80000000u;
+            }
+        }
+        // prologue: halo of chunk 0 -> buffer 0, weights of chunks 0 and 1 -> slots 0 and 1 (everything of the previous tile is drained)
+        StaticFor<HPW>::run([&](auto kc_) { constexpr int k = decltype(kc_)::value; dma_buf(hoff[k], rs, 0u, rfl(wm0 + k * 8192)); });
+        StaticFor<WPW>::run([&](auto jc) { constexpr int j = decltype(jc)::value; dma_buf(wvoff[j], rw, 0u, rfl(wm0 + W0_OFF + j * 8192)); });
+        StaticFor<WPW>::run([&](auto jc) { constexpr int j = decltype(jc)::value; dma_buf(wvoff[j], rw, (unsigned)WBLK, rfl(wm0 + W1_OFF + j * 8192)); });   // (nchunks >= 4)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][ph][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (g == 1) asm volatile("s_barrier" ::: "memory");                 // group 1 runs one phase behind group 0
+
+        unsigned hx = 0;                          // XOR of the halo buffer being READ (0 / H1_OFF)
+        unsigned wcur = W0_OFF, wnx1 = W1_OFF, wnx2 = W2_OFF;      // slot read by this chunk, by the next one, filled for the one after
+        for (int kc = 0; kc < nchunks; kc++) {
+            const bool lastc = kc == nchunks - 1;
+            // requests beyond the last chunk go through an EMPTY descriptor (every lane out of range: zeros into a buffer nobody reads,
+            // no memory traffic) so that every chunk issues the same number of requests and the wait counts stay static
+            const unsigned hsoff = (unsigned)(kc + 1) * 64u, wsoff = (unsigned)(kc + 2) * (unsigned)WBLK;
+            rsrc_t rsn = rs, rwn = rw;
+            if (kc + 1 >= nchunks) { rsn[2] = 0u; }
+            if (kc + 2 >= nchunks) { rwn[2] = 0u; }
+            const unsigned hm0 = wm0 + (hx ^ (unsigned)H1_OFF);            // this wave's first piece of the halo buffer being FILLED
+            const unsigned wfill = wm0 + wnx2;
+            const unsigned wrd = wl + wcur;
+            // ------------------------------------------------ cluster A: tap (m, n) -> ee eo oe oo
+            {
+                uint4 xa[2][2], wa[4][2];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) xa[i][ks] = *(const uint4*)(lds + (xat[i + 1][0] ^ hx) + ks * 512);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) wa[u][ks] = *(const uint4*)(lds + wrd + u * 2048 + ks * 512);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                StaticFor<16>::run([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, ks = m >> 3, i = (m >> 2) & 1, u = m & 3;
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wa[u][ks], *(const bf16x8_t*)&xa[i][ks], acc[i][u], 0, 0, 0);
+                    if constexpr (m == 1 || m == 4 || m == 7 || m == 10 || m == 13) {
+                        constexpr int k = (m - 1) / 3;                       // halo piece k of chunk kc + 1
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(DBG && (dbg & 4)))
+                            asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                         :: "v"(hoff[k]), "s"(hm0), "s"(rsn), "s"(hsoff), "i"(k * 8192) : "memory", "scc");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ------------------------------------------------ cluster B: taps (m-1, n) -> ee eo, (m-1, n-1) -> ee
+            {
+                uint4 xb[2][2][2], wb[3][2];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) xb[i][bb][ks] = *(const uint4*)(lds + (xat[i][bb] ^ hx) + ks * 512);
+#pragma unroll
+                for (int u = 0; u < 3; u++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) wb[u][ks] = *(const uint4*)(lds + wrd + (4 + u) * 2048 + ks * 512);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                StaticFor<12>::run([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, ks = m / 6, r6 = m % 6, i = r6 / 3, u = r6 % 3;      // u 0: ee <- (m-1, n); 1: eo <- (m-1, n); 2: ee <- (m-1, n-1)
+                    constexpr int ph = u == 1 ? 1 : 0, bb = u == 2 ? 1 : 0;
+                    acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wb[u][ks], *(const bf16x8_t*)&xb[i][bb][ks], acc[i][ph], 0, 0, 0);
+                    if constexpr (m == 2 || m == 5 || m == 8) {
+                        constexpr int j = (m - 2) / 3;                       // weight piece j of chunk kc + 2
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(DBG && (dbg & 1)))
+                            asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                         :: "v"(wvoff[j]), "s"(wfill), "s"(rwn), "s"(wsoff), "i"(j * 8192) : "memory", "scc");
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ------------------------------------------------ cluster C: tap (m, n-1) -> ee oe
+            {
+                uint4 xc[2][2], wc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) xc[i][ks] = *(const uint4*)(lds + (xat[i + 1][1] ^ hx) + ks * 512);
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) wc[u][ks] = *(const uint4*)(lds + wrd + (7 + u) * 2048 + ks * 512);
+                __builtin_amdgcn_sched_barrier(0);
+                // the halo tile of the NEXT chunk (requested during this chunk's cluster A) has landed - this wave's pieces; the barriers
+                // make it true for everybody's before anyone reads it.  Still in flight: the three weight pieces of chunk kc + 2.
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(WPW) : "memory");
+                if (!(lastc && g == 1)) asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                StaticFor<8>::run([&](auto mc) {
+                    constexpr int m = decltype(mc)::value, ks = m >> 2, i = (m >> 1) & 1, u = m & 1;            // u 0: ee, 1: oe
+                    acc[i][2 * u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wc[u][ks], *(const bf16x8_t*)&xc[i][ks], acc[i][2 * u], 0, 0, 0);
+                });
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!lastc) asm volatile("s_barrier" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            hx ^= (unsigned)H1_OFF;
+            { const unsigned t = wcur; wcur = wnx1; wnx1 = wnx2; wnx2 = t; }
+        }
+
+        // ---------------------------------------------------------------- epilogue (both groups in step again)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // every request has landed, every fragment read is done
+        const auto p = P();
+        const int OH = 2 * p->H, OW = 2 * p->W, Cout = p->Cout;
+        const int R = 2 * (y0 + 2 * wave);                                  // t row of (input row 0 of the wave, py 0); y rows R .. R + 3
+        const int Xe = 2 * (x0 + l31);                                      // this lane's even output column
+        // noise of this lane's 4 rows x 2 columns (requested before the exchange, consumed at the end)
+        f2_t nz[4];
+        const float nwv = p->noise ? p->noise_w[0] * p->gain : 0.f;
+        {
+            const float* nzb = p->noise ? p->noise + (size_t)b * p->noise_bstride : nullptr;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int oy = R + k;
+                nz[k] = f2_t{0.f, 0.f};
+                if (nzb && (unsigned)oy < (unsigned)OH && Xe >= 0 && Xe + 1 < OW) nz[k] = *(const f2_t*)(nzb + (size_t)oy * OW + Xe);
+            }
+        }
+        // t words of the wave's four t rows ((t[.][2n], t[.][2n+1]) of 16 channels, rounded to bf16) go through LDS: a wave needs the
+        // last row of the wave above and the first two of the wave below, and reading its own rows back per channel half keeps the
+        // epilogue's register footprint (7 rows x 8 words + 64 sums) below the main loop's.  [wave][row][lane][16 words] = 128 KiB.
+        {
+            unsigned char* ex = lds + (size_t)wave * 16384 + lane * 64;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int py = 0; py < 2; py++)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        unsigned w4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) w4[e] = pack2bf(acc[i][2 * py][4 * q4 + e], acc[i][2 * py + 1][4 * q4 + e]);
+                        *(uint4*)(ex + (2 * i + py) * 4096 + q4 * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // row r = 0 .. 6 <-> t row R - 1 + r: the wave above's row 3 | own rows 0 .. 3 | the wave below's rows 0, 1
+        // (wave 0 / wave 7: the rows that would need the missing neighbour lie outside the tile's output range; any data will do)
+        unsigned exrow[7];
+        exrow[0] = (unsigned)((wave > 0 ? wave - 1 : 0) * 16384 + 3 * 4096 + lane * 64);
+#pragma unroll
+        for (int r = 1; r <= 4; r++) exrow[r] = (unsigned)(wave * 16384 + (r - 1) * 4096 + lane * 64);
+        exrow[5] = (unsigned)((wave < 7 ? wave + 1 : 7) * 16384 + lane * 64);
+        exrow[6] = exrow[5] + 4096;
+        // rows this wave finishes: y rows R + k that lie in the tile's range [28 ty, 28 ty + 27] (= [2 y0 + 2, 2 y0 + 29]) and in the image
+        const int ylo = 2 * y0 + 2, yhi = min(2 * y0 + 29, OH - 1);
+        const bool colv = l31 >= 1 && l31 <= 30 && Xe >= 0 && Xe + 1 < OW && !(DBG && (dbg & 8));
+        const float slope = p->act == DGE_ACT_LRELU ? 0.2f : (p->act == DGE_ACT_RELU ? 0.f : 1.f);
+        const float bg = p->bias_scale * p->gain;
+        const unsigned K0 = 0x3e80u, K1 = 0x3f40u;            // bf16 0.25, 0.75
+        const unsigned cL = K0 << 16, cC_e = K1 | (K1 << 16), cR_e = K0, cC_o = K0 | (K1 << 16), cR_o = K1 | (K0 << 16);
+        bf16_t* yb = p->y + (size_t)b * OH * OW * Cout;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                  // the lane's two runs of 8 channels
+            const int c0 = nt * 32 + 16 * h + 8 * kh;
+            float bia[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) bia[e] = p->bias ? p->bias[c0 + e] * bg : 0.f;
+            float ya[4][2][8];                          // y rows R .. R + 3, columns Xe, Xe + 1
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) ya[k][c][e] = 0.f;
+            unsigned trow[7][8];
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const uint4 a0 = *(const uint4*)(lds + exrow[r] + h * 32), a1 = *(const uint4*)(lds + exrow[r] + h * 32 + 16);
+                trow[r][0] = a0.x; trow[r][1] = a0.y; trow[r][2] = a0.z; trow[r][3] = a0.w;
+                trow[r][4] = a1.x; trow[r][5] = a1.y; trow[r][6] = a1.z; trow[r][7] = a1.w;
+            }
+            StaticFor<7>::run([&](auto rc) {
+                constexpr int r = decltype(rc)::value;          // t row R - 1 + r
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const unsigned wc = trow[r][e];
+                    const unsigned wlft = __builtin_amdgcn_mov_dpp(wc, 0x138, 0xf, 0xf, true);   // lane n - 1: (t[2n - 2], t[2n - 1])
+                    const unsigned wrgt = __builtin_amdgcn_mov_dpp(wc, 0x130, 0xf, 0xf, true);   // lane n + 1: (t[2n + 2], t[2n + 3])
+                    float he, ho;
+                    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(he) : "v"(wlft), "v"(cL));
+                    he = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wc, *(const bf2_t*)&cC_e, he, false);
+                    he = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_e, he, false);
+                    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(ho) : "v"(wc), "v"(cC_o));
+                    ho = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_o, ho, false);
+                    // h row r feeds y rows k = r - 3 .. r with F[r - k]
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        constexpr float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+                        if (r - k >= 0 && r - k <= 3) {
+                            ya[k][0][e] = fmaf(F[r - k], he, ya[k][0][e]);
+                            ya[k][1][e] = fmaf(F[r - k], ho, ya[k][1][e]);
+                        }
+                    }
+                }
+            });
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int oy = R + k;
+                const bool rowv = oy >= ylo && oy <= yhi && oy >= 0;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const float nzv = (c == 0 ? nz[k][0] : nz[k][1]) * nwv;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { const float u = ya[k][c][e] + (nzv + bia[e]); v[e] = fmaxf(u, u * slope); }
+                    const uint4 o = pack16(v, (bf16_t*)nullptr);
+                    if (rowv && colv) *(uint4*)(yb + ((size_t)oy * OW + Xe + c) * Cout + c0) = o;
+                }
+            }
+        }
+        tile += stride;
+        if (tile >= tile_end) break;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read the exchange area: the next prologue may overwrite it
+    }
+}
+
+// per-sample weight image: [sample][channel tile 32][chunk 32][18 pieces][part 4][row 16][8] bf16, slot-local unit order (unit_q),
+// W'[b][u][o][k] = bf16(wu[q(u)][o][k] * in_scale[b][k] * out_scale[b][o] * gain)
+__global__ __launch_bounds__(256) void up_pp_pack_kernel(const bf16_t* __restrict__ wu, bf16_t* __restrict__ out, int Cout, int Cin,
+                                                         const float* __restrict__ in_scale, const float* __restrict__ out_scale, float gain, int nb) {
+    const int nchunks = Cin / 32, ntn = Cout / 32;
+    // one thread = one 16-byte group: (piece, part qd, row r); grid.x over (nt, chunk, piece), threads 64 per piece
+    int bid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int l = threadIdx.x & 63, qd = l >> 4, r = l & 15;
+    const int pc = bid % WPIECES; bid /= WPIECES;
+    const int kc = bid % nchunks;
+    const int nt = bid / nchunks;
+    if (nt >= ntn) return;
+    const int u = pc >> 1, o = nt * 32 + (pc & 1) * 16 + r, k0 = kc * 32 + qd * 8;
+    const uint4 wv = *(const uint4*)(wu + ((size_t)unit_q(u) * Cout + o) * Cin + k0);
+    float f[8];
+    unpack16(wv, f, (bf16_t*)nullptr);
+    for (int b = blockIdx.y; b < nb; b += gridDim.y) {
+        const float on = gain * (out_scale ? out_scale[(size_t)b * Cout + o] : 1.f);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = f[e] * ((in_scale ? in_scale[(size_t)b * Cin + k0 + e] : 1.f) * on);
+        *(uint4*)(out + ((((size_t)b * ntn + nt) * nchunks + kc) * WPIECES + pc) * 512 + (qd * 16 + r) * 8) = pack16(v, (bf16_t*)nullptr);
+    }
+}
+
+}  // namespace
+
+extern "C" int dge_up_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype) {
+    static const bool off = getenv("DGE_NO_UP_PP") != nullptr;
+    if (dtype != DGE_BF16 || off) return 0;
+    if (Cin % 32 != 0 || Cin < 128 || Cout % 32 != 0) return 0;              // (>= 4 chunks: the prologue requests chunks 0 and 1 unconditionally)
+    if (0) return 0;              // (Cin = 64: the streaming kernel's layer; >= 4 chunks per tile here)
+    if ((long long)H * W * Cin * 2 >= (1ll << 31) || (long long)Cin * Cout * 18 >= (1ll << 31)) return 0;
+    if (H < 16 || W < 16) return 0;
+    const long tiles = (long)B * ((H + 13) / 14) * ((W + 29) / 30) * (Cout / 32);
+    static const int min_tiles = getenv("DGE_UP_PP_MIN_TILES") ? atoi(getenv("DGE_UP_PP_MIN_TILES")) : 192;
+    return tiles >= min_tiles ? 1 : 0;
+}
+
+extern "C" int dge_pack_up_pp(const void* w_units, void* out, int Cout, int Cin, const float* in_scale, const float* out_scale, float gain,
+                              int nb, hipStream_t s) {
+    DGE_CHECK(w_units && out, "pack_up_pp: null tensor");
+    DGE_CHECK(Cout % 32 == 0 && Cin % 32 == 0 && nb >= 1, "pack_up_pp: Cout=%d and Cin=%d must be multiples of 32", Cout, Cin);
+    DGE_CHECK(nb == 1 || in_scale || out_scale, "pack_up_pp: per-sample copies need a per-sample scale");
+    const long pieces = (long)(Cout / 32) * (Cin / 32) * WPIECES;
+    hipLaunchKernelGGL(up_pp_pack_kernel, dim3((unsigned)((pieces + 3) / 4), (unsigned)(pieces >= 1024 ? (nb + 1) / 2 : nb)), dim3(256), 0, s,
+                       (const bf16_t*)w_units, (bf16_t*)out, Cout, Cin, in_scale, out_scale, gain, nb);
+    DGE_LAUNCH_CHECK("pack_up_pp");
+    return 0;
+}
+
+extern "C" int dge_up_pp(const void* x, const void* w_img, long long w_bstride, void* y, const float* noise, int noise_bstride,
+                         const float* noise_w, const float* bias, float bias_scale, float gain, int act, int B, int H, int W, int Cin,
+                         int Cout, hipStream_t s) {
+    DGE_CHECK(x && w_img && y, "up_pp: null tensor");
+    DGE_CHECK(dge_up_pp_supported(B, H, W, Cin, Cout, DGE_BF16), "up_pp: %dx%d Cin=%d Cout=%d B=%d is not a shape dge_up_pp_supported() accepts", H, W, Cin, Cout, B);
+    DGE_CHECK(!noise || noise_w, "up_pp: noise needs its weight");
+    DGE_CHECK(gain > 0.f, "up_pp: the gain is folded into the weights / noise / bias and must be positive");
+    UPParams p;
+    p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_img; p.y = (bf16_t*)y; p.w_bstride = w_bstride * 2;
+    p.bias = bias; p.noise = noise; p.noise_w = noise_w;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.noise_bstride = noise_bstride; p.act = act;
+    p.bias_scale = bias_scale; p.gain = gain;
+    p.tiles_x = (W + 29) / 30; p.tiles_y = (H + 13) / 14;                   // 60 x 28 finished outputs per tile; tile (tx, ty) reads input positions 30 tx - 1 .. + 31, 14 ty - 1 .. + 15
+    p.ntn = Cout / 32; p.nchunks = Cin / 32;
+    p.dbg = dge_env().up_dbg;
+    const long tiles = (long)p.tiles_x * p.tiles_y * B * p.ntn;
+    int cus = 256;
+    {
+        static int cu_of_dev[64] = {0};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (cu_of_dev[dev] == 0) {
+                int n = 0;
+                cu_of_dev[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n >= 8) ? n / 8 * 8 : 256;
+            }
+            cus = cu_of_dev[dev];
+        }
+    }
+    const long grid = tiles < cus ? (tiles + 7) / 8 * 8 : cus;
+    dge_note_kernel("up_pp<bf16,16,32,32>");
+    if (p.dbg) hipLaunchKernelGGL((up_pp_kernel<true>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((up_pp_kernel<false>), dim3((unsigned)grid), dim3(512), 0, s, p);
+    DGE_LAUNCH_CHECK("up_pp");
+    return 0;
+}

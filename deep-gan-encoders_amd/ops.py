@@ -469,6 +469,52 @@ def conv_in_bwd_fromrgb_supported(B, H, W, cin, cout, dtype):
     return bool(lib().dge_conv_in_bwd_fromrgb_supported(int(B), int(H), int(W), int(cin), int(cout), 3, int(dtype)))
 
 
+def up_pp_supported(B, H, W, cin, cout, dtype):
+    """True when an up layer of this shape runs on the ping-pong kernel of csrc/up_pp.hip (Cin >= 128; H, W = the INPUT grid)"""
+    return bool(lib().dge_up_pp_supported(int(B), int(H), int(W), int(cin), int(cout), int(dtype)))
+
+
+def pack_up_pp(w_units, cout, cin, in_scale=None, out_scale=None, gain=1.0, out=None):
+    """Weight image of up_pp from pack_upconv_weight's bf16 [9, Cout, Cin] units: one shared copy, or - with in_scale [B, Cin] /
+    out_scale [B, Cout] - B copies with style, demodulation and gain folded in (stylegan2_generator.py:858-875).  [nb, 9*Cin*Cout] bf16."""
+    if w_units.dtype != torch.bfloat16:
+        raise DgeError("pack_up_pp: expects the bf16 units of pack_upconv_weight")
+    nb = 1
+    for t in (in_scale, out_scale):
+        if t is not None:
+            nb = t.shape[0]
+    if out is None:
+        out = torch.empty((nb, 9 * cin * cout), dtype=torch.bfloat16, device=w_units.device)
+    check(lib().dge_pack_up_pp(_p(w_units), _p(out), int(cout), int(cin), _f32(in_scale), _f32(out_scale), float(gain), nb, _stream()),
+          "dge_pack_up_pp")
+    return out
+
+
+def up_pp(x, w_img, cout, bias=None, bias_scale=1.0, noise=None, noise_w=None, act=ACT_NONE, gain=1.0):
+    """x [B,H,W,Cin] bf16 -> y [B,2H,2W,cout]: conv_transpose2d(stride 2) + 4x4 FIR + noise / bias / activation (dge_up_pp) with the
+    per-sample weight image of pack_up_pp (style, demodulation and gain folded in)."""
+    B, H, W, Cin = x.shape
+    if x.dtype != torch.bfloat16 or not x.is_cuda:
+        raise DgeError("up_pp: bf16 CUDA activations only (the HIP path has no CPU fallback)")
+    y = torch.empty((B, 2 * H, 2 * W, cout), dtype=x.dtype, device=x.device)
+    nbs = 0 if (noise is None or noise.shape[0] == 1) else 4 * H * W
+    if noise_w is not None and noise_w.numel() != 1:
+        raise DgeError("up_pp: one noise strength per layer (stylegan2_generator.py:911-916)")
+    wbs = 0 if w_img.shape[0] == 1 else w_img.stride(0)
+
+    def launch():
+        check(lib().dge_up_pp(_p(x), _p(w_img), int(wbs), _p(y), _f32(noise), nbs, _f32(noise_w), _f32(bias), float(bias_scale),
+                              float(gain), int(act), B, H, W, Cin, int(cout), _stream()), "dge_up_pp")
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); launch(); e1.record()
+        abytes = sum(t.numel() * t.element_size() for t in (x, y)) + 18 * Cin * cout * B
+        PROFILE.append((e0, e1, 2.0 * 9.0 * Cin * cout * H * W * B, (B, H, W, Cin, cout, 3, "upfir", False), abytes))
+    else:
+        launch()
+    return y
+
+
 def conv_pp_supported(B, H, W, cin, cout, dtype):
     """True when a 3x3 stride-1 launch of this shape runs on the ping-pong implicit GEMM (csrc/conv_pp.hip: C >= 128 at 64^2 .. 256^2)"""
     return bool(lib().dge_conv_pp_supported(int(B), int(H), int(W), int(cin), int(cout), int(dtype)))

@@ -39,6 +39,7 @@ def _dt(compute_dtype):
 import os as _os
 _PP_GEN = not _os.environ.get("DGE_NO_PP_GEN")
 _DENSE_CHAIN = _os.environ.get("DGE_DENSE_CHAIN") == "1"
+_UP_PP = not _os.environ.get("DGE_NO_UP_PP_GEN")
 
 
 class DenseBlock(nn.Module):
@@ -194,6 +195,14 @@ class ModulateConvBlock(nn.Module):
         wu = self._prepared_up(dt)
         if wu is not None:
             assert rgb is None
+            B, H, W, _ = x.shape
+            if (_UP_PP and s is not None and d is not None and (noise is None or nw.numel() == 1)
+                    and ops.up_pp_supported(B, H, W, self.in_c, self.out_c, dt)):
+                # MFMA-bound up layers (Cin >= 128): fused modulation (:858-875) folded into one weight image per sample, ping-pong
+                # implicit GEMM with the FIR in registers (csrc/up_pp.hip)
+                wimg = ops.pack_up_pp(wu, self.out_c, self.in_c, in_scale=s, out_scale=d, gain=self.gain)
+                return ops.up_pp(x, wimg, self.out_c, bias=self.bias, bias_scale=self.bscale, noise=noise, noise_w=nw, act=self.act,
+                                 gain=self.gain)
             return ops.upconv_fir(x, wu, self.out_c, in_scale=s, out_scale=d, bias=self.bias, bias_scale=self.bscale,
                                   noise=noise, noise_w=nw, act=self.act, gain=self.gain)
         B, H, W, _ = x.shape

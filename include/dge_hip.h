@@ -465,6 +465,20 @@ int dge_upconv_fir(const void* x, const void* w_packed, void* y, const float* in
                    const float* noise, int noise_bstride, const float* noise_w, int noise_w_stride, const float* bias,
                    float bias_scale, float gain, int act, int B, int H, int W, int Cin, int Cout, int dtype, dge_stream_t stream);
 
+/* ---- The same up layer as a ping-pong implicit GEMM for the MFMA-bound layers (csrc/up_pp.hip; Cin >= 128: layers 7 / 9 / 11 / 13
+ * of the 1024^2 generator).  stylegan2_generator.py:879-896 conv_transpose2d + FIR in the reference's FUSED-modulation form
+ * (:858-875): dge_pack_up_pp folds style, demodulation and gain into one weight image per sample,
+ * W'[b][unit][o][i] = bf16(w_units[unit][o][i] * in_scale[b][i] * out_scale[b][o] * gain) with w_units = dge_pack_upconv_weight's
+ * [9][Cout][Cin] bf16 tensor (9*Cin*Cout elements per copy; nb = 1 shared copy or B copies); dge_up_pp runs
+ * y[b] = act(FIR(conv_transpose2d(x[b], W'[b])) + noise*noise_w*gain + bias*bias_scale*gain)   (:908-921), x [B,H,W,Cin] ->
+ * y [B,2H,2W,Cout], bf16.  w_bstride: bf16 elements between the samples' images (0 = shared).  Shapes per dge_up_pp_supported(). */
+int dge_up_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype);
+int dge_pack_up_pp(const void* w_units, void* out, int Cout, int Cin, const float* in_scale, const float* out_scale, float gain,
+                   int nb, dge_stream_t stream);
+int dge_up_pp(const void* x, const void* w_img, long long w_bstride, void* y, const float* noise, int noise_bstride,
+              const float* noise_w, const float* bias, float bias_scale, float gain, int act, int B, int H, int W, int Cin, int Cout,
+              dge_stream_t stream);
+
 /* ---- Ping-pong implicit GEMM for the MFMA-bound 3x3 stride-1 layers (csrc/conv_pp.hip) -----------------------------------
  * ModulateConvBlock.forward, stride-1 branch, in the reference's FUSED-modulation form (stylegan2_generator.py:858-875: the
  * style multiplies the weight, the demodulation divides it, one weight per sample; :898-904 conv; :911-921 noise, bias,

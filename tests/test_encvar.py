@@ -156,17 +156,17 @@ def test_hip_e_pg_gradients_vs_reference_golden(cd):
     loss = (z * R.randn("ep.gz", tuple(z.shape), 64).cuda()).sum()
     loss.backward()
     meas("encpg_loss", cd=cd, rel=abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"])))
-    assert abs(float(loss.detach()) - float(g["loss"])) < (2e-4 if cd == "f32" else 0.1) * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < (2e-5 if cd == "f32" else 1e-2) * abs(float(g["loss"]))      # measured 4.3e-6 / 6.3e-3
     # f32: 1e-4 per tensor (measured 3.0e-6).  The fixture's biases keep every leaky-relu pre-activation >= 1e-4 * max away from the
     # kink (tools/gen_golden.py: clear_kinks) and the run is deterministic (tests/conftest.py): no slope can flip against the
     # reference, and the number is the same on every run.  (Before: 2e-3 .. 1.1e-2 from run to run, one flip = ~5e-3 of a 64-element sum.)
     # bf16: storage rounding (2^-9 relative) is 40x the fixture's kink margin, so slopes DO flip against the f32 reference and the
     # small reductions (64-element bias / noise-weight sums) move by 10-20 % each; the run is deterministic, the bounds are 1.5x
-    # the values it gives: worst tensor 0.129 (decode_block.1.noise_weight_1), all tensors as one vector L2 0.056 / cosine 0.9985.
+    # the values it gives: worst tensor 0.225 (decode_block.1.bias_1), all tensors as one vector L2 0.156 / cosine 0.988.
     if cd == "f32":
         _check_grads({k: p.grad for k, p in E.named_parameters()}, g, 1e-4, 40, tiny_abs=5e-2)
     else:
-        _check_grads({k: p.grad for k, p in E.named_parameters()}, g, 0.2, 40, tiny_abs=0.5, global_tol=(0.085, 0.9975))
+        _check_grads({k: p.grad for k, p in E.named_parameters()}, g, 0.34, 40, tiny_abs=0.5, global_tol=(0.24, 0.98))
 
 
 # ---------------------------------------------------------------------------- E_BIG
@@ -243,11 +243,10 @@ def test_hip_e_blur_gradients_vs_reference_golden(cd):
     x, w = E(img, noises=noises)
     loss = (x * R.randn("eb.gx", tuple(x.shape), 63).cuda()).sum() + (w * R.randn("eb.gw", tuple(w.shape), 63).cuda()).sum()
     loss.backward()
-    # (the functional is a signed sum with heavy cancellation: |loss| = 17 against sum|terms| ~ 1e3: one bf16 rounding of the terms
-    #  is ~ 4e-3 * 1e3 / 17 = 0.24 of |loss|; runs land at 0.02 .. 0.11 depending on the order of the f32 atomics - one of
-    #  ~12 runs of an unchanged build exceeded the former 0.1)
+    # (deterministic run: 5.6e-6 in f32, 2.0e-3 in bf16 - the functional is a signed sum with heavy cancellation, |loss| = 17 against
+    #  sum|terms| ~ 1e3; in the default mode the bf16 value moved between 0.02 and 0.11 with the order of the f32 atomics)
     meas("encblur_loss", cd=cd, rel=abs(float(loss) - float(g["loss"])) / abs(float(g["loss"])))
-    assert abs(float(loss) - float(g["loss"])) < (2e-4 if cd == "f32" else 0.25) * abs(float(g["loss"]))
+    assert abs(float(loss) - float(g["loss"])) < (2e-5 if cd == "f32" else 4e-3) * abs(float(g["loss"]))
     named = {k: p.grad for k, p in E.named_parameters()}
     if cd == "f32":
         # kink-free fixture + deterministic run (see test_hip_e_pg_gradients_vs_reference_golden): measured 2.1e-4 per tensor
@@ -300,10 +299,10 @@ def test_hip_e_big_gradients_vs_reference_golden(cd):
     loss = (z * R.randn("ebg.gz", tuple(z.shape), 82).cuda()).sum() + (c_v * R.randn("ebg.gcv", tuple(c_v.shape), 82).cuda()).sum()
     loss.backward()
     meas("encbig_loss", cd=cd, rel=abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"])))
-    assert abs(float(loss.detach()) - float(g["loss"])) < (2e-4 if cd == "f32" else 0.1) * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) < (2e-5 if cd == "f32" else 1e-3) * abs(float(g["loss"]))      # measured 2.3e-6 / 2.5e-4
     # see test_hip_e_pg_gradients_vs_reference_golden (kink-free fixture, deterministic run).  f32: measured 5.7e-6;
-    # bf16: worst tensor 0.225 (decode_block.1.bias_1), all tensors as one vector L2 0.156 / cosine 0.988
+    # bf16: worst tensor 0.129 (decode_block.1.noise_weight_1), all tensors as one vector L2 0.056 / cosine 0.9985
     if cd == "f32":
         _check_grads({k: p.grad for k, p in E.named_parameters()}, g, 1e-4, 60)
     else:
-        _check_grads({k: p.grad for k, p in E.named_parameters()}, g, 0.35, 60, global_tol=(0.24, 0.98))
+        _check_grads({k: p.grad for k, p in E.named_parameters()}, g, 0.2, 60, global_tol=(0.085, 0.9975))
