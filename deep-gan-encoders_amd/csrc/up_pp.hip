@@ -72,9 +72,11 @@ constexpr int HPIECES = (HPIX + 15) / 16;            // 36
 constexpr int HPW = (HPIECES + 7) / 8;               // 5 halo requests per wave and chunk
 constexpr int WPIECES = 18, WPW = 3;                 // weight block of a chunk: 9 units x 2 pieces; 3 requests per wave (6 of 24 out of range)
 constexpr int WBLK = WPIECES * 1024;                 // 18,432 B per (sample, channel tile, chunk)
-// LDS map: halo 0 | weight slot 0 | halo 1 (at 64 KiB: the buffer toggle is one XOR) | weight slots 1, 2
-constexpr int H1_OFF = 65536, W0_OFF = 36864, W1_OFF = 102400, W2_OFF = 126976, UP_LDS = 163840;
-static_assert(HPW * 8 * 1024 <= W0_OFF + 4096 && W0_OFF + 24576 <= H1_OFF && W2_OFF + 24576 <= UP_LDS, "LDS map");
+// LDS map: halo 0 (40 KiB) | weight slot 0 (24 KiB) | halo 1 (at 64 KiB: the buffer toggle is one XOR) | weight slots 1, 2
+// (a halo tile is requested as 40 pieces, the last four all out of range: they WRITE ZEROS, so they need LDS of their own; likewise the
+//  24 requested pieces of an 18-piece weight block)
+constexpr int H1_OFF = 65536, W0_OFF = 40960, W1_OFF = 106496, W2_OFF = 131072, UP_LDS = 163840;
+static_assert(HPW * 8 * 1024 <= W0_OFF && W0_OFF + 24576 <= H1_OFF && H1_OFF + HPW * 8 * 1024 <= W1_OFF && W1_OFF + 24576 <= W2_OFF && W2_OFF + 24576 <= UP_LDS, "LDS map");
 constexpr int EXCH_BYTES = 8 * 4 * 64 * 64;          // epilogue: the 4 t rows x 16 words per lane of every wave = 128 KiB from offset 0
 static_assert(EXCH_BYTES <= UP_LDS, "exchange area");
 // slot-local unit order of a chunk's weight block: A = ee eo oe oo of tap (m, n) | B = ee eo of (m-1, n), ee of (m-1, n-1) | C = ee oe of (m, n-1)
@@ -141,10 +143,10 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
             const auto p = P();
             const unsigned xbytes = (unsigned)(p->H * p->W) * (unsigned)p->Cin * 2u;
             rs = make_rsrc((unsigned long long)p->x + (unsigned long long)b * xbytes, xbytes);
-            // (the SGPR offset of a buffer access takes no part in the range check: the weight descriptor spans ONE chunk block, the chunk
-            //  is the scalar offset; a lane's offset beyond the block = a piece that does not exist = no traffic)
+            // (the descriptor spans the tile's whole weight image, the chunk is the scalar offset - measured on gfx950: the scalar offset
+            //  DOES take part in the range check; the six pieces of a request round that do not exist carry an out-of-range lane offset)
             rw = make_rsrc((unsigned long long)p->w + (unsigned long long)b * (unsigned long long)p->w_bstride +
-                           (unsigned long long)nt * nchunks * (unsigned long long)WBLK, (unsigned)WBLK);
+                           (unsigned long long)nt * nchunks * (unsigned long long)WBLK, (unsigned)nchunks * (unsigned)WBLK);
             int lane_o = lane;
             asm volatile("" : "+v"(lane_o));
 #pragma unroll
@@ -286,6 +288,33 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
         const int OH = 2 * p->H, OW = 2 * p->W, Cout = p->Cout;
         const int R = 2 * (y0 + 2 * wave);                                  // t row of (input row 0 of the wave, py 0); y rows R .. R + 3
         const int Xe = 2 * (x0 + l31);                                      // this lane's even output column
+        if (DBG && (dbg & 32)) {                    // timing aid: no epilogue at all (K loop + tile prologue only)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int ph = 0; ph < 4; ph++) asm volatile("" :: "v"(acc[i][ph][0]), "v"(acc[i][ph][15]));
+            tile += stride;
+            if (tile >= tile_end) break;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            continue;
+        }
+        if (DBG && (dbg & 16)) {                    // development aid: the raw transposed-conv result t instead of the finished output
+            bf16_t* yb0 = p->y + (size_t)b * OH * OW * Cout;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int ph = 0; ph < 4; ph++) {
+                    const int oy = R + 2 * i + (ph >> 1), ox = Xe + (ph & 1);
+                    if ((unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) yb0[((size_t)oy * OW + ox) * Cout + nt * 32 + 16 * (r >> 3) + 8 * kh + (r & 7)] = f2bf(acc[i][ph][r]);
+                    }
+                }
+            tile += stride;
+            if (tile >= tile_end) break;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            continue;
+        }
         // noise of this lane's 4 rows x 2 columns (requested before the exchange, consumed at the end)
         f2_t nz[4];
         const float nwv = p->noise ? p->noise_w[0] * p->gain : 0.f;
@@ -425,15 +454,10 @@ __global__ __launch_bounds__(256) void up_pp_pack_kernel(const bf16_t* __restric
 }  // namespace
 
 extern "C" int dge_up_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype) {
-    static const bool off = getenv("DGE_NO_UP_PP") != nullptr;
-    if (dtype != DGE_BF16 || off) return 0;
+    if (dtype != DGE_BF16 || B < 1) return 0;
     if (Cin % 32 != 0 || Cin < 128 || Cout % 32 != 0) return 0;              // (>= 4 chunks: the prologue requests chunks 0 and 1 unconditionally)
-    if (0) return 0;              // (Cin = 64: the streaming kernel's layer; >= 4 chunks per tile here)
-    if ((long long)H * W * Cin * 2 >= (1ll << 31) || (long long)Cin * Cout * 18 >= (1ll << 31)) return 0;
-    if (H < 16 || W < 16) return 0;
-    const long tiles = (long)B * ((H + 13) / 14) * ((W + 29) / 30) * (Cout / 32);
-    static const int min_tiles = getenv("DGE_UP_PP_MIN_TILES") ? atoi(getenv("DGE_UP_PP_MIN_TILES")) : 192;
-    return tiles >= min_tiles ? 1 : 0;
+    if ((long long)H * W * Cin * 2 >= (1ll << 31) || (long long)Cin * Cout * 18 >= (1ll << 31) || (long long)4 * H * W * Cout * 2 >= (1ll << 32)) return 0;
+    return (H >= 8 && W >= 8) ? 1 : 0;
 }
 
 extern "C" int dge_pack_up_pp(const void* w_units, void* out, int Cout, int Cin, const float* in_scale, const float* out_scale, float gain,

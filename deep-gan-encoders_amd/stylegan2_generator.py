@@ -39,7 +39,7 @@ def _dt(compute_dtype):
 import os as _os
 _PP_GEN = not _os.environ.get("DGE_NO_PP_GEN")
 _DENSE_CHAIN = _os.environ.get("DGE_DENSE_CHAIN") == "1"
-_UP_PP = not _os.environ.get("DGE_NO_UP_PP_GEN")
+_UP_PP = _os.environ.get("DGE_UP_PP") == "1"      # opt-in (round 5: equal to upconv_fir at batch 8)
 
 
 class DenseBlock(nn.Module):

@@ -194,6 +194,46 @@ def test_generator_up_layer_fullsize(cin, cout, Rin, B, kernel):
     _up_layer_case(cin, cout, Rin, B, kernel)
 
 
+UP_PP_LAYERS = [
+    (512, 512, 32, 32, 8),        # layer7
+    (512, 256, 64, 64, 8),        # layer9
+    (256, 128, 128, 128, 8),      # layer11
+    (128, 64, 256, 256, 8),       # layer13
+    (128, 96, 70, 66, 2),         # ragged: tiles cut on both axes (28 x 60 outputs per tile), 3 channel tiles
+    (160, 32, 17, 45, 3),         # 5 K chunks, one channel tile, odd sizes
+]
+
+
+@pytest.mark.parametrize("cin,cout,Hin,Win,B", UP_PP_LAYERS)
+def test_up_layer_ping_pong_kernel(cin, cout, Hin, Win, B):
+    """csrc/up_pp.hip (dge_pack_up_pp + dge_up_pp: the up layer as a ping-pong implicit GEMM with the FIR in registers; opt-in with
+    DGE_UP_PP=1) by name at the generator's four MFMA-bound up layers and on ragged shapes, against the same oracle and
+    bounds as the kernels it stands in for (_up_layer_case): ModulateConvBlock.forward, scale_factor 2 (:879-896, :908-921)."""
+    from dge_amd import ops
+    g = _gen(2100 + cin + Hin)
+    x = _act(B, Hin, Win, cin, g)
+    w = _wgt(cout, cin, 3, g)
+    wscale = 1.0 / math.sqrt(9 * cin)
+    s = 1.0 + 0.3 * torch.randn(B, cin, device=DEV, generator=g)
+    d = 0.5 + torch.rand(B, cout, device=DEV, generator=g)
+    noise = torch.randn(1, 2 * Hin, 2 * Win, device=DEV, generator=g)
+    ns = torch.tensor([0.37], device=DEV)
+    bias = 0.2 * torch.randn(cout, device=DEV, generator=g)
+    assert ops.up_pp_supported(B, Hin, Win, cin, cout, ops.BF16)
+    wimg = ops.pack_up_pp(ops.pack_upconv_weight(w, ops.BF16, wscale), cout, cin, in_scale=s, out_scale=d, gain=math.sqrt(2.0))
+    y = ops.up_pp(x, wimg, cout, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=math.sqrt(2.0))
+    assert _kernel() == "up_pp<bf16,16,32,32>"
+    wq = CR.bf16_round(w.cpu() * wscale)
+    for b in SAMPLES(B):
+        a = (_nchw(x, b), wq, s[b:b + 1].cpu(), d[b:b + 1].cpu(), noise.cpu(), 0.37, bias.cpu(), 1.0, 1.0)
+        # (as _up_layer_case: t is kept as bf16 for the FIR; here style / demodulation / gain are folded into the bf16 weights as in
+        #  upconv_stream - one storage rounding more than the oracle's)
+        viol = _one_rounding(_nchw(y, b), CR.upconv_fir(*a, q=CR.bf16_round), slack=4e-3)
+        assert viol <= 0, (b, viol)
+        e = _relmax(_nchw(y, b), CR.upconv_fir(*a))
+        assert e < 8e-3, (b, e)
+
+
 def _up_layer_case(cin, cout, Rin, B, kernel, Win=None, samples=None):
     """ModulateConvBlock.forward, scale_factor 2 (:879-896 conv_transpose2d + FIR, :908-921), through the dispatch the
     generator itself uses (phase form when supported and the output resolution is >= 32, else the folded form)."""
