@@ -219,6 +219,41 @@ def _cbn_cond_grad(ctx, st, g_cond):
     ops.linear_t(g_b.contiguous(), ctx["wof"], g_cond, accumulate=True)
 
 
+import os as _os
+_NO_PACK_GROUP = bool(_os.environ.get("DGE_NO_PACK_GROUP"))
+
+
+def _pack_all(module, sns, dt, dgrad):
+    """Packed copies of the W_eff of every conv `_SN` in `sns` for the coming pass in ONE launch per layout (forward; data gradient
+    when the pass is saved for a backward) instead of one dge_pack_conv_weight launch per conv and pass (round 5 profile of --mtype 4:
+    214 pack launches per step).  The W_eff are the ones sn_prepare() parked on the modules; the packed tensors are allocated on first
+    use and refreshed in place afterwards (same stream: a pass reads them before the next pass rewrites them).  Returns
+    {id(sn): {mode: packed}}; modules whose W_eff is not parked (per-weight path) are left to pack_conv_weight."""
+    out, entries = {}, {ops.PACK_FWD: [], ops.PACK_DGRAD: []}
+    if _NO_PACK_GROUP:
+        return out
+    cache = module.__dict__.setdefault("_pk_cache", {})
+    for sn in sns:
+        prep = sn.__dict__.get("_prep")
+        if prep is None or prep[0].dim() != 4:
+            continue
+        w = prep[0]
+        if not w.is_contiguous():
+            continue
+        for mode in ((ops.PACK_FWD, ops.PACK_DGRAD) if dgrad else (ops.PACK_FWD,)):
+            key = (id(sn), mode, dt)
+            pk = cache.get(key)
+            if pk is None:
+                pk = cache[key] = ops.pack_conv_weight(w, mode, dt, 1.0)        # first pass: allocates (and packs)
+            else:
+                entries[mode].append((w, mode, dt, 1.0, pk))
+            out.setdefault(id(sn), {})[mode] = pk
+    for mode, ent in entries.items():
+        if ent:
+            module.__dict__["_pk_scratch_%d" % mode] = ops.pack_conv_weights_multi(ent, module.__dict__.get("_pk_scratch_%d" % mode))
+    return out
+
+
 class GenBlock(nn.Module):
     def __init__(self, in_size, out_size, condition_vector_dim, reduction_factor=4, up_sample=False, n_stats=51, eps=1e-12):
         super().__init__()
@@ -235,16 +270,19 @@ class GenBlock(nn.Module):
         self.bn_3 = BigGANBatchNorm(mid, condition_vector_dim, n_stats, eps, True)
         self.conv_3 = _SN((out_size, mid, 1, 1), True, eps)
 
-    def run(self, x, cond, truncation, dt, training, saved=None):
+    def run(self, x, cond, truncation, dt, training, saved=None, packed=None):
         recs = []
 
         def conv(sn, bn, inp, k, cout, **kw):
             ctx = {} if saved is not None else None
             a, b = bn.affine(truncation, cond, training, ctx)
             w = sn.effective_weight(training).contiguous()
-            wp = ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0)
+            pk = (packed or {}).get(id(sn), {})
+            wp = pk.get(ops.PACK_FWD)
+            if wp is None:
+                wp = ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0)
             if saved is not None:
-                recs.append(dict(inp=inp, a=a, b=b, w=w, k=k, ctx=ctx))
+                recs.append(dict(inp=inp, a=a, b=b, w=w, k=k, ctx=ctx, wpd=pk.get(ops.PACK_DGRAD)))
             return ops.conv2d(inp, wp, cout, k, in_scale=a, in_shift=b, in_relu=True, bias=sn.bias.detach(), **kw)
         t = conv(self.conv_0, self.bn_0, x, 1, self.mid)
         t = conv(self.conv_1, self.bn_1, t, 3, self.mid, in_up2=self.up_sample)
@@ -261,7 +299,8 @@ class GenBlock(nn.Module):
         for idx in (3, 2, 1, 0):
             r = recs[idx]
             cin = r["inp"].shape[3]
-            gu = ops.conv2d(g, ops.pack_conv_weight(r["w"], ops.PACK_DGRAD, dt, 1.0), cin, r["k"])
+            wpd = r.get("wpd")
+            gu = ops.conv2d(g, wpd if wpd is not None else ops.pack_conv_weight(r["w"], ops.PACK_DGRAD, dt, 1.0), cin, r["k"])
             if idx == 1 and self.up_sample:
                 gu, _ = ops.nearest_up2_bwd(gu)
             g, st = ops.affine_relu_bwd(gu, r["inp"], r["a"], r["b"])
@@ -279,11 +318,13 @@ class SelfAttn(nn.Module):
         self.snconv1x1_o_conv = _SN((in_channels, in_channels // 2, 1, 1), False, eps)
         self.gamma = nn.Parameter(torch.zeros(1))
 
-    def run(self, x, dt, training, saved=None):
+    def run(self, x, dt, training, saved=None, packed=None):
         B, H, W, Cc = x.shape
-        ws = [sn.effective_weight(training).contiguous() for sn in (self.snconv1x1_theta, self.snconv1x1_phi, self.snconv1x1_g,
-                                                                     self.snconv1x1_o_conv)]
-        pk = lambda w: ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0)
+        sns = (self.snconv1x1_theta, self.snconv1x1_phi, self.snconv1x1_g, self.snconv1x1_o_conv)
+        ws = [sn.effective_weight(training).contiguous() for sn in sns]
+        pks = [(packed or {}).get(id(sn), {}) for sn in sns]
+        fwd = {id(w): pk.get(ops.PACK_FWD) for w, pk in zip(ws, pks)}
+        pk = lambda w: fwd[id(w)] if fwd.get(id(w)) is not None else ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0)
         theta = ops.conv2d(x, pk(ws[0]), Cc // 8, 1)
         phi_pre = ops.conv2d(x, pk(ws[1]), Cc // 8, 1)
         phi = ops.maxpool2(phi_pre)
@@ -305,7 +346,8 @@ class SelfAttn(nn.Module):
             probs.append(P)
         gam = self.gamma.detach().reshape(1, 1).expand(B, Cc).contiguous()
         if saved is not None:
-            saved.append(("attn", self, dict(theta=theta, phi_pre=phi_pre, phi=phi, g_pre=g_pre, g=g, ws=ws, probs=probs)))
+            saved.append(("attn", self, dict(theta=theta, phi_pre=phi_pre, phi=phi, g_pre=g_pre, g=g, ws=ws, probs=probs,
+                                             wpd=[pk_.get(ops.PACK_DGRAD) for pk_ in pks])))
         return ops.conv2d(o, pk(ws[3]), Cc, 1, out_scale=gam, addend=x, add_scale=1.0)
 
     def backward(self, rec, g_out, dt):
@@ -316,7 +358,8 @@ class SelfAttn(nn.Module):
         B, H, W, D = theta.shape
         M, DV, Cc = phi.shape[1] * phi.shape[2], gv.shape[3], 8 * D
         wth, wph, wg, wo = rec["ws"]
-        pkd = lambda w: ops.pack_conv_weight(w, ops.PACK_DGRAD, dt, 1.0)
+        dg = {id(w): p_ for w, p_ in zip(rec["ws"], rec.get("wpd") or [None] * 4)}
+        pkd = lambda w: dg[id(w)] if dg.get(id(w)) is not None else ops.pack_conv_weight(w, ops.PACK_DGRAD, dt, 1.0)
         pkf = lambda m: ops.pack_conv_weight(m.float().contiguous().view(m.shape[0], m.shape[1], 1, 1), ops.PACK_FWD, dt, 1.0)
         gam = self.gamma.detach().reshape(1, 1).expand(B, DV).contiguous()
         g_o = ops.conv2d(g_out, pkd(wo), DV, 1, out_scale=gam)                     # [B,H,W,DV]
@@ -363,12 +406,21 @@ class Generator(nn.Module):
         ch = self.config.channel_width
         sn_prepare(self, training)
         sn_cbn_linears(self, cond_vector)
+        convs = self.__dict__.get("_conv_sns")
+        if convs is None:
+            convs = []
+            for layer in self.layers:
+                convs += [layer.conv_0, layer.conv_1, layer.conv_2, layer.conv_3] if isinstance(layer, GenBlock) else \
+                    [layer.snconv1x1_theta, layer.snconv1x1_phi, layer.snconv1x1_g, layer.snconv1x1_o_conv]
+            self.__dict__["_conv_sns"] = convs
+        packed = _pack_all(self, convs, dt, saved is not None)
         wz = self.gen_z.effective_weight(training).contiguous()
         z = ops.linear(cond_vector, wz, self.gen_z.bias.detach())   # [B, 4*4*16ch] == NHWC
         x = ops.nchw_to_nhwc(z.view(B, 4 * 4 * 16 * ch, 1, 1), B, dt).view(B, 4, 4, 16 * ch)
         layers = [] if saved is not None else None
         for layer in self.layers:
-            x = layer.run(x, cond_vector, truncation, dt, training, layers) if isinstance(layer, GenBlock) else layer.run(x, dt, training, layers)
+            x = layer.run(x, cond_vector, truncation, dt, training, layers, packed) if isinstance(layer, GenBlock) else \
+                layer.run(x, dt, training, layers, packed)
         a, b = self.bn.affine(truncation, None, training)
         a, b = a.expand(B, -1).contiguous(), b.expand(B, -1).contiguous()
         w = self.conv_to_rgb.effective_weight(training)[:16].contiguous()            # only channels 0..2 are used (:253)
