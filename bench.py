@@ -298,7 +298,7 @@ def main():
         # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
         traffic, tsrc = None, None
         # (this round's file only: a file of an earlier round describes other kernels - without it the field is null)
-        tname = "r04_conv_traffic.json"
+        tname = "r05_conv_traffic.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and a.mtype == 2 and a.img_size == 1024 and a.batch == 8 and a.dtype == "bf16":
             with open(tpath) as f:

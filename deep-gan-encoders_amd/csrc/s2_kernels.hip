@@ -235,43 +235,6 @@ __global__ void linear_kernel(const float* __restrict__ x, int ldx, const float*
     }
 }
 
-// The same layer with the batch folded into the wave: one wave per output o computes up to 8 samples from ONE read of the weight row
-// (linear_kernel reads the row once per sample: B * O waves; here O waves per group of 8 samples - the mapping network's eight
-// 512 x 512 layers at batch 8 are 16 x 5.6 us per generator pass in that form).  Per (b, o) the arithmetic is linear_kernel's
-// (the same lane-strided partial sums in the same order, wave_sum, scale / bias / activation / gain): bit-identical results.
-__global__ void linear_cols_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
-                                   const float* __restrict__ bias, float* __restrict__ y, int ldy, int B, int I, int O,
-                                   float wscale, float bscale, float add, int act, float gain, int square) {
-    const int o = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (o >= O) return;
-    const int b0 = blockIdx.y * 8, nb = min(8, B - b0);
-    const float* wr = W + (size_t)o * I;
-    float s[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) s[j] = 0.f;
-    for (int i = lane; i < I; i += 64) {
-        const float wv = wr[i];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (j < nb) { float xv = x[(size_t)(b0 + j) * ldx + i]; if (square) xv *= xv; s[j] += xv * wv; }
-        }
-    }
-    const float bb = bias ? bias[o] * bscale : 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        if (j < nb) {                                   // (wave-uniform)
-            const float t = wave_sum(s[j]);
-            if (lane == 0) {
-                float v = t * wscale + bb + add;
-                if (act == LIN_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
-                else if (act == LIN_ACT_RELU) v = v > 0.f ? v : 0.f;
-                else if (act == LIN_ACT_RSQRT) v = rsqrtf(v);
-                y[(size_t)(b0 + j) * ldy + o] = v * gain;
-            }
-        }
-    }
-}
-
 // A chain of dense layers in ONE launch (the mapping network: pixel norm + 8 DenseBlocks of 512, :199-278 / :925-996; 16 launches of
 // ~5.6 us per generator forward before).  One workgroup per sample, 16 waves; the activations ping-pong through LDS; wave v computes
 // outputs v, v + 16, ... with exactly linear_kernel's arithmetic (lane-strided partial sums, wave_sum, scale / bias / act / gain), so
@@ -636,13 +599,6 @@ extern "C" int dge_weight_sumsq(const float* w_oihw, float* wsq, int cout, int c
 extern "C" int dge_linear(const float* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int I, int O,
                           float wscale, float bscale, float add, int act, float gain, int square_input, hipStream_t s) {
     DGE_CHECK(B > 0 && I > 0 && O > 0, "linear: bad shape");
-    static const bool no_cols = getenv("DGE_NO_LINEAR_COLS") != nullptr;
-    if (B >= 2 && O >= 256 && !no_cols) {           // enough outputs to fill the chip with one wave per output: fold the batch into the wave
-        hipLaunchKernelGGL(linear_cols_kernel, dim3((unsigned)((O + 3) / 4), (unsigned)((B + 7) / 8)), dim3(256), 0, s, x, ldx, w, bias, y, ldy,
-                           B, I, O, wscale, bscale, add, act, gain, square_input);
-        DGE_LAUNCH_CHECK("linear_cols");
-        return 0;
-    }
     const long waves = (long)B * O;
     hipLaunchKernelGGL(linear_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, x, ldx, w, bias, y, ldy, B, I, O,
                        wscale, bscale, add, act, gain, square_input);

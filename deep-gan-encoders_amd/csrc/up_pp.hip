@@ -72,12 +72,13 @@ constexpr int HPIECES = (HPIX + 15) / 16;            // 36
 constexpr int HPW = (HPIECES + 7) / 8;               // 5 halo requests per wave and chunk
 constexpr int WPIECES = 18, WPW = 3;                 // weight block of a chunk: 9 units x 2 pieces; 3 requests per wave (6 of 24 out of range)
 constexpr int WBLK = WPIECES * 1024;                 // 18,432 B per (sample, channel tile, chunk)
+constexpr int NSTORE = 16;                           // stores of one epilogue, per wave (4 rows x 2 columns x 2 channel runs)
 // LDS map: halo 0 (40 KiB) | weight slot 0 (24 KiB) | halo 1 (at 64 KiB: the buffer toggle is one XOR) | weight slots 1, 2
 // (a halo tile is requested as 40 pieces, the last four all out of range: they WRITE ZEROS, so they need LDS of their own; likewise the
 //  24 requested pieces of an 18-piece weight block)
 constexpr int H1_OFF = 65536, W0_OFF = 40960, W1_OFF = 106496, W2_OFF = 131072, UP_LDS = 163840;
 static_assert(HPW * 8 * 1024 <= W0_OFF && W0_OFF + 24576 <= H1_OFF && H1_OFF + HPW * 8 * 1024 <= W1_OFF && W1_OFF + 24576 <= W2_OFF && W2_OFF + 24576 <= UP_LDS, "LDS map");
-constexpr int EXCH_BYTES = 8 * 4 * 64 * 64;          // epilogue: the 4 t rows x 16 words per lane of every wave = 128 KiB from offset 0
+constexpr int EXCH_BYTES = 8 * 3 * 64 * 64;          // epilogue: 3 boundary t rows x 16 words per lane and wave = 96 KiB from offset 0
 static_assert(EXCH_BYTES <= UP_LDS, "exchange area");
 // slot-local unit order of a chunk's weight block: A = ee eo oe oo of tap (m, n) | B = ee eo of (m-1, n), ee of (m-1, n-1) | C = ee oe of (m, n-1)
 // -> dge_pack_upconv_weight's q (phase (0,0): q = 2a + b; (0,1): 4 + a; (1,0): 6 + b; (1,1): 8; a / b = row / column shift)
@@ -127,48 +128,51 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
     for (int j = 0; j < WPW; j++) wvoff[j] = (wave + 8 * j) < WPIECES ? (unsigned)((wave + 8 * j) * 1024 + lane * 16) : 0x80000000u;
 
     f32x16_t acc[2][4];                         // [input row of the wave][phase 2 py + px]
-    for (;;) {
-        // ---------------------------------------------------------------- tile
-        int x0, y0, b, nt;
-        {
-            const auto p = P();
-            int id = tile;
-            nt = id % p->ntn; id /= p->ntn;
-            x0 = (id % p->tiles_x) * 30 - 1; id /= p->tiles_x;             // first input column / row of the tile (-1: the zero border)
-            y0 = (id % p->tiles_y) * 14 - 1; b = id / p->tiles_y;
-        }
-        rsrc_t rs, rw;
-        unsigned hoff[HPW];
-        {
-            const auto p = P();
-            const unsigned xbytes = (unsigned)(p->H * p->W) * (unsigned)p->Cin * 2u;
-            rs = make_rsrc((unsigned long long)p->x + (unsigned long long)b * xbytes, xbytes);
-            // (the descriptor spans the tile's whole weight image, the chunk is the scalar offset - measured on gfx950: the scalar offset
-            //  DOES take part in the range check; the six pieces of a request round that do not exist carry an out-of-range lane offset)
-            rw = make_rsrc((unsigned long long)p->w + (unsigned long long)b * (unsigned long long)p->w_bstride +
-                           (unsigned long long)nt * nchunks * (unsigned long long)WBLK, (unsigned)nchunks * (unsigned)WBLK);
-            int lane_o = lane;
-            asm volatile("" : "+v"(lane_o));
+    int x0, y0, b, nt;                          // tile whose requests are being issued / whose chunks run
+    rsrc_t rs, rw;
+    unsigned hoff[HPW];
+    // tile set-up + prologue requests: halo of chunk 0 -> buffer 0, weights of chunks 0 and 1 -> slots 0 and 1.  Called for the first
+    // tile up front and for every next tile from the middle of the previous tile's epilogue (its LDS exchange is over, the FIR
+    // arithmetic and the stores still to come hide the latency; the 16 stores are issued AFTER these requests, so s_waitcnt
+    // vmcnt(16) at the top of the tile means "the prologue has landed" while the stores drain under the first chunks).
+    auto start_tile = [&](int id) {
+        const auto p = P();
+        nt = id % p->ntn; id /= p->ntn;
+        x0 = (id % p->tiles_x) * 30 - 1; id /= p->tiles_x;             // first input column / row of the tile (-1: the zero border)
+        y0 = (id % p->tiles_y) * 14 - 1; b = id / p->tiles_y;
+        const unsigned xbytes = (unsigned)(p->H * p->W) * (unsigned)p->Cin * 2u;
+        rs = make_rsrc((unsigned long long)p->x + (unsigned long long)b * xbytes, xbytes);
+        // (the descriptor spans the tile's whole weight image, the chunk is the scalar offset - measured on gfx950: the scalar offset
+        //  DOES take part in the range check; the six pieces of a request round that do not exist carry an out-of-range lane offset)
+        rw = make_rsrc((unsigned long long)p->w + (unsigned long long)b * (unsigned long long)p->w_bstride +
+                       (unsigned long long)nt * nchunks * (unsigned long long)WBLK, (unsigned)nchunks * (unsigned)WBLK);
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
 #pragma unroll
-            for (int k = 0; k < HPW; k++) {
-                const int hp = (wave + 8 * k) * 16 + (lane_o & 15), qd = lane_o >> 4;
-                const int hr = hp / HC, hc = hp - hr * HC;
-                const int gy = y0 - 1 + hr, gx = x0 - 1 + hc;
-                const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->H) & ((unsigned)gx < (unsigned)p->W);
-                hoff[k] = ok ? (unsigned)(((gy * p->W + gx) * p->Cin + qd * 8) * 2) : 0x80000000u;
-            }
+        for (int k = 0; k < HPW; k++) {
+            const int hp = (wave + 8 * k) * 16 + (lane_o & 15), qd = lane_o >> 4;
+            const int hr = hp / HC, hc = hp - hr * HC;
+            const int gy = y0 - 1 + hr, gx = x0 - 1 + hc;
+            const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->H) & ((unsigned)gx < (unsigned)p->W);
+            hoff[k] = ok ? (unsigned)(((gy * p->W + gx) * p->Cin + qd * 8) * 2) : 0x80000000u;
         }
-        // prologue: halo of chunk 0 -> buffer 0, weights of chunks 0 and 1 -> slots 0 and 1 (everything of the previous tile is drained)
         StaticFor<HPW>::run([&](auto kc_) { constexpr int k = decltype(kc_)::value; dma_buf(hoff[k], rs, 0u, rfl(wm0 + k * 8192)); });
         StaticFor<WPW>::run([&](auto jc) { constexpr int j = decltype(jc)::value; dma_buf(wvoff[j], rw, 0u, rfl(wm0 + W0_OFF + j * 8192)); });
         StaticFor<WPW>::run([&](auto jc) { constexpr int j = decltype(jc)::value; dma_buf(wvoff[j], rw, (unsigned)WBLK, rfl(wm0 + W1_OFF + j * 8192)); });   // (nchunks >= 4)
+    };
+    start_tile(tile);
+    bool first = true;
+    for (;;) {
+        // ---------------------------------------------------------------- tile
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int ph = 0; ph < 4; ph++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[i][ph][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (first) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NSTORE) : "memory");      // the previous tile's stores may still be in flight
+        first = false;
         if (g == 1) asm volatile("s_barrier" ::: "memory");                 // group 1 runs one phase behind group 0
 
         unsigned hx = 0;                          // XOR of the halo buffer being READ (0 / H1_OFF)
@@ -283,19 +287,23 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
         }
 
         // ---------------------------------------------------------------- epilogue (both groups in step again)
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // every request has landed, every fragment read is done
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // every request has landed (the dummies of the last chunks write zeros), every fragment read is done
         const auto p = P();
         const int OH = 2 * p->H, OW = 2 * p->W, Cout = p->Cout;
         const int R = 2 * (y0 + 2 * wave);                                  // t row of (input row 0 of the wave, py 0); y rows R .. R + 3
         const int Xe = 2 * (x0 + l31);                                      // this lane's even output column
+        const int next = tile + stride;
+        const bool has_next = next < tile_end;
         if (DBG && (dbg & 32)) {                    // timing aid: no epilogue at all (K loop + tile prologue only)
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int ph = 0; ph < 4; ph++) asm volatile("" :: "v"(acc[i][ph][0]), "v"(acc[i][ph][15]));
-            tile += stride;
-            if (tile >= tile_end) break;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!has_next) break;
+            tile = next;
+            asm volatile("s_barrier" ::: "memory");
+            start_tile(tile);
+            first = true;
             continue;
         }
         if (DBG && (dbg & 16)) {                    // development aid: the raw transposed-conv result t instead of the finished output
@@ -310,12 +318,15 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                         for (int r = 0; r < 16; r++) yb0[((size_t)oy * OW + ox) * Cout + nt * 32 + 16 * (r >> 3) + 8 * kh + (r & 7)] = f2bf(acc[i][ph][r]);
                     }
                 }
-            tile += stride;
-            if (tile >= tile_end) break;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (!has_next) break;
+            tile = next;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            start_tile(tile);
+            first = true;
             continue;
         }
-        // noise of this lane's 4 rows x 2 columns (requested before the exchange, consumed at the end)
+        // everything the tail reads from memory, before the next tile's requests go out (a load behind them would wait for them):
+        // noise of this lane's 4 rows x 2 columns, bias of its 16 channels
         f2_t nz[4];
         const float nwv = p->noise ? p->noise_w[0] * p->gain : 0.f;
         {
@@ -327,103 +338,128 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                 if (nzb && (unsigned)oy < (unsigned)OH && Xe >= 0 && Xe + 1 < OW) nz[k] = *(const f2_t*)(nzb + (size_t)oy * OW + Xe);
             }
         }
-        // t words of the wave's four t rows ((t[.][2n], t[.][2n+1]) of 16 channels, rounded to bf16) go through LDS: a wave needs the
-        // last row of the wave above and the first two of the wave below, and reading its own rows back per channel half keeps the
-        // epilogue's register footprint (7 rows x 8 words + 64 sums) below the main loop's.  [wave][row][lane][16 words] = 128 KiB.
+        const float bg = p->bias_scale * p->gain;
+        f2_t bia[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (p->bias) { b0 = *(const float4*)(p->bias + nt * 32 + 16 * h + 8 * kh); b1 = *(const float4*)(p->bias + nt * 32 + 16 * h + 8 * kh + 4); }
+            bia[h][0] = f2_t{b0.x * bg, b0.y * bg}; bia[h][1] = f2_t{b0.z * bg, b0.w * bg};
+            bia[h][2] = f2_t{b1.x * bg, b1.y * bg}; bia[h][3] = f2_t{b1.z * bg, b1.w * bg};
+        }
+        // t words of the wave's four t rows: (t[.][2n], t[.][2n+1]) of 16 channels, rounded to bf16 (where upconv_fir / upconv_stream round t)
+        unsigned tw[7][16];                         // row r <-> t row R - 1 + r: [0] the wave above's last row | [1..4] own | [5], [6] the wave below's first two
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int py = 0; py < 2; py++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) tw[1 + 2 * i + py][e] = pack2bf(acc[i][2 * py][e], acc[i][2 * py + 1][e]);
+        // the three boundary rows go through LDS (own rows 0, 1 for the wave above, 3 for the wave below): [wave][slot][lane][16 words] = 96 KiB
         {
-            unsigned char* ex = lds + (size_t)wave * 16384 + lane * 64;
+            unsigned char* ex = lds + (size_t)wave * (3 * 4096) + lane * 64;
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int sl = 0; sl < 3; sl++) {
+                constexpr int rows[3] = {1, 2, 4};
 #pragma unroll
-                for (int py = 0; py < 2; py++)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; q4++) {
-                        unsigned w4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) w4[e] = pack2bf(acc[i][2 * py][4 * q4 + e], acc[i][2 * py + 1][4 * q4 + e]);
-                        *(uint4*)(ex + (2 * i + py) * 4096 + q4 * 16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                    }
+                for (int q4 = 0; q4 < 4; q4++)
+                    *(uint4*)(ex + sl * 4096 + q4 * 16) = make_uint4(tw[rows[sl]][4 * q4], tw[rows[sl]][4 * q4 + 1], tw[rows[sl]][4 * q4 + 2], tw[rows[sl]][4 * q4 + 3]);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // row r = 0 .. 6 <-> t row R - 1 + r: the wave above's row 3 | own rows 0 .. 3 | the wave below's rows 0, 1
-        // (wave 0 / wave 7: the rows that would need the missing neighbour lie outside the tile's output range; any data will do)
-        unsigned exrow[7];
-        exrow[0] = (unsigned)((wave > 0 ? wave - 1 : 0) * 16384 + 3 * 4096 + lane * 64);
+        {
+            // (wave 0 / wave 7: the rows that would need the missing neighbour lie outside the tile's output range; any data will do)
+            const unsigned char* exu = lds + (size_t)(wave > 0 ? wave - 1 : 0) * (3 * 4096) + lane * 64 + 2 * 4096;
+            const unsigned char* exd = lds + (size_t)(wave < 7 ? wave + 1 : 7) * (3 * 4096) + lane * 64;
 #pragma unroll
-        for (int r = 1; r <= 4; r++) exrow[r] = (unsigned)(wave * 16384 + (r - 1) * 4096 + lane * 64);
-        exrow[5] = (unsigned)((wave < 7 ? wave + 1 : 7) * 16384 + lane * 64);
-        exrow[6] = exrow[5] + 4096;
-        // rows this wave finishes: y rows R + k that lie in the tile's range [28 ty, 28 ty + 27] (= [2 y0 + 2, 2 y0 + 29]) and in the image
-        const int ylo = 2 * y0 + 2, yhi = min(2 * y0 + 29, OH - 1);
+            for (int q4 = 0; q4 < 4; q4++) {
+                const uint4 a = *(const uint4*)(exu + q4 * 16), c0 = *(const uint4*)(exd + q4 * 16), c1 = *(const uint4*)(exd + 4096 + q4 * 16);
+                tw[0][4 * q4] = a.x; tw[0][4 * q4 + 1] = a.y; tw[0][4 * q4 + 2] = a.z; tw[0][4 * q4 + 3] = a.w;
+                tw[5][4 * q4] = c0.x; tw[5][4 * q4 + 1] = c0.y; tw[5][4 * q4 + 2] = c0.z; tw[5][4 * q4 + 3] = c0.w;
+                tw[6][4 * q4] = c1.x; tw[6][4 * q4 + 1] = c1.y; tw[6][4 * q4 + 2] = c1.z; tw[6][4 * q4 + 3] = c1.w;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the exchange area is dead (and noise / bias are in registers)
+        // what the stores need of THIS tile, then the next tile's set-up and prologue requests
+        const int ylo = 2 * y0 + 2, yhi = min(2 * y0 + 29, OH - 1);         // the tile's output rows [28 ty, 28 ty + 27], inside the image
         const bool colv = l31 >= 1 && l31 <= 30 && Xe >= 0 && Xe + 1 < OW && !(DBG && (dbg & 8));
         const float slope = p->act == DGE_ACT_LRELU ? 0.2f : (p->act == DGE_ACT_RELU ? 0.f : 1.f);
-        const float bg = p->bias_scale * p->gain;
+        const unsigned ybytes = (unsigned)(OH * OW) * (unsigned)Cout * 2u;
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p->y + (size_t)b * OH * OW * Cout, 0, ybytes, 0x00020000);
+        unsigned yvoff[4];                          // byte offset of (row R + k, column Xe, channel run 0); out of range = the store is dropped
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int oy = R + k;
+            yvoff[k] = (colv && oy >= ylo && oy <= yhi && oy >= 0) ? (unsigned)((oy * OW + Xe) * Cout + nt * 32 + 8 * kh) * 2u : 0x80000000u;
+        }
+        const unsigned cb2 = (unsigned)Cout * 2u;
+        if (has_next) start_tile(next);
         const unsigned K0 = 0x3e80u, K1 = 0x3f40u;            // bf16 0.25, 0.75
         const unsigned cL = K0 << 16, cC_e = K1 | (K1 << 16), cR_e = K0, cC_o = K0 | (K1 << 16), cR_o = K1 | (K0 << 16);
-        bf16_t* yb = p->y + (size_t)b * OH * OW * Cout;
 #pragma unroll
         for (int h = 0; h < 2; h++) {                  // the lane's two runs of 8 channels
-            const int c0 = nt * 32 + 16 * h + 8 * kh;
-            float bia[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) bia[e] = p->bias ? p->bias[c0 + e] * bg : 0.f;
-            float ya[4][2][8];                          // y rows R .. R + 3, columns Xe, Xe + 1
+            f2_t ya[4][2][4];                           // y rows R .. R + 3, columns Xe, Xe + 1, channel pairs: start from noise * strength + bias
 #pragma unroll
             for (int k = 0; k < 4; k++)
 #pragma unroll
-                for (int c = 0; c < 2; c++)
+                for (int c = 0; c < 2; c++) {
+                    const float nzv = (c == 0 ? nz[k][0] : nz[k][1]) * nwv;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) ya[k][c][e] = 0.f;
-            unsigned trow[7][8];
-#pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const uint4 a0 = *(const uint4*)(lds + exrow[r] + h * 32), a1 = *(const uint4*)(lds + exrow[r] + h * 32 + 16);
-                trow[r][0] = a0.x; trow[r][1] = a0.y; trow[r][2] = a0.z; trow[r][3] = a0.w;
-                trow[r][4] = a1.x; trow[r][5] = a1.y; trow[r][6] = a1.z; trow[r][7] = a1.w;
-            }
+                    for (int e2 = 0; e2 < 4; e2++) ya[k][c][e2] = bia[h][e2] + f2_t{nzv, nzv};
+                }
             StaticFor<7>::run([&](auto rc) {
                 constexpr int r = decltype(rc)::value;          // t row R - 1 + r
+                f2_t he[4], ho[4];
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
-                    const unsigned wc = trow[r][e];
+                    const unsigned wc = tw[r][8 * h + e];
+                    if (DBG && (dbg & 64)) {            // timing aid: no horizontal FIR (DPP + dot2)
+                        he[e >> 1][e & 1] = __uint_as_float(wc << 16); ho[e >> 1][e & 1] = __uint_as_float(wc & 0xffff0000u);
+                        continue;
+                    }
                     const unsigned wlft = __builtin_amdgcn_mov_dpp(wc, 0x138, 0xf, 0xf, true);   // lane n - 1: (t[2n - 2], t[2n - 1])
                     const unsigned wrgt = __builtin_amdgcn_mov_dpp(wc, 0x130, 0xf, 0xf, true);   // lane n + 1: (t[2n + 2], t[2n + 3])
-                    float he, ho;
-                    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(he) : "v"(wlft), "v"(cL));
-                    he = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wc, *(const bf2_t*)&cC_e, he, false);
-                    he = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_e, he, false);
-                    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(ho) : "v"(wc), "v"(cC_o));
-                    ho = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_o, ho, false);
-                    // h row r feeds y rows k = r - 3 .. r with F[r - k]
+                    float a0, a1;
+                    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a0) : "v"(wlft), "v"(cL));
+                    a0 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wc, *(const bf2_t*)&cC_e, a0, false);
+                    a0 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_e, a0, false);
+                    asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a1) : "v"(wc), "v"(cC_o));
+                    a1 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_o, a1, false);
+                    he[e >> 1][e & 1] = a0; ho[e >> 1][e & 1] = a1;
+                }
+                // h row r feeds y rows k = r - 3 .. r with F[r - k] (packed f32 math: two channels per instruction)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        constexpr float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-                        if (r - k >= 0 && r - k <= 3) {
-                            ya[k][0][e] = fmaf(F[r - k], he, ya[k][0][e]);
-                            ya[k][1][e] = fmaf(F[r - k], ho, ya[k][1][e]);
+                for (int k = 0; k < 4; k++) {
+                    constexpr float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+                    if (r - k >= 0 && r - k <= 3) {
+                        const f2_t f = f2_t{F[r - k], F[r - k]};
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; e2++) {
+                            ya[k][0][e2] = __builtin_elementwise_fma(f, he[e2], ya[k][0][e2]);
+                            ya[k][1][e2] = __builtin_elementwise_fma(f, ho[e2], ya[k][1][e2]);
                         }
                     }
                 }
             });
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int oy = R + k;
-                const bool rowv = oy >= ylo && oy <= yhi && oy >= 0;
+            for (int k = 0; k < 4; k++)
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    const float nzv = (c == 0 ? nz[k][0] : nz[k][1]) * nwv;
-                    float v[8];
+                    u32x4_t o;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) { const float u = ya[k][c][e] + (nzv + bia[e]); v[e] = fmaxf(u, u * slope); }
-                    const uint4 o = pack16(v, (bf16_t*)nullptr);
-                    if (rowv && colv) *(uint4*)(yb + ((size_t)oy * OW + Xe + c) * Cout + c0) = o;
+                    for (int e2 = 0; e2 < 4; e2++) {
+                        const f2_t u = ya[k][c][e2], lo = u * slope;
+                        o[e2] = pack2bf(fmaxf(u[0], lo[0]), fmaxf(u[1], lo[1]));
+                    }
+                    // every wave issues all NSTORE stores (rows / columns outside the tile's range carry an out-of-range offset and are
+                    // dropped): the wait count at the top of the next tile relies on it
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, yvoff[k] + (unsigned)c * cb2, h * 32, 0);
                 }
-            }
         }
-        tile += stride;
-        if (tile >= tile_end) break;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave has read the exchange area: the next prologue may overwrite it
+        if (!has_next) break;
+        tile = next;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // per-sample weight image: [sample][channel tile 32][chunk 32][18 pieces][part 4][row 16][8] bf16, slot-local unit order (unit_q),

@@ -12,7 +12,8 @@ ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
 PACK_FWD, PACK_UPFOLD, PACK_DGRAD, PACK_UPFOLD_DGRAD, PACK_SG1_UP, PACK_SG1_UP_DGRAD, PACK_UPT2D_DGRAD = 0, 1, 2, 3, 4, 5, 6
 PACK_FRAG = 0x100     # OR-ed into a pack mode: MFMA-fragment order for the low-resolution kernel (csrc/conv_small.hip)
 import os as _os
-_PF = {"on": not _os.environ.get("DGE_NO_PREFETCH"), "prev": None, "next": {}}     # low-resolution weight prefetch chain (conv2d)
+import weakref as _weakref
+_PF = {"on": not _os.environ.get("DGE_NO_PREFETCH"), "prev": {}, "next": {}}     # low-resolution weight prefetch chain (conv2d)
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag, algorithmic_bytes) per conv launch
 
 
@@ -387,13 +388,26 @@ def conv2d(x, w_packed, cout, ksize=3, up=False, in_scale=None, in_shift=None, o
     if d.w_layout and _PF["on"]:
         # L2 warm-up hint for the low-resolution kernel: the launch warms the weights of the low-resolution launch that followed it
         # the LAST time it ran (a step repeats its launch sequence; packed copies keep their addresses) - dge_conv_desc.prefetch_w
+        # The chain is keyed by (stream, address): launches of different streams (the three loss windows) do not follow each other.
+        # An entry holds a WEAK reference to the packed tensor it points at: a re-allocated copy (load_state_dict, a new model) makes
+        # the entry stale and it is dropped instead of warming freed memory; the table is bounded.
+        sk = (_stream().value or 0)
         key = w_packed.data_ptr()
-        if _PF["prev"] is not None and _PF["prev"] != key:
-            _PF["next"][_PF["prev"]] = (key, w_packed.shape[1], w_packed.shape[2], w_packed)
-        _PF["prev"] = key
-        nxt = _PF["next"].get(key)
+        prev = _PF["prev"].get(sk) if isinstance(_PF["prev"], dict) else None
+        if not isinstance(_PF["prev"], dict):
+            _PF["prev"] = {}
+        if prev is not None and prev != key:
+            if len(_PF["next"]) > 512:
+                _PF["next"].clear()
+            _PF["next"][(sk, prev)] = (key, w_packed.shape[1], w_packed.shape[2], _weakref.ref(w_packed))
+        _PF["prev"][sk] = key
+        nxt = _PF["next"].get((sk, key))
         if nxt is not None:
-            d.prefetch_w, d.prefetch_ntot, d.prefetch_cin = C.c_void_p(nxt[0]), int(nxt[1]), int(nxt[2])
+            t = nxt[3]()
+            if t is None or t.data_ptr() != nxt[0]:
+                del _PF["next"][(sk, key)]
+            else:
+                d.prefetch_w, d.prefetch_ntot, d.prefetch_cin = C.c_void_p(nxt[0]), int(nxt[1]), int(nxt[2])
     if prep is not None:
         if stats is None or dot_src is None:
             raise DgeError("conv2d: prep needs stats and dot_src")

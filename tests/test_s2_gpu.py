@@ -192,30 +192,3 @@ def test_dense_chain_is_bit_identical_to_the_per_layer_launches():
     assert torch.equal(got, w)
     got2 = ops.dense_chain(z, [getattr(M, f"dense{i}") for i in range(M.num_layers)], pixelnorm=True)
     assert torch.equal(got2, w)
-
-
-@pytest.mark.gpu
-def test_batched_dense_layer_is_bit_identical_to_the_per_sample_launch():
-    """dge_linear folds the batch into the wave for B >= 2 (linear_cols_kernel: one read of a weight row serves 8 samples;
-    stylegan2_generator.py:990-996 DenseBlock) - per (sample, output) the arithmetic of the single-sample kernel, so the rows of a
-    batched call equal the per-sample calls bit for bit (ragged batch: 11 = 8 + 3; strided rows; squared input of the demodulation)"""
-    import torch
-    from dge_amd import ops
-    torch.manual_seed(5)
-    W = torch.randn(512, 512, device="cuda") * 0.05
-    bias = torch.randn(512, device="cuda")
-    xs = torch.randn(11, 3, 512, device="cuda")
-    x = xs[:, 1]                                            # row stride 1536
-    for act, sq in ((ops.ACT_LRELU, False), (ops.ACT_NONE, True)):
-        got = ops.linear(x, W, bias, 0.7, 0.01, 1.0, act, 1.41, square_input=sq)
-        for b in range(11):
-            one = ops.linear(x[b:b + 1], W, bias, 0.7, 0.01, 1.0, act, 1.41, square_input=sq)
-            assert torch.equal(got[b:b + 1], one), (act, sq, b)
-    # the mapping network at batch 8 takes this path: against the one-launch chain (one workgroup per sample, same arithmetic)
-    from dge_amd.stylegan2_generator import MappingModule
-    M = MappingModule().cuda()
-    with torch.no_grad():
-        for p in M.parameters():
-            p.copy_(torch.randn_like(p) * (1.0 if p.ndim == 2 else 0.1))
-    z = torch.randn(8, 512, device="cuda")
-    assert torch.equal(M(z)["w"], ops.dense_chain(z, [getattr(M, f"dense{i}") for i in range(M.num_layers)], pixelnorm=True))
