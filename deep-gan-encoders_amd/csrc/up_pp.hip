@@ -417,6 +417,10 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                         he[e >> 1][e & 1] = __uint_as_float(wc << 16); ho[e >> 1][e & 1] = __uint_as_float(wc & 0xffff0000u);
                         continue;
                     }
+                    // he = .25 t[2n-1] + .75 t[2n] + .75 t[2n+1] + .25 t[2n+2], ho = .25 t[2n] + .75 t[2n+1] + .75 t[2n+2] + .25 t[2n+3] on the
+                    // bf16 pairs (t[2n], t[2n+1]) of lanes n - 1, n, n + 1.  (Tried: the neighbour words as the DPP operand of
+                    // v_dot2c_f32_bf16_dpp itself - 5 instructions per word instead of 7 - from inline asm: the hazard recognizer does not see
+                    // the DOT writes inside an asm block, and 2e-5 of the outputs came out wrong at block boundaries.  Builtins only.)
                     const unsigned wlft = __builtin_amdgcn_mov_dpp(wc, 0x138, 0xf, 0xf, true);   // lane n - 1: (t[2n - 2], t[2n - 1])
                     const unsigned wrgt = __builtin_amdgcn_mov_dpp(wc, 0x130, 0xf, 0xf, true);   // lane n + 1: (t[2n + 2], t[2n + 3])
                     float a0, a1;
