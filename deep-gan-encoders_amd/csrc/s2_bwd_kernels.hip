@@ -210,6 +210,41 @@ __global__ void up2_bwd_kernel(const float* __restrict__ g, float* __restrict__ 
     gprev[idx] = s;
 }
 
+// the same for w % 4 == 0: one thread = 4 consecutive outputs of a row; the 4 x 10 window comes in as four 16-byte loads per row
+// (the scalar form issued 16 four-byte loads per output: 79 us at 1024^2 -> 512^2, batch 8, for 125 MB)
+__global__ __launch_bounds__(256) void up2_bwd_v4_kernel(const float* __restrict__ g, float* __restrict__ gprev, int BC, int h, int w) {
+    const int wq = w >> 2;
+    const long n = (long)BC * h * wq;
+    const long idx = blockIdx.x * 256L + threadIdx.x;
+    if (idx >= n) return;
+    const int xq = idx % wq; const long r = idx / wq; const int y = r % h; const int bc = r / h;
+    const int H2 = 2 * h, W2 = 2 * w, X = 8 * xq;          // first input column of B
+    const float* gp = g + (size_t)bc * 4 * h * w;
+    const float wt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    float c[10];
+#pragma unroll
+    for (int j = 0; j < 10; j++) c[j] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int yy = 2 * y + a - 1;
+        if (yy < 0 || yy >= H2) continue;
+        const float* row = gp + (size_t)yy * W2 + X;
+        const float4 B = *(const float4*)row, C4 = *(const float4*)(row + 4);
+        const float Aw = X > 0 ? row[-1] : 0.f;
+        const float Dx = X + 8 < W2 ? row[8] : 0.f;
+        c[0] = fmaf(wt[a], Aw, c[0]);
+        c[1] = fmaf(wt[a], B.x, c[1]); c[2] = fmaf(wt[a], B.y, c[2]); c[3] = fmaf(wt[a], B.z, c[3]); c[4] = fmaf(wt[a], B.w, c[4]);
+        c[5] = fmaf(wt[a], C4.x, c[5]); c[6] = fmaf(wt[a], C4.y, c[6]); c[7] = fmaf(wt[a], C4.z, c[7]); c[8] = fmaf(wt[a], C4.w, c[8]);
+        c[9] = fmaf(wt[a], Dx, c[9]);
+    }
+    float4 o;
+    o.x = 0.25f * c[0] + 0.75f * c[1] + 0.75f * c[2] + 0.25f * c[3];
+    o.y = 0.25f * c[2] + 0.75f * c[3] + 0.75f * c[4] + 0.25f * c[5];
+    o.z = 0.25f * c[4] + 0.75f * c[5] + 0.75f * c[6] + 0.25f * c[7];
+    o.w = 0.25f * c[6] + 0.75f * c[7] + 0.75f * c[8] + 0.25f * c[9];
+    *(float4*)(gprev + (size_t)idx * 4) = o;
+}
+
 // =================================================================== C ABI
 
 extern "C" int dge_modconv_bwd_prep(const void* gx, const void* x, const float* d, const float* noise, void* gy, float* R,
@@ -427,7 +462,11 @@ extern "C" int dge_torgb_bwd(const float* gimg, const void* x, const float* wrgb
 
 extern "C" int dge_up2_bwd(const float* g, float* gprev, int BC, int h, int w, hipStream_t s) {
     const long n = (long)BC * h * w;
-    hipLaunchKernelGGL(up2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, gprev, BC, h, w);
+    if ((w & 3) == 0 && w >= 8) {
+        const long nq = n / 4;
+        hipLaunchKernelGGL(up2_bwd_v4_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, g, gprev, BC, h, w);
+    } else
+        hipLaunchKernelGGL(up2_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, gprev, BC, h, w);
     DGE_LAUNCH_CHECK("up2_bwd");
     return 0;
 }

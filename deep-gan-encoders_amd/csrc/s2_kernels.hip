@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include <vector>
+#include <algorithm>
 #include <string.h>
 #include "conv_params.h"
 
@@ -115,6 +116,11 @@ struct DgePackDesc {
     float scale;
     long long pair_start;                 // first (n, k) pair of this tensor in the launch's pair space
     long long tile_start;                 // first 32 x 32 (n, k) tile of this tensor in the launch's tile space
+    // paired entry (tiled kernel only): the data-gradient copy (mode 2) of the SAME weight rides on the forward copy's tiles - one
+    // staged 32 x 32 x taps source block feeds both layouts (the encoder re-packs both after every optimizer step: the source is
+    // read once instead of twice).  out2 == nullptr: not paired.  An entry that was absorbed by its partner has tiles_n = 0.
+    void* out2;
+    int ntot2, kdim2, mode2, tiles_i;     // tiles_i: tiles along the source's input-channel axis (paired entries)
 };
 __device__ __forceinline__ float pack_gather(const float* __restrict__ w, int mode, int Cout, int Cin, int ntap, int n, int k, int tap) {
     if (mode == 0) return n < Cout ? w[((size_t)n * Cin + k) * ntap + tap] : 0.f;
@@ -147,43 +153,85 @@ __global__ void pack_multi_kernel(const DgePackDesc* __restrict__ descs, int nd,
 // each optimizer step.  Here a workgroup owns a 32 x 32 (n, k) tile of one packed tensor for all taps: the source block is
 // 32 rows (output channels of w) of 32*taps CONTIGUOUS floats in both layouts, read coalesced into LDS, and written out k-fastest
 // (64-byte runs of bf16, or the 1 KiB fragment runs).  Other modes gather from global memory as before.
+// Round 5: (i) the tile -> tensor search runs on a copy of the tile_start column in LDS (it was ~7 dependent global loads per tile),
+// (ii) the source block is fetched as 16-byte loads, all of a thread's loads in flight at once (it was 36 dependent 4-byte loads per
+// thread), (iii) a forward copy and the data-gradient copy of the same weight share one staged block (DgePackDesc::out2).
+constexpr int PK_LDW = 32 * 9 + 1;                        // row pitch in floats (odd: the transposed reads spread over the banks)
+template <bool TR>
+__device__ __forceinline__ void pack_emit_bf16(const float* __restrict__ tile, int ntap, int n0, int k0, bf16_t* __restrict__ out, int ntot, int kdim,
+                                               int frag, float scale) {
+    // 8 consecutive k per thread: one 16-byte store (row-major: a 64-byte run per n; fragment order: 8 k of a lane)
+    for (int idx = threadIdx.x; idx < 128 * ntap; idx += 256) {
+        const int kc = idx & 3, nn = (idx >> 2) & 31, tap = idx >> 7;
+        const int n = n0 + nn, k = k0 + kc * 8;
+        if (k >= kdim || n >= ntot) continue;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            v[j] = scale * (!TR ? tile[nn * PK_LDW + (kc * 8 + j) * ntap + tap] : tile[(kc * 8 + j) * PK_LDW + nn * ntap + (ntap - 1 - tap)]);
+        *(uint4*)(out + pack_out_index(frag, tap, n, k, ntot, kdim)) =
+            make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    }
+}
 __global__ __launch_bounds__(256) void pack_multi_tiled_kernel(const DgePackDesc* __restrict__ descs, int nd, long long total_tiles) {
-    constexpr int LDW = 32 * 9 + 1;                        // row pitch in floats (odd: the transposed reads spread over the banks)
-    __shared__ float tile[32 * LDW];
+    __shared__ float tile[32 * PK_LDW];
+    constexpr int NDL = 512;
+    __shared__ long long tstart[NDL];
+    const bool lds_search = nd <= NDL;
+    if (lds_search) {
+        for (int i = threadIdx.x; i < nd; i += 256) tstart[i] = descs[i].tile_start;
+        __syncthreads();
+    }
     for (long long tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
         int lo = 0, hi = nd - 1;
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].tile_start <= tix) lo = mid; else hi = mid - 1; }
+        // (entries without tiles share their successor's tile_start: "last entry with tile_start <= tix" skips them)
+        if (lds_search) { while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tstart[mid] <= tix) lo = mid; else hi = mid - 1; } }
+        else { while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (descs[mid].tile_start <= tix) lo = mid; else hi = mid - 1; } }
         const DgePackDesc e = descs[lo];
         const int local = (int)(tix - e.tile_start);
-        const int kt = (e.kdim + 31) / 32;
-        const int n0 = (local / kt) * 32, k0 = (local % kt) * 32;
         const int ntap = e.ks * e.ks, mode = e.mode & 0xff, frag = e.mode & 0x100;
+        const bool paired = e.out2 != nullptr;
+        const int kt = paired ? e.tiles_i : (e.kdim + 31) / 32;
+        const int n0 = (local / kt) * 32, k0 = (local % kt) * 32;
         const bool staged = (mode == 0 || mode == 2) && ntap <= 9;
         __syncthreads();                                   // the previous tile's readers are done
         if (staged) {
             // source rows = output channels o of w [Cout][Cin][taps]; columns = (i, tap) for 32 consecutive i
             const int o0 = mode == 0 ? n0 : k0, i0 = mode == 0 ? k0 : n0;
             const int run = 32 * ntap;
-            for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
-                const int r = idx / run, c = idx - r * run;
-                const int o = o0 + r, i = i0 + c / ntap;
-                tile[r * LDW + c] = (o < e.cout && i < e.cin) ? e.w[((size_t)o * e.cin + i0) * ntap + c] : 0.f;
+            const int iv = min(32, e.cin - i0);            // valid input channels of the block (<= 0: none)
+            if ((e.cin & 3) == 0 && ntap == 9) {
+                // 16-byte loads: row r holds iv * 9 valid floats (a multiple of 4, 16-byte aligned: cin % 4 == 0, i0 % 32 == 0); 72 units per full row
+                const int upr = iv > 0 ? iv * 9 / 4 : 0;
+                float4 v[9];
+                int rr[9], cc[9];
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    const int u = threadIdx.x + q * 256;       // 32 rows x 72 units
+                    rr[q] = u / 72; cc[q] = u - rr[q] * 72;
+                    const int o = o0 + rr[q];
+                    v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (o < e.cout && cc[q] < upr) v[q] = *(const float4*)(e.w + ((size_t)o * e.cin + i0) * 9 + cc[q] * 4);
+                }
+#pragma unroll
+                for (int q = 0; q < 9; q++) {
+                    float* t = tile + rr[q] * PK_LDW + cc[q] * 4;
+                    t[0] = v[q].x; t[1] = v[q].y; t[2] = v[q].z; t[3] = v[q].w;
+                }
+            } else {
+                for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+                    const int r = idx / run, c = idx - r * run;
+                    const int o = o0 + r, i = i0 + c / ntap;
+                    tile[r * PK_LDW + c] = (o < e.cout && i < e.cin) ? e.w[((size_t)o * e.cin + i0) * ntap + c] : 0.f;
+                }
             }
             __syncthreads();
         }
         if (staged && e.dtype == DGE_BF16 && (e.kdim & 7) == 0) {
-            // 8 consecutive k per thread: one 16-byte store (row-major: a 64-byte run per n; fragment order: 8 k of a lane)
-            for (int idx = threadIdx.x; idx < 128 * ntap; idx += 256) {
-                const int kc = idx & 3, nn = (idx >> 2) & 31, tap = idx >> 7;
-                const int n = n0 + nn, k = k0 + kc * 8;
-                if (k >= e.kdim) continue;
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    v[j] = e.scale * (mode == 0 ? tile[nn * LDW + (kc * 8 + j) * ntap + tap] : tile[(kc * 8 + j) * LDW + nn * ntap + (ntap - 1 - tap)]);
-                *(uint4*)((bf16_t*)e.out + pack_out_index(frag, tap, n, k, e.ntot, e.kdim)) =
-                    make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-            }
+            if (mode == 0) pack_emit_bf16<false>(tile, ntap, n0, k0, (bf16_t*)e.out, e.ntot, e.kdim, frag, e.scale);
+            else pack_emit_bf16<true>(tile, ntap, n0, k0, (bf16_t*)e.out, e.ntot, e.kdim, frag, e.scale);
+            // (paired: this entry is the forward copy - n = o, k = i; the partner is the data-gradient copy - n = i, k = o)
+            if (paired) pack_emit_bf16<true>(tile, ntap, k0, n0, (bf16_t*)e.out2, e.ntot2, e.kdim2, e.mode2 & 0x100, e.scale);
             continue;
         }
         for (int idx = threadIdx.x; idx < 1024 * ntap; idx += 256) {
@@ -191,7 +239,7 @@ __global__ __launch_bounds__(256) void pack_multi_tiled_kernel(const DgePackDesc
             const int n = n0 + nn, k = k0 + kk;
             if (k >= e.kdim) continue;
             float v;
-            if (staged) v = mode == 0 ? tile[nn * LDW + kk * ntap + tap] : tile[kk * LDW + nn * ntap + (ntap - 1 - tap)];
+            if (staged) v = mode == 0 ? tile[nn * PK_LDW + kk * ntap + tap] : tile[kk * PK_LDW + nn * ntap + (ntap - 1 - tap)];
             else v = pack_gather(e.w, mode, e.cout, e.cin, ntap, n, k, tap);
             v *= e.scale;
             const size_t o = pack_out_index(frag, tap, n, k, e.ntot, e.kdim);
@@ -554,9 +602,38 @@ extern "C" int dge_pack_conv_weights_multi(const long long* table_host, void* de
                   "pack_multi: fragment order needs bf16, N %% 32 == 0, K %% 16 == 0");
         d.pair_start = pairs;
         pairs += (long long)d.ntot * d.kdim;
-        d.tile_start = tiles;
-        tiles += (long long)(d.ntot / 32) * ((d.kdim + 31) / 32);
+        d.out2 = nullptr; d.ntot2 = d.kdim2 = d.mode2 = d.tiles_i = 0;
         DGE_CHECK(d.ntot % 32 == 0, "pack_multi: packed N is padded to the N tile (multiple of 32)");
+    }
+    // forward copy + data-gradient copy of one weight -> one entry of the tiled kernel (see DgePackDesc::out2)
+    static int nopair = -1;
+    if (nopair < 0) nopair = getenv("DGE_PACK_NOPAIR") ? 1 : 0;
+    std::vector<char> absorbed(n, 0);
+    if (!nopair)
+        for (int i = 0; i < n; i++) {
+            DgePackDesc& f = host[i];
+            if ((f.mode & 0xff) != 0 || f.dtype != DGE_BF16 || f.ks != 3 || (f.kdim & 7) || absorbed[i]) continue;
+            for (int j = 0; j < n; j++) {
+                const DgePackDesc& g = host[j];
+                if (j == i || absorbed[j] || g.out2 || (g.mode & 0xff) != 2 || g.w != f.w || g.dtype != DGE_BF16 || g.ks != 3 || (g.kdim & 7) ||
+                    g.cout != f.cout || g.cin != f.cin || g.scale != f.scale)
+                    continue;
+                f.out2 = g.out; f.ntot2 = g.ntot; f.kdim2 = g.kdim; f.mode2 = g.mode;
+                absorbed[j] = 1;
+                break;
+            }
+        }
+    for (int i = 0; i < n; i++) {
+        DgePackDesc& d = host[i];
+        d.tile_start = tiles;
+        if (absorbed[i]) continue;
+        if (d.out2) {
+            const int to = std::max(d.ntot / 32, (d.kdim2 + 31) / 32);          // tiles along the source's output-channel axis
+            d.tiles_i = std::max((d.kdim + 31) / 32, d.ntot2 / 32);
+            tiles += (long long)to * d.tiles_i;
+        } else {
+            tiles += (long long)(d.ntot / 32) * ((d.kdim + 31) / 32);
+        }
     }
     // upload = 0: descs_dev still holds the descriptors of an earlier call with the same table (the steady state of a
     // training loop: a pageable host -> device copy waits for the stream to drain, so it is paid once, not per step)
