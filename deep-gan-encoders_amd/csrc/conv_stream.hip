@@ -380,6 +380,17 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             biasv[mt][r] = live ? TT[chan_of_reg(mt, r) * 16 + 12] : 0.f;
             if constexpr (C::ENC) nwv[mt][r] = live ? TT[chan_of_reg(mt, r) * 16 + 13] : 0.f;
             if constexpr (C::DOT) oscv[r] = live ? TT[chan_of_reg(mt, r) * 16 + 14] : 0.f;
+            if constexpr (C::ENC) {
+                // zero padding follows the norm: the tap COLUMN that falls outside the image does not carry the folded shift.  That term
+                // depends on the lane (= pixel column) and the channel only: it goes into the lane's C operand here, once.  (It used to be
+                // subtracted per row from a table in LDS - 16 dependent LDS round trips per row on the two edge strips of an image, 3 x
+                // the step time of an interior strip; all strips of a launch are resident at once, so the edge strips set its duration.)
+                const int gxl = x0 + n31;
+                if (live && edge_strip && (gxl == 0 || gxl == p.W - 1)) {
+                    const float* __restrict__ T = TT + chan_of_reg(mt, r) * 16;
+                    biasv[mt][r] -= (gxl == 0 ? T[10] : 0.f) + (gxl == p.W - 1 ? T[11] : 0.f);
+                }
+            }
         }
     const float nw_uniform = (!C::ENC && C::NOISE && p.noise) ? p.noise_w[0] * p.gain : 0.f;
     const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
@@ -447,6 +458,15 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     const bool pv = gx < p.W;
     // output byte offset of this lane inside an image row: pixel, this wave's channels, this lane's first run of 8
     const unsigned yoff = (unsigned)gx * C::CPB + (unsigned)(wave * C::MTW * 32 * 2) + kh * 16;
+    // pooled flavour: buffer descriptors of this sample's pooled output [H/2][W/2][COUT] bf16 and sign mask [H/2][W/2][COUT/8] words;
+    // lane offsets of the even pixels inside the image (every other lane: out of range = the store is dropped)
+    const bool pool_lane = C::POOL && (n31 & 1) == 0 && pv;
+    const unsigned py_voff = pool_lane ? (unsigned)(gx >> 1) * C::CPB + (unsigned)(wave * C::MTW * 64) + kh * 16 : 0x80000000u;
+    const unsigned pm_voff = pool_lane ? ((unsigned)(gx >> 1) * (COUT / 8) + (unsigned)(wave * C::MTW * 4) + kh) * 4u : 0x80000000u;
+    const unsigned pool_px = C::POOL ? (unsigned)(p.H >> 1) * (unsigned)(p.W >> 1) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)p.y + (size_t)b * pool_px * C::CPB, 0, (int)(pool_px * C::CPB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc((C::POOL && p.pool_mask) ? (unsigned char*)p.pool_mask + (size_t)b * pool_px * (COUT / 8) * 4 : (unsigned char*)p.y, 0,
+                                                                               (C::POOL && p.pool_mask) ? (int)(pool_px * (COUT / 8) * 4) : 0, 0x00020000);
 
     float s0[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s1[C::MTW][(C::STATS || C::DOT) ? 16 : 1], s2[(C::PREP || C::INB) ? 16 : 1];
     if constexpr (C::STATS || C::DOT) {
@@ -526,13 +546,14 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             for (int r = 0; r < 16; r++) v[r] = acc[mt][r];
             if constexpr (C::ENC) {
                 // zero padding follows the norm: taps that fall outside the image do not carry the folded shift
+                // (the left / right tap columns: in the C operand, see biasv)  Top / bottom image row: two rows per image take this path
                 const bool top = gy == 0, bot = gy == p.H - 1;
-                if (edge_strip | top | bot) {
+                if (top | bot) {
                     const float cl = gx == 0 ? 1.f : 0.f, cr = gx == p.W - 1 ? 1.f : 0.f;
 #pragma unroll
                     for (int r = 0; r < NREG; r++) {
                         const float* __restrict__ T = TT + chan_of_reg(mt, r) * 16;
-                        float corr = cl * T[10] + cr * T[11];
+                        float corr = 0.f;
                         if (top) corr += T[0] + T[1] + T[2] - cl * T[0] - cr * T[2];
                         if (bot) corr += T[6] + T[7] + T[8] - cl * T[6] - cr * T[8];
                         v[r] -= corr;
@@ -612,7 +633,10 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                 unsigned sb = 0;
 #pragma unroll
                 for (int r = 0; r < NREG; r++) sb |= (v[r] > 0.f ? 1u : 0u) << r;
-                if ((gy & 1) == 0) {                                   // wave-uniform: the segment starts on an even row
+                // (row parity = parity of the ring position: segments start on even rows - launch_stream - and the ring period is even;
+                //  a run-time `gy & 1` branch cost 17 register copies per even row)
+                static_assert(!C::POOL || C::NR % 2 == 0, "pooled flavour: even ring period");
+                if constexpr ((I & 1) == 0) {
 #pragma unroll
                     for (int r = 0; r < NREG; r++) prow[mt][r] = v[r];
                     psign[mt] = sb;
@@ -624,24 +648,31 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
                     const float cs = prow[mt][r] + v[r];
                     v[r] = 0.25f * (cs + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(unsigned, cs), 0xB1, 0xf, 0xf, true)));
                 }
+                // stores through buffer descriptors of the sample's pooled plane / mask plane: lane part of the offset fixed for the strip
+                // (odd pixels and pixels right of the image carry an out-of-range offset: dropped), row part scalar.  (64-bit per-lane
+                // pointers here were spilled, and every reload waited for ALL outstanding loads - the row prefetches - with vmcnt(0).)
+                const unsigned prow_i = (unsigned)(gy >> 1);
                 if (p.pool_mask) {
                     // mask word of a pooled pixel and 8-channel chunk: byte q = position (2oy, 2ox), (2oy, 2ox+1), (2oy+1, 2ox), (2oy+1, 2ox+1)
                     // (the layout of dge_blend_pool_mask / dge_act_bwd_mask)
                     const unsigned own = (psign[mt] & 0xffffu) | (sb << 16);       // runs: [7:0], [15:8] even row | [23:16], [31:24] odd row
                     const unsigned nbr = __builtin_amdgcn_mov_dpp(own, 0xB1, 0xf, 0xf, true);
-                    if ((n31 & 1) == 0 && pv) {
-                        const int OWp = p.W >> 1, cpt = COUT / 8;
-                        unsigned* __restrict__ mrow = p.pool_mask + (((size_t)b * (p.H >> 1) + (gy >> 1)) * OWp + (gx >> 1)) * cpt + (wave * C::MTW + mt) * 4 + kh;
-                        mrow[0] = (own & 0xffu) | ((nbr & 0xffu) << 8) | (((own >> 16) & 0xffu) << 16) | (((nbr >> 16) & 0xffu) << 24);
-                        if constexpr (NREG == 16)
-                            mrow[2] = ((own >> 8) & 0xffu) | (((nbr >> 8) & 0xffu) << 8) | (((own >> 24) & 0xffu) << 16) | (((nbr >> 24) & 0xffu) << 24);
-                    }
+                    const unsigned msoff = prow_i * (unsigned)(p.W >> 1) * (unsigned)(COUT / 8) * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32((own & 0xffu) | ((nbr & 0xffu) << 8) | (((own >> 16) & 0xffu) << 16) | (((nbr >> 16) & 0xffu) << 24),
+                                                          rs_mask, pm_voff + (unsigned)mt * 16u, msoff, 0);
+                    if constexpr (NREG == 16)
+                        __builtin_amdgcn_raw_buffer_store_b32(((own >> 8) & 0xffu) | (((nbr >> 8) & 0xffu) << 8) | (((own >> 24) & 0xffu) << 16) | (((nbr >> 24) & 0xffu) << 24),
+                                                              rs_mask, pm_voff + (unsigned)mt * 16u + 8u, msoff, 0);
                 }
-                if ((n31 & 1) == 0 && pv) {
-                    unsigned char* dstp = (unsigned char*)p.y + (((size_t)b * (p.H >> 1) + (gy >> 1)) * (p.W >> 1) + (gx >> 1)) * C::CPB +
-                                          (unsigned)(wave * C::MTW * 64) + kh * 16 + mt * 64;
-                    *(uint4*)dstp = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
-                    if constexpr (NREG == 16) *(uint4*)(dstp + 32) = make_uint4(pack2bf(v[8], v[9]), pack2bf(v[10], v[11]), pack2bf(v[12], v[13]), pack2bf(v[14], v[15]));
+                {
+                    const unsigned ysoff = prow_i * (unsigned)(p.W >> 1) * (unsigned)C::CPB;
+                    u32x4_t q0, q1;
+                    q0[0] = pack2bf(v[0], v[1]); q0[1] = pack2bf(v[2], v[3]); q0[2] = pack2bf(v[4], v[5]); q0[3] = pack2bf(v[6], v[7]);
+                    __builtin_amdgcn_raw_buffer_store_b128(q0, rs_pool, py_voff + (unsigned)mt * 64u, ysoff, 0);
+                    if constexpr (NREG == 16) {
+                        q1[0] = pack2bf(v[8], v[9]); q1[1] = pack2bf(v[10], v[11]); q1[2] = pack2bf(v[12], v[13]); q1[3] = pack2bf(v[14], v[15]);
+                        __builtin_amdgcn_raw_buffer_store_b128(q1, rs_pool, py_voff + (unsigned)mt * 64u + 32u, ysoff, 0);
+                    }
                 }
                 continue;
             }
@@ -682,7 +713,9 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
         StaticFor<C::NR>::run([&](auto ic) {
             constexpr int I = decltype(ic)::value;
             if (!done) {
-                if (s0_ + I < rows) step(ic, s0_ + I, npar);
+                // (pooled flavour: `rows` is even - an odd row follows its even row without a second test, so that the even row's values
+                //  reach it in registers)
+                if ((C::POOL && (I & 1)) || s0_ + I < rows) step(ic, s0_ + I, npar);
                 else done = true;
             }
         });

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../deep-gan-encoders_amd/csrc"
 mkdir -p ../variants build
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 -c ../../tools/probes/conv_stream_experiments.hip -o build/conv_stream_$1.o
-objs=$(ls build/*.o | grep -v "conv_stream")
+objs=$(ls build/*.o | grep -v "build/conv_stream")
 hipcc --offload-arch=gfx950 -shared -fPIC $objs build/conv_stream_$1.o -o ../variants/libdge_$1.so
 rm -f build/conv_stream_$1.o
 echo "built variants/libdge_$1.so"

@@ -448,7 +448,7 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     // ---- one output row.  I = position in the ring period (compile time): halo rows in slots I, I+1, I+2 (mod NR)
 #ifdef DGE_SC_TIMING
     long long* tlog = (long long*)(lds + C::T_OFF);      // [16 steps][5] of job 0 (the table is dead once the constants are in registers)
-    const bool tjob = blockIdx.x == 64 && wid == 0;
+    const bool tjob = blockIdx.x == 64 && wid == (C::TEAM == 2 ? 2 : 1);      // (team 1 = strip 1: an interior strip)
 #define DGE_T(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); \
                       if (tjob && s >= 40 && s < 56 && lane == 0) tlog[(s - 40) * 5 + k] = t_; } while (0)
 #else
