@@ -195,6 +195,9 @@ __global__ __launch_bounds__((64 * SC<CIN, COUT, FL>::TEAM * SC<CIN, COUT, FL>::
 void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int njobs, int jobs_per_xcd) {
     using C = SC<CIN, COUT, FL>;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds_all[];
+#ifdef DGE_SC_TIMING          // tuning builds (tools/build_variant.sh ... main): per-job clock stamps, see the end of the kernel
+    const long long tj0 = __builtin_readcyclecounter();
+#endif
     const int lane = threadIdx.x & 63;
     const int wid = (int)rfl(threadIdx.x >> 6);
     const int team = wid / C::TEAM;                                              // teams of a workgroup never synchronise with each other
@@ -326,14 +329,30 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             float osc = p.gain;
             if (!C::DOT && p.out_scale && ov) osc *= p.out_scale[b * COUT + o];
             if (C::INB && ov) osc *= p.in_coef[((size_t)b * COUT + o) * 3];
+            // the row's epilogue constants: requested here, used behind the tap loop (they were three more dependent round trips there)
+            const int oc = ov ? o : 0;
+            float c_bias = (!C::DOT && p.bias) ? p.bias[oc] : 0.f;
+            float c_nw = (C::NOISE && p.noise) ? p.noise_w[oc * p.noise_w_stride] : 0.f;
+            float c_osc = (C::DOT && !C::INB && p.out_scale) ? p.out_scale[b * COUT + oc] : 1.f;
+            float c_in1 = 0.f, c_in2 = 0.f;
+            if constexpr (C::INB) { c_in1 = p.in_coef[((size_t)b * COUT + oc) * 3 + 1]; c_in2 = p.in_coef[((size_t)b * COUT + oc) * 3 + 2]; }
             float tall = 0.f, tleft = 0.f, tright = 0.f;
+            // all 9 * KS loads of the row go out before the first one is used (rows that do not exist read row 0 and are zeroed below):
+            // with the load inside the tap loop every tap waited for its own round trip - 9 dependent misses, ~19 k cycles of a job's
+            // ~200 k (measured per job, tools/perf_stream_jobs.py)
+            {
+                const bf16_t* __restrict__ wrow = Wp + (size_t)(ov ? o : 0) * CIN + kh * 8;
+#pragma unroll
+                for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+                    for (int ks = 0; ks < C::KS; ks++) wf[mt][tap][ks] = *(const uint4*)(wrow + (size_t)tap * p.Ntot * CIN + ks * 16);
+            }
 #pragma unroll
             for (int tap = 0; tap < 9; tap++) {
                 float tt = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < C::KS; ks++) {
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (ov) v = *(const uint4*)(Wp + ((size_t)(tap * p.Ntot + o) * CIN + ks * 16 + kh * 8));
+                    uint4 v = ov ? wf[mt][tap][ks] : make_uint4(0, 0, 0, 0);
                     float f[8];
                     unpack16(v, f, (bf16_t*)nullptr);
 #pragma unroll
@@ -356,12 +375,12 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
             }
             if (kh == 0 && ov) {
                 const int e = (mt * 32 + cl) * 16;
-                float bb = (!C::DOT && p.bias) ? p.bias[o] * p.bias_scale * p.gain : 0.f;
+                float bb = (!C::DOT && p.bias) ? c_bias * p.bias_scale * p.gain : 0.f;
                 if constexpr (C::ENC) { TT[e + 9] = tall; TT[e + 10] = tleft; TT[e + 11] = tright; bb += tall; }
-                if constexpr (C::INB) bb = p.in_coef[((size_t)b * COUT + o) * 3 + 2];
+                if constexpr (C::INB) bb = c_in2;
                 TT[e + 12] = bb;
-                TT[e + 13] = (C::NOISE && p.noise) ? p.noise_w[o * p.noise_w_stride] * p.gain : 0.f;
-                TT[e + 14] = C::INB ? p.in_coef[((size_t)b * COUT + o) * 3 + 1] : ((C::DOT && p.out_scale) ? p.out_scale[b * COUT + o] : 1.f);
+                TT[e + 13] = (C::NOISE && p.noise) ? c_nw * p.gain : 0.f;
+                TT[e + 14] = C::INB ? c_in1 : c_osc;
             }
         }
     }
@@ -707,6 +726,12 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
         DGE_T(4);
     };
 
+#ifdef DGE_SC_TIMING
+    const int tjob_id = ((blockIdx.x & 7) * jobs_per_xcd + (blockIdx.x >> 3)) * C::TPW + team;
+    __builtin_amdgcn_sched_barrier(0);
+    const long long tj1 = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     unsigned npar = 0;                                                      // noise buffer of the current period (byte offset 0 / 1024)
     for (int s0_ = 0; s0_ < rows; s0_ += C::NR, npar ^= 1024u) {
         bool done = false;
@@ -727,6 +752,13 @@ void conv_stream_kernel(ConvParams p, int nstrips, int nseg, int seg_rows, int n
     }
     // no DMA may land after the wave has given its LDS back
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef DGE_SC_TIMING
+    // [job][4] int64 over the first bytes of the OUTPUT (the result is garbage there): entry, loop start, loop end, rows | realtime
+    if (lane == 0 && wave == 0) {
+        long long* tl = (long long*)p.y + (size_t)tjob_id * 4;
+        tl[0] = tj0; tl[1] = tj1; tl[2] = __builtin_readcyclecounter(); tl[3] = ((long long)rows << 40) | (long long)(__builtin_amdgcn_s_memrealtime() & 0xffffffffffll);
+    }
+#endif
 
     // ---- statistics: reduce over the 32 pixel lanes, one atomic per channel per wave
     if constexpr (C::FRB) {
@@ -918,7 +950,13 @@ bool dge_conv_rgb_ok(const ConvParams& p, int dtype, int ksize) {
 
 int dge_conv_stream_launch(const ConvParams& p, hipStream_t s) {
 #define GO(CI, CO) if (p.Cin == CI && p.Cout == CO) return launch_flavour<CI, CO>(p, s)
+#ifdef DGE_SC_ONLY          // tuning builds: one channel configuration (compile time)
+#define GO2(...) GO(__VA_ARGS__)
+    GO2(DGE_SC_ONLY);
+#undef GO2
+#else
     GO(16, 16); GO(16, 32); GO(16, 64); GO(32, 16); GO(32, 32); GO(32, 64); GO(64, 16); GO(64, 32); GO(64, 64);
+#endif
 #undef GO
     dge_set_error("conv_stream: unsupported channel configuration %d -> %d", p.Cin, p.Cout);
     return -1;

@@ -6,7 +6,10 @@
 set -e
 cd "$(dirname "$0")/../deep-gan-encoders_amd/csrc"
 mkdir -p ../variants build
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 -c ../../tools/probes/conv_stream_experiments.hip -o build/conv_stream_$1.o
+# third argument "main": compile the product's conv_stream.hip (it carries DGE_SC_TIMING job stamps and DGE_SC_ONLY) instead of the experiment copy
+SRC=../../tools/probes/conv_stream_experiments.hip
+[ "$3" = "main" ] && SRC=conv_stream.hip
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $2 -c $SRC -o build/conv_stream_$1.o
 objs=$(ls build/*.o | grep -v "build/conv_stream")
 hipcc --offload-arch=gfx950 -shared -fPIC $objs build/conv_stream_$1.o -o ../variants/libdge_$1.so
 rm -f build/conv_stream_$1.o
