@@ -172,6 +172,37 @@ def test_grouped_weight_pack_equals_the_single_tensor_pack():
 
 
 @pytest.mark.gpu
+def test_grouped_weight_pack_pairs_forward_and_data_gradient_copies():
+    """A forward copy and the data-gradient copy of the SAME 3x3 bf16 weight share one staged source block in the grouped launch
+    (DgePackDesc::out2, csrc/s2_kernels.hip): bit-identical to the single-tensor packs for full, partial (16 / 24 / 40 channels: padded
+    N tiles, partial K tiles) and 512-channel tiles, in both orders of the table, next to unpaired entries; padding rows stay zero."""
+    from dge_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    shapes = [(32, 16), (16, 16), (64, 32), (24, 40), (128, 64), (512, 512), (40, 24)]
+    ws = [torch.randn(co, ci, 3, 3, device="cuda", generator=g) for co, ci in shapes]
+    w1 = torch.randn(64, 32, 1, 1, device="cuda", generator=g)            # 1x1: never paired
+    entries, singles = [], []
+    for i, w in enumerate(ws):
+        modes = (ops.PACK_FWD, ops.PACK_DGRAD) if i % 2 == 0 else (ops.PACK_DGRAD, ops.PACK_FWD)
+        for m in modes:
+            ref = ops.pack_conv_weight(w, m, ops.BF16, 1.0)
+            singles.append(ref)
+            entries.append((w, m, ops.BF16, 1.0, torch.zeros_like(ref)))
+    for m in (ops.PACK_FWD, ops.PACK_DGRAD):
+        ref = ops.pack_conv_weight(w1, m, ops.BF16, 1.0)
+        singles.append(ref)
+        entries.append((w1, m, ops.BF16, 1.0, torch.zeros_like(ref)))
+    scratch = ops.pack_conv_weights_multi(entries)
+    for (w, m, _, _, o), ref in zip(entries, singles):
+        assert torch.equal(o.view(torch.uint8), ref.view(torch.uint8)), (tuple(w.shape), m)
+    for w in ws + [w1]:
+        w.mul_(-0.75)
+    assert ops.pack_conv_weights_multi(entries, scratch) is scratch
+    for (w, m, _, _, o) in entries:
+        assert torch.equal(o.view(torch.uint8), ops.pack_conv_weight(w, m, ops.BF16, 1.0).view(torch.uint8)), (tuple(w.shape), m)
+
+
+@pytest.mark.gpu
 def test_dense_chain_is_bit_identical_to_the_per_layer_launches():
     """dge_dense_chain (the mapping network's 8 DenseBlocks in one launch, stylegan2_generator.py:262-278) against dge_pixelnorm +
     8 x dge_linear: same arithmetic, same bits"""
