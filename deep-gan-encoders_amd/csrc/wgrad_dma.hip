@@ -67,6 +67,14 @@ struct WCfg {
     static int lds_bytes() { return TAB_OFF + 64 * 4; }
 };
 
+#ifdef DGE_WG_TIMING          // tuning builds: clock stamps of one workgroup's tile loop (tools/perf_wgrad_timing.py)
+__device__ long long wg_tlog[64 * 6];
+#define DGE_WT(k) do { __builtin_amdgcn_sched_barrier(0); const long long t_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); \
+                       if (tlogon && t - t_begin >= 8 && t - t_begin < 40) wg_tlog[(t - t_begin - 8) * 6 + k] = t_; } while (0)
+#else
+#define DGE_WT(k)
+#endif
+
 template <class C>
 __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ X,
                                                                 const float* __restrict__ sc, const float* __restrict__ sh,
@@ -210,11 +218,18 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
 #pragma unroll
     for (int s = 0; s < NS - 1; s++) if (t_begin + s < t_end) issue(s);
     int stage = 0;
+#ifdef DGE_WG_TIMING
+    const bool tlogon = lin == 40 && tid == 0;
+#endif
     for (int t = t_begin; t < t_end; t++) {
         const int younger = t_end - 1 - t;                 // tiles issued after tile t that may stay in flight
+        DGE_WT(0);
         wait_tile(younger < NS - 2 ? younger : NS - 2);    // this wave's pieces of tile t have landed
+        DGE_WT(1);
         __syncthreads();                                   // ... everybody's have, and everybody is done with tile t-1
+        DGE_WT(2);
         if (t + NS - 1 < t_end) issue(stage == 0 ? NS - 1 : stage - 1);
+        DGE_WT(3);
         const unsigned char* sg = lds + stage * C::STAGE;
         const unsigned char* sx = sg + C::GBYTES;
         const int y0 = cty * TH, x0 = ctx * 16;
@@ -281,6 +296,10 @@ __global__ __launch_bounds__(C::NW * 64, 2) void wgrad_dma_kernel(const bf16_t* 
                 }
             }
         });
+#ifdef DGE_WG_TIMING
+        asm volatile("s_nop 0" :: "v"(acc[0][0]), "v"(acc[8][15]));
+#endif
+        DGE_WT(4);
         if (++ctx == tiles_x) { ctx = 0; ++cty; }
         stage = stage + 1 == NS ? 0 : stage + 1;
     }
@@ -392,6 +411,11 @@ int launch(const void* g, const void* x, const float* sc, const float* sh, float
 
 }  // namespace
 
+#ifdef DGE_WG_TIMING
+extern "C" int dge_wgrad_tlog(long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(wg_tlog), (size_t)n * sizeof(long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 // bf16 3x3 weight gradient on the streaming kernel; returns 1 when the shape is not covered (the caller falls back to
 // conv_wgrad_tr_kernel), 0 on success, < 0 on error.
 // dots (optional, with wdot = the layer's weight [cout][cin][3][3] f32): [dots_slots][B][cin][2], pre-zeroed, += (sum g_x*x, sum g_x)
