@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--graph", action="store_true", help="single GPU only: replay the step from a captured hipGraph (removes the "
                     "host launch overhead that bounds small batches); off by default so that N=1 and N>1 run the same path")
+    ap.add_argument("--no-prefetch", action="store_true", help="run the generator pass that opens iteration n + 1 at the start of that iteration "
+                    "instead of beside the second backward of iteration n (EAlignStep.step(prefetch_next=True), the training loop's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the batch-2 and eval-mode-G entries")
@@ -163,7 +165,11 @@ def main():
         st.capture()
         run = lambda i: st.replay(i)
     else:
-        run = lambda i: st.step(i)
+        # the training loop's eager form (dge_amd.e_align.train): every step also issues the generator pass that opens the NEXT iteration,
+        # beside its own second backward.  Iterations are numbered consecutively through warm-up and timed region, each timed step
+        # consumes one prefetched pass and issues one: the work per step is that of the serial loop (extras.serial_sample times it).
+        pf = not a.no_prefetch and a.mtype != 4
+        run = lambda i: st.step(i, prefetch_next=pf)
     # priming (not one of the W warm-up steps): RCCL builds its channels inside the first collective and the allocator / code
     # objects settle during the first step; with a small W that start-up cost would otherwise leak into the timed region
     if dist.is_initialized():
@@ -176,6 +182,8 @@ def main():
     if dist.is_initialized():
         st.comm_stats = {"events": []}         # EAlignStep._sync_grads: events around the exposed part of the gradient exchange
     dt, step_stats = timed_steps(run, a.warmup, a.steps, sync)
+    if not a.graph:
+        st.cancel_prefetch()            # (the pass the last timed step issued for an iteration this run does not make)
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,7 +198,8 @@ def main():
         "config": {"workload": f"E_align_s2 two-phase step, {gname} + {type(E).__name__}(startf={a.start_features}, "
                                f"L={E.layer_count}) + LPIPS-VGG16 (seeded stand-in weights), batch {a.batch}/GPU",
                    "global_batch": a.batch * world, "img_size": a.img_size, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if a.graph else "eager"},
+                   "launch": "hipGraph replay" if a.graph else ("eager; the generator pass of iteration n + 1 issued on a side stream beside the image "
+                                                                 "losses / backward passes of iteration n (train()'s default; extras.serial_sample: without)" if (not a.no_prefetch and a.mtype != 4) else "eager")},
         "step_ms": step_stats,
     }
     if dist.is_initialized():
@@ -235,10 +244,18 @@ def main():
             except Exception as ex:
                 extras["batch2"] = {"value": None, "note": f"not measured: {ex}"}
             del st2
+        if not a.graph and not a.no_prefetch:
+            for i in range(2):
+                st.step(i)
+            dn, sn = timed_steps(lambda i: st.step(i), 2, 8, sync)
+            extras["serial_sample"] = {"value": a.batch * 8 / dn, "unit": "images/sec", "ms_per_step": dn / 8 * 1e3, "step_ms_median": sn["median"],
+                                       "note": "the headline step with the generator pass of an iteration at its own start (--no-prefetch)"}
         G.eval()
         for i in range(2):
-            st.step(i)
-        de, se = timed_steps(lambda i: st.step(i), 2, 6, sync)
+            run(i)
+        de, se = timed_steps(run, 2, 6, sync)
+        if not a.graph:
+            st.cancel_prefetch()
         G.train()
         extras["eval_mode_G"] = {"value": a.batch * 6 / de, "unit": "images/sec", "ms_per_step": de / 6 * 1e3, "step_ms_median": se["median"],
                                  "note": "generator.eval(): no w_avg EMA, no style mixing in the first pass"}

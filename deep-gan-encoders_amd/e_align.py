@@ -363,24 +363,63 @@ class EAlignStep:
         slot[1].record()
         return out
 
-    def step(self, iteration, z=None, noises=None, gen_noises=(None, None), new_z=None):
+    def _draw_and_sample(self, iteration):
+        """The head of an iteration with default inputs (E_align_s2.py:102-115): set_seed, z on the host, generator pass under
+        no_grad.  Runs at the start of step(iteration) - or, with prefetch_next, beside the second backward of step(iteration - 1)."""
+        B = self.batch_size
+        set_seed(iteration % 30000)
+        # every rank draws the same global z and takes its slice (SURVEY 8e)
+        zg = torch.randn(B * self.world, self.z_dim)
+        z = self._upload(zg[self.rank * B:(self.rank + 1) * B])
+        with torch.no_grad():
+            imgs1, w1 = self.gen.sample(z, None)
+        return z, imgs1, w1
+
+    def cancel_prefetch(self):
+        """Drops a generator pass that step(..., prefetch_next=True) issued for an iteration that will not run (end of a loop that
+        could not know it was at its end).  The generator's own state has seen that pass (StyleGAN2 train mode: one w_avg update) and
+        so have the random generators; returns the iteration number it belonged to, or None."""
+        pref = self.__dict__.pop("_pref", None)
+        return None if pref is None else pref[0]
+
+    def _prefetch_ok(self):
+        from . import ops
+        return (self.stage == 2 and self.dev.type == "cuda" and not isinstance(self.gen, _BigGANAdapter) and not self.reference_noise
+                and not ops.is_deterministic() and not torch.cuda.is_current_stream_capturing())
+
+    def step(self, iteration, z=None, noises=None, gen_noises=(None, None), new_z=None, prefetch_next=False):
         """`noises`: optional encoder noise tensors; `gen_noises`: optional (first, second) generator noise lists for
         generators that draw noise per call (StyleGAN1); `new_z`: the style-mixing latent of StyleGAN2's train mode -- all only
-        for parity runs against captured reference noise."""
+        for parity runs against captured reference noise.
+        `prefetch_next`: the caller's promise that its next call is step(iteration + 1) with default inputs (a training loop).  The
+        generator pass that opens that iteration - set_seed(iteration + 1), z, G(z) under no_grad: the training DATA of the encoder, which
+        depends on nothing the encoder does (E_align_s2.py:102-115) - is then issued on a side stream beside this iteration's image
+        losses and backward passes, whose low-resolution launches leave most of the chip idle (measured at batch 8, same box: 22.07 ->
+        21.56 ms per step).  Same work per iteration, same numbers: nothing between that point (behind E(imgs1) and synthesis(w2), the
+        last consumers of random numbers and of the generator's state in an iteration) and the next iteration's start draws a random
+        number or reads w_avg, so every draw and the w_avg update happen in the order of the serial loop.  A step that finds a
+        prefetched pass it was not promised (another iteration number, explicit inputs) raises instead of silently using or dropping it."""
         G, E = self.G, self.E
         B = self.batch_size
         from . import ops
         if isinstance(self.gen, _StyleGAN2Adapter):
             self.gen.new_z = new_z
         ops.zero_arena_begin(self.dev)       # one memset for all of this step's accumulation buffers
-        if z is None or not z.is_cuda:
-            set_seed(iteration % 30000)
         big = isinstance(self.gen, _BigGANAdapter)
-        if z is None:
-            # every rank draws the same global z and takes its slice (SURVEY 8e)
-            zg = self.gen.draw(iteration, B * self.world, self.dev) if big else torch.randn(B * self.world, self.z_dim)
-            z = zg[self.rank * B:(self.rank + 1) * B]
-        z = self._upload(z)
+        pref = self.__dict__.pop("_pref", None)
+        if pref is not None:
+            if pref[0] != iteration or z is not None or noises is not None or new_z is not None or gen_noises != (None, None):
+                raise RuntimeError(f"step({iteration}): the previous step prefetched the generator pass of iteration {pref[0]} with default "
+                                   "inputs (prefetch_next=True is a promise about the next call)")
+            z, imgs1, w1 = pref[1:]
+        else:
+            if z is None or not z.is_cuda:
+                set_seed(iteration % 30000)
+            if z is None:
+                # every rank draws the same global z and takes its slice (SURVEY 8e)
+                zg = self.gen.draw(iteration, B * self.world, self.dev) if big else torch.randn(B * self.world, self.z_dim)
+                z = zg[self.rank * B:(self.rank + 1) * B]
+            z = self._upload(z)
         # the re-pack of the encoder's conv weights (stale since the last optimizer step) beside the generator's first pass:
         # an HBM-bound copy next to small-grid low-resolution layers; joined in front of the encoder
         pack_side = None
@@ -393,8 +432,9 @@ class EAlignStep:
             pack_side.wait_stream(main)
             with torch.cuda.stream(pack_side):
                 refresh_packs(E)
-        with torch.no_grad():
-            imgs1, w1 = self.gen.sample(z, gen_noises[0])
+        if pref is None:
+            with torch.no_grad():
+                imgs1, w1 = self.gen.sample(z, gen_noises[0])
         if pack_side is not None:
             torch.cuda.current_stream(self.dev).wait_stream(pack_side)
         if noises is None and self.reference_noise:
@@ -404,6 +444,24 @@ class EAlignStep:
         imgs2 = self.gen.synth(w2, gen_noises[1])
 
         gctx = losses.GlobalBatch(self.world) if (self.dist_on and self.exact_ddp) else None
+        pf_side = None
+
+        def issue_prefetch():
+            # the next iteration's generator pass on a side stream (see the docstring).  The side stream starts behind everything
+            # queued so far; its results are handed to the next call after the join at the end of this one.
+            nonlocal pf_side
+            if getattr(self, "_pf_stream", None) is None:
+                self._pf_stream = torch.cuda.Stream(device=self.dev)
+            pf_side, main = self._pf_stream, torch.cuda.current_stream(self.dev)
+            pf_side.wait_stream(main)
+            with torch.cuda.stream(pf_side):
+                nxt = self._draw_and_sample(iteration + 1)
+            for t in nxt:
+                t.record_stream(main)
+            self._pref = (iteration + 1,) + tuple(nxt)
+        do_pf = prefetch_next and self._prefetch_ok()
+        if do_pf and _PREFETCH_AT == "loss":
+            issue_prefetch()
         if self.stage == 1:
             # E_align_cropping_s1.py:185-203: .detach().clone() on every loss input, loss_tsa = imgs + medium + small
             with torch.no_grad():
@@ -413,6 +471,8 @@ class EAlignStep:
         else:
             loss_tsa, info_img = losses.image_loss_tsa(imgs1, imgs2, self.lpips, global_batch=gctx)
             self.opt.zero_grad()
+            if do_pf and _PREFETCH_AT == "bwd1":
+                issue_prefetch()
             loss_tsa.backward(retain_graph=True)
             gs = self._sync_grads()
             self.opt.step(grad_scale=gs)
@@ -420,9 +480,13 @@ class EAlignStep:
         loss_w, info_w = losses.space_loss(w1, w2, image_space=False, global_batch=gctx)
         loss_mtv = loss_w * 0.01
         self.opt.zero_grad()
+        if do_pf and pf_side is None:
+            issue_prefetch()
         loss_mtv.backward()
         gs = self._sync_grads()
         self.opt.step(grad_scale=gs)
+        if pf_side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(pf_side)
         ops.zero_arena_end()
         # (detached: a result that kept its grad_fn would keep this iteration's autograd graph alive - and with it the
         #  AccumulateGrad nodes of E's parameters, bound to the stream they were created on; see capture())
@@ -433,6 +497,9 @@ class EAlignStep:
 
 
 _SIDE_STREAMS = os.environ.get("DGE_SIDE_STREAMS", "1") != "0"
+# where step(prefetch_next=True) issues the next iteration's generator pass: beside the image losses ("loss"), the first backward
+# ("bwd1") or the second backward ("bwd2").  Same box, batch 8, two rounds: serial 22.07 / 22.23 ms, bwd2 21.70 / 21.81, bwd1 21.71 / 21.78, loss 21.56 / 21.67
+_PREFETCH_AT = os.environ.get("DGE_PREFETCH_AT", "loss")
 # the early weight re-pack beside the generator's first pass: - 0.13 ms in round 3, + 0.08 ms against this round's kernels (three
 # same-box pairs, 24.08 vs 24.17 ms): opt-in
 _PACK_STREAM = os.environ.get("DGE_PACK_STREAM", "0") == "1"
@@ -609,6 +676,7 @@ def train(tensor_writer=None, args=None):
     use_graph = mode == "graph" or (mode == "auto" and not st.dist_on and args.batch_size <= 2 and args.mtype != 4
                                     and not getattr(args, "deterministic", False))
     first = 0
+    prefetch = not getattr(args, "no_prefetch", False)
     if use_graph:
         r = st.capture()
         first = st._g_iter           # capture() ran iterations 0 .. first - 1 for real (its warm-up): the loop continues behind them,
@@ -617,7 +685,8 @@ def train(tensor_writer=None, args=None):
         if getattr(args, "experiment_dir", None):
             torch.save(E.state_dict(), "%s/E_model_ep0_iter0.pth" % args.experiment_dir)       # the reference's iteration-0 dump
     for iteration in range(first, args.iterations):
-        r = st.replay(iteration) if use_graph else st.step(iteration)
+        # (eager launches: the next iteration's generator pass goes out beside this iteration's second backward, EAlignStep.step)
+        r = st.replay(iteration) if use_graph else st.step(iteration, prefetch_next=(prefetch and iteration + 1 < args.iterations))
         if iteration % 100 == 0:
             print("ep_%d_iter_%d" % (iteration // 30000, iteration % 30000), "loss_tsa", float(r["loss_tsa"]),
                   "loss_w", float(r["loss_w"]))
@@ -637,6 +706,8 @@ def main(argv=None):
     add_model_args(parser)
     parser.add_argument("--launch", choices=("auto", "eager", "graph"), default="auto",
                         help="auto: hipGraph replay of the iteration for single-process runs at batch <= 2, eager otherwise")
+    parser.add_argument("--no_prefetch", action="store_true", help="eager launches: run the generator pass of iteration n + 1 at the start of that "
+                        "iteration instead of beside the second backward of iteration n (same numbers either way)")
     parser.add_argument("--stage", type=int, default=2, help="2: E_align_s2.py; 1: E_align_cropping_s1.py (latent phase only trains E)")
     parser.add_argument("--legacy_zero_grad", action="store_true", help="stage 1: optimizer.zero_grad() as torch < 2.0 (zero-filled gradients, the "
                         "reference's pinned environment): the first optimizer step of an iteration ticks every Adam state")

@@ -748,3 +748,49 @@ def test_train_loop_makes_the_same_updates_in_graph_and_eager_launch_modes(capsy
     assert out["eager"][0] == out["graph"][0] == 10, (out["eager"][0], out["graph"][0])
     # w_avg: EMA over the batch mean of mapping(z_it), it = 0 .. 4 (stylegan2_generator.py:177-181) - identical z sequence in both modes
     assert relerr(out["graph"][1], out["eager"][1].numpy()) < 1e-5
+
+
+def test_prefetched_generator_pass_makes_the_same_iterations():
+    """EAlignStep.step(..., prefetch_next=True): the generator pass that opens iteration n + 1 (set_seed, z, G(z) under no_grad,
+    E_align_s2.py:102-115) issued beside the second backward of iteration n.  Nothing between that point and the start of iteration
+    n + 1 draws a random number or reads the generator's state, so the loop makes the iterations of the serial loop: the same z / style
+    mixing / noise sequence (w_avg after the run is bit-identical: the mapping path has no atomics), the same losses and encoder
+    parameters up to the order of the f32 atomics.  A step that was not promised raises."""
+    import dge_amd
+    from dge_amd import ops
+    from dge_amd.encoder import BE
+    from dge_amd.lpips import LPIPS
+    from dge_amd.e_align import EAlignStep
+    if ops.is_deterministic():
+        pytest.skip("the prefetch is not offered in deterministic mode (one stream owns the slot workspace)")
+    res = {}
+    for mode in ("serial", "prefetch"):
+        G = dge_amd.StyleGAN2Generator(64, fmaps_base=2048, fmaps_max=128, compute_dtype="f32").cuda()
+        G.load_state_dict(R.fill_s2(s2_shapes(64, fmaps_base=2048, fmaps_max=128), seed=11))
+        G.train()
+        for p in G.parameters():
+            p.requires_grad_(False)
+        E = BE(startf=16, maxf=64, layer_count=5, compute_dtype="f32").cuda()
+        E.load_state_dict(R.fill_encoder(enc_shapes(16, 64, 5), seed=31))
+        LP = LPIPS(compute_dtype="f32").cuda()
+        LP.load_state_dict(LR.seeded_params(0))
+        st = EAlignStep(G, E, LP, lr=0.0015, batch_size=2)
+        losses = []
+        for it in range(4):
+            r = st.step(it, prefetch_next=(mode == "prefetch" and it < 3))
+            losses.append((float(r["loss_tsa"]), float(r["loss_w"])))
+        res[mode] = (losses, G.truncation.w_avg.detach().cpu().clone(), {k: v.detach().cpu().clone() for k, v in E.state_dict().items()})
+        if mode == "prefetch":
+            assert st.__dict__.get("_pref") is None          # the last step issued none
+            st.step(4, prefetch_next=True)
+            with pytest.raises(RuntimeError, match="prefetched"):
+                st.step(7)
+            assert st.cancel_prefetch() is None              # the failed call consumed the slot
+            st.step(5, prefetch_next=True)
+            assert st.cancel_prefetch() == 6
+    (l0, w0, p0), (l1, w1, p1) = res["serial"], res["prefetch"]
+    assert torch.equal(w0, w1)
+    for a, b in zip(l0, l1):
+        assert abs(a[0] - b[0]) <= 1e-4 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-4 * abs(a[1]), (l0, l1)
+    for k in p0:
+        assert relerr(p1[k], p0[k].numpy()) < 1e-4, k
