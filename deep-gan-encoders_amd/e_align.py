@@ -384,7 +384,7 @@ class EAlignStep:
 
     def _prefetch_ok(self):
         from . import ops
-        return (self.stage == 2 and self.dev.type == "cuda" and not isinstance(self.gen, _BigGANAdapter) and not self.reference_noise
+        return (_SIDE_STREAMS and self.stage == 2 and self.dev.type == "cuda" and not isinstance(self.gen, _BigGANAdapter) and not self.reference_noise
                 and not ops.is_deterministic() and not torch.cuda.is_current_stream_capturing())
 
     def step(self, iteration, z=None, noises=None, gen_noises=(None, None), new_z=None, prefetch_next=False):

@@ -38,13 +38,16 @@ def _models():
     return G, E, LP
 
 
-def _run_steps(B, nsteps=2):
+def _run_steps(B, nsteps=2, prefetch=False):
     from dge_amd.e_align import EAlignStep
     G, E, LP = _models()
     st = EAlignStep(G, E, LP, lr=0.0015, batch_size=B)
     out = {}
     for it in range(nsteps):
-        r = st.step(it)                     # z, style-mixing latent and encoder noise are all drawn inside
+        # z, style-mixing latent and encoder noise are all drawn inside.  prefetch (the ranks of the two-process run): the training
+        # loop's eager form - the generator pass of iteration it + 1, with its w_avg all-reduce, goes out on a side stream beside the
+        # image losses of iteration it, between the collectives of the main stream
+        r = st.step(it, prefetch_next=(prefetch and it + 1 < nsteps))
         out[f"it{it}_w2"] = r["w2"].detach().cpu()
         out[f"it{it}_losses"] = torch.stack([r["loss_tsa"].detach().cpu(), r["loss_w"].detach().cpu()])
         out[f"it{it}_info"] = r["info_img"].cpu()
@@ -66,7 +69,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out = _run_steps(2)
+        out = _run_steps(2, prefetch=True)
         # numpy (pickled by value): torch tensors would travel as shared-memory handles that die with this process
         out["params"] = {k: v.numpy() for k, v in out["params"].items()}
         q.put((rank, {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in out.items()}))
