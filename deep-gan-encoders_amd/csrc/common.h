@@ -211,8 +211,10 @@ __device__ __forceinline__ void block_chan_flush(float (&s)[NS][EP], int cpt, in
 // Workgroups per sample of the streaming kernels that end in a per-(b,c) atomic flush (block_chan_flush).  Same-address
 // f32 atomics retire at ~40 ns, so W workgroups cost W*40 ns on top of the data time; few workgroups underfeed HBM.
 // Measured on the E_align step: 1024/sample -> 256/sample +9 % step throughput at B=8; 512 loses 2 % at B=2 against 256.
+static inline int dge_stream_grid_cap1();
 static inline int dge_stream_grid(int npix, int ppi, int B) {
     int cap = 1024 / (B < 1 ? 1 : B); cap = cap < 96 ? 96 : (cap > 256 ? 256 : cap);
+    if (B == 1) cap = dge_stream_grid_cap1();
     const int g = (npix + ppi - 1) / ppi;
     return g > cap ? cap : (g < 1 ? 1 : g);
 }
@@ -241,6 +243,10 @@ struct DgeEnv {
     int torgb_thread, wgrad_th8, wgrad_groups, up_dbg;   // DGE_TORGB_THREAD, DGE_WGRAD_TH8, DGE_WGRAD_GROUPS (0 = default), DGE_UP_DBG
 };
 const DgeEnv& dge_env();
+// batch 1 (the embedding_img inversion loop): workgroups per sample of the flushing stream kernels.  256 = one workgroup per CU fed HBM at
+// 0.7 TB/s (blur_noise_act at 1024^2: 95 us for 67 MB); measured on the loop (hipGraph replay): 256 -> 13.2 ms per iteration, 384 -> 12.8,
+// 512 -> 12.7, 768 -> 12.8, 1024 -> 13.1 (the same-address flush takes over).  DGE_STREAM_CAP1 overrides.
+static inline int dge_stream_grid_cap1() { static const int v = getenv("DGE_STREAM_CAP1") ? atoi(getenv("DGE_STREAM_CAP1")) : 512; return v < 32 ? 32 : v; }
 
 // error plumbing shared by the C ABI translation units
 void dge_set_error(const char* fmt, ...);
