@@ -139,6 +139,8 @@ SIGNATURES = {
     "dge_rgb_tanh_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dge_sn_group": [_P, _I, _I, _I, _P, _F, _I, _P],
     "dge_sn_entry_size": [],
+    "dge_cbn_sn_wgrad_entry_size": [],
+    "dge_cbn_sn_wgrad_group": [_P, _I, C.c_longlong, _I, _P, _I, _I, _P, _P],
     "dge_upconv_supported": [_I, _I, _I],
     "dge_pack_upconv_weight": [_P, _P, _I, _I, _F, _I, _P],
     "dge_upconv_fir": [_P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _F, _F, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -10,6 +10,8 @@ prologue (no activation in between), so its backward is linear: the data-gradien
 conv_3 / bn_3 commute with the average pool (1x1 conv, per-channel affine), so that branch is differentiated at the pooled
 resolution.  Gradient enters through z only (E_align_s2.py:207-221; loss_c is commented out).
 """
+import os
+
 import torch
 
 from . import ops
@@ -79,8 +81,16 @@ def big_encoder_forward(E, img, cond_vector, noises=None, save=False, truncation
     return xo, c_v, z, saved
 
 
-def _cbn_param_grads(bn, bn_ctx, dots, cond, grads, name):
-    """dots [B,C,2] = (dL/da, dL/db) -> gradients of `scale.weight_orig` / `offset.weight_orig` (biggan BigGANBatchNorm :141-144)."""
+_NO_CBN_GROUP = bool(os.environ.get("DGE_NO_CBN_GROUP"))
+_CBN_TAB = {}          # device -> (host bytes of the last entry table, its device copy, the pinned staging buffer)
+
+
+def _cbn_param_grads(bn, bn_ctx, dots, cond, grads, name, pend=None):
+    """dots [B,C,2] = (dL/da, dL/db) -> gradients of `scale.weight_orig` / `offset.weight_orig` (biggan BigGANBatchNorm :141-144).
+    `pend` (a list): the work is only recorded; _cbn_param_grads_flush runs all norms of the backward in two launches."""
+    if pend is not None and not _NO_CBN_GROUP:
+        pend.append((bn, bn_ctx, dots, name))
+        return
     g_a, g_b = dots[:, :, 0], dots[:, :, 1]
     g_scale = ((g_a - g_b * bn_ctx["mean"]) * bn_ctx["rstd"]).contiguous()
     g_off = g_b.contiguous()
@@ -91,11 +101,67 @@ def _cbn_param_grads(bn, bn_ctx, dots, cond, grads, name):
         grads[f"{name}.{key}.weight_orig"] = sn_weight_grad(gw, w_live, sn)
 
 
+def _cbn_param_grads_flush(pend, cond, grads):
+    """All conditional-batch-norm parameter gradients of a backward: dge_cbn_sn_wgrad_group (two launches; the per-norm form above
+    is ~20 torch launches per norm: dense_wgrad + the spectral-norm backward as tensor glue)."""
+    if not pend:
+        return
+    import numpy as np
+    dev = cond.device
+    B, K = cond.shape
+    rec = np.dtype([("dots", "u8"), ("mean", "u8"), ("rstd", "u8"), ("W", "u8"), ("u", "u8"), ("v", "u8"), ("sigma", "u8"), ("out", "u8"),
+                    ("C", "i4"), ("kind", "i4"), ("row0", "i8")])
+    assert rec.itemsize == ops.lib().dge_cbn_sn_wgrad_entry_size()
+    n = 2 * len(pend)
+    tab = np.zeros(n, dtype=rec)
+    Cs = [int(d.shape[1]) for (_, _, d, _) in pend for _k in range(2)]
+    rows = int(sum(Cs))
+    out_all = torch.empty(rows * K, dtype=torch.float32, device=dev)
+    keep = []
+    r0 = 0
+    for i, (bn, ctx, dots, name) in enumerate(pend):
+        Cc = int(dots.shape[1])
+        mean, rstd = ctx["mean"].float().contiguous(), ctx["rstd"].float().contiguous()
+        keep += [mean, rstd]
+        for kind, key, sn in ((0, "scale", ctx["sn_sc"]), (1, "offset", ctx["sn_of"])):
+            w_live = getattr(bn, key).weight_orig
+            if tuple(w_live.shape) != (Cc, K) or not w_live.is_contiguous():
+                raise ops.DgeError(f"{name}.{key}: weight_orig {tuple(w_live.shape)} does not match [C={Cc}, K={K}]")
+            u, v, sig = sn["u"].contiguous(), sn["v"].contiguous(), sn["sigma"].reshape(1)
+            keep += [u, v, sig]
+            e = tab[2 * i + kind]
+            e["dots"], e["mean"], e["rstd"] = dots.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            e["W"], e["u"], e["v"], e["sigma"] = w_live.data_ptr(), u.data_ptr(), v.data_ptr(), sig.data_ptr()
+            e["out"] = out_all.data_ptr() + 4 * r0 * K
+            e["C"], e["kind"], e["row0"] = Cc, kind, r0
+            grads[f"{name}.{key}.weight_orig"] = out_all[r0 * K:(r0 + Cc) * K].view(Cc, K)
+            r0 += Cc
+    # the table is the same from step to step once the allocator has settled (arena buffers, cached blocks): uploaded only when it
+    # changes, through a pinned buffer (a pageable host-to-device copy waits for the stream to drain - twice per step here)
+    raw = tab.view(np.uint8)
+    hit = _CBN_TAB.get(dev)
+    if hit is not None and hit[0].shape == raw.shape and np.array_equal(hit[0], raw):
+        tab_dev = hit[1]
+    else:
+        pin = torch.from_numpy(raw.copy()).pin_memory()
+        tab_dev = pin.to(dev, non_blocking=True)
+        _CBN_TAB[dev] = (raw.copy(), tab_dev, pin)
+    rowdot = torch.empty(rows, dtype=torch.float32, device=dev)
+    ops.check(ops.lib().dge_cbn_sn_wgrad_group(ops._p(tab_dev), n, rows, max(Cs), ops._f32(cond.contiguous()), B, K, ops._p(rowdot), ops._stream()),
+              "dge_cbn_sn_wgrad_group")
+    pend.clear()
+
+
+_ZERO_BC = {}
+
+
 def _affine_coef(a):
-    """in_bwd coefficients (A, Bc, Cc) = (a, 0, 0): g_x = a * g."""
-    coef = torch.zeros(a.shape + (3,), dtype=torch.float32, device=a.device)
-    coef[:, :, 0] = a
-    return coef
+    """in_bwd coefficients (A, Bc, Cc) = (a, 0, 0): g_x = a * g.  (one launch: the zero planes are cached per shape)"""
+    key = (tuple(a.shape), a.device)
+    z = _ZERO_BC.get(key)
+    if z is None:
+        z = _ZERO_BC[key] = torch.zeros(a.shape, dtype=torch.float32, device=a.device)
+    return torch.stack((a.float(), z, z), dim=-1)
 
 
 def big_encoder_backward(E, saved, g_z, g_cv=None):
@@ -108,6 +174,7 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
     dt = ops.dtype_of(saved["x0"])
     cond = saved["cond"]
     grads = {}
+    pend = []          # conditional-batch-norm parameter gradients: recorded per norm, run grouped behind the block loop
 
     def lin_bwd(lin, gy, x, name):
         W = lin.weight.detach()
@@ -144,7 +211,7 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
             grads[pre + "conv_2.weight"] = gW2
             dots2 = ops.zeros((B, Cc, 2), dev)
             g_u2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
-            _cbn_param_grads(blk.batch_norm_2, rec["c2"], dots2, cond, grads, pre + "batch_norm_2")
+            _cbn_param_grads(blk.batch_norm_2, rec["c2"], dots2, cond, grads, pre + "batch_norm_2", pend)
             g_pre1 = ops.in_bwd(g_u2, x1, _affine_coef(rec["a2"]), noise=rec["n1"], act=True, red=red1)
             if has3:
                 xp = rec["xp"]
@@ -154,7 +221,7 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
                 grads[pre + "conv_3.weight"] = gW3
                 dots3 = ops.zeros((B, Cc, 2), dev)
                 g_u3 = ops.conv2d(g_out, _packed(cache, blk.conv_3, dt, ops.PACK_DGRAD), Cc, 1, stats=dots3, dot_src=xp)
-                _cbn_param_grads(blk.batch_norm_3, rec["c3"], dots3, cond, grads, pre + "batch_norm_3")
+                _cbn_param_grads(blk.batch_norm_3, rec["c3"], dots3, cond, grads, pre + "batch_norm_3", pend)
                 extra = ops.in_bwd(g_u3, xp, _affine_coef(rec["a3"]))          # a3 * g at the pooled resolution
             else:
                 extra = g_out
@@ -168,8 +235,9 @@ def big_encoder_backward(E, saved, g_z, g_cv=None):
         grads[pre + "conv_1.weight"] = gW1
         dots1 = ops.zeros((B, Cc, 2), dev)
         g_u1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
-        _cbn_param_grads(blk.batch_norm_1, rec["c1"], dots1, cond, grads, pre + "batch_norm_1")
+        _cbn_param_grads(blk.batch_norm_1, rec["c1"], dots1, cond, grads, pre + "batch_norm_1", pend)
         g_out = ops.in_bwd(g_u1, x, _affine_coef(rec["a1"]), extra=extra, extra_pool=extra_pool, extra_scale=extra_scale)
+    _cbn_param_grads_flush(pend, cond, grads)
     fr = ops.fromrgb_bwd(g_out, saved["x0"], saved["img"].float())
     C0 = E.startf
     grads["FromRGB.from_rgb.weight"] = fr[:, :3].reshape(C0, 3, 1, 1)

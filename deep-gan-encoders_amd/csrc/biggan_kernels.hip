@@ -380,3 +380,67 @@ extern "C" int dge_sn_group(const void* entries, int n, int maxO, int maxK, floa
     return 0;
 }
 extern "C" int dge_sn_entry_size(void) { return (int)sizeof(SnEntry); }
+
+// ------------------------------------------------------------------ parameter gradients of ALL conditional batch norms of a backward
+// A BigGANBatchNorm has two spectral-norm linears of the condition vector (scale / offset, biggan BigGANBatchNorm :141-144).  With the
+// per-(b,c) sums (dL/da, dL/db) of its affine from the data-gradient epilogue, the gradient w.r.t. weight_orig is
+//   gy[b,o] = (g_a - g_b * mean[o]) * rstd[o]   (scale)   |   g_b   (offset)
+//   gw[o,k] = sum_b gy[b,o] * cond[b,k]                                  (dense weight gradient)
+//   out     = (gw - <gw, W> / sigma * u v^T) / sigma                    (spectral norm backward, u / v constant: sn_weight_grad)
+// - 20 launches per batch norm as torch glue (E_BIG: 21 norms, two backward passes per step: ~900 launches of a host-bound step).
+// Here: one table entry per linear, two launches per backward.  No atomics: pass 1 leaves gw and one partial <gw, W> per row, pass 2
+// sums an entry's partials in a fixed order.
+struct CbnGradEntry { const float* dots; const float* mean; const float* rstd; const float* W; const float* u; const float* v; const float* sigma;
+                      float* out; int C; int kind; long long row0; };
+__global__ __launch_bounds__(256) void cbn_sn_wgrad_rows_kernel(const CbnGradEntry* __restrict__ E, int n, long long rows, const float* __restrict__ cond,
+                                                                int B, int K, float* __restrict__ rowdot) {
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (E[mid].row0 <= row) lo = mid; else hi = mid - 1; }
+    const CbnGradEntry e = E[lo];
+    const int o = (int)(row - e.row0);
+    float part = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float gw = 0.f;
+        for (int b = 0; b < B; b++) {
+            const float ga = e.dots[((size_t)b * e.C + o) * 2], gb = e.dots[((size_t)b * e.C + o) * 2 + 1];
+            const float gy = e.kind == 0 ? (ga - gb * e.mean[o]) * e.rstd[o] : gb;
+            gw = fmaf(gy, cond[(size_t)b * K + k], gw);
+        }
+        e.out[(size_t)o * K + k] = gw;
+        part = fmaf(gw, e.W[(size_t)o * K + k], part);
+    }
+    part = wave_sum(part);
+    if (lane == 0) rowdot[row] = part;
+}
+__global__ __launch_bounds__(256) void cbn_sn_wgrad_apply_kernel(const CbnGradEntry* __restrict__ E, int K, const float* __restrict__ rowdot) {
+    __shared__ float red[256];
+    const CbnGradEntry e = E[blockIdx.y];
+    float s = 0.f;
+    for (int o = threadIdx.x; o < e.C; o += 256) s += rowdot[e.row0 + o];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    const float sigma = e.sigma[0];
+    const float dot = red[0] / sigma;
+    const long long total = (long long)e.C * K;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int o = (int)(i / K), k = (int)(i - (long long)o * K);
+        e.out[i] = (e.out[i] - dot * (e.u[o] * e.v[k])) / sigma;
+    }
+}
+extern "C" int dge_cbn_sn_wgrad_entry_size(void) { return (int)sizeof(CbnGradEntry); }
+// entries: device array of n CbnGradEntry (row0 = prefix sum of C); rowdot: scratch of `rows` floats; cond [B][K] f32
+extern "C" int dge_cbn_sn_wgrad_group(const void* entries, int n, long long rows, int maxC, const float* cond, int B, int K, float* rowdot,
+                                      hipStream_t s) {
+    DGE_CHECK(entries && cond && rowdot && n >= 1 && rows >= 1 && B >= 1 && K >= 1, "cbn_sn_wgrad_group: bad arguments");
+    hipLaunchKernelGGL(cbn_sn_wgrad_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const CbnGradEntry*)entries, n, rows, cond, B, K, rowdot);
+    DGE_LAUNCH_CHECK("cbn_sn_wgrad_rows");
+    const long long per = (long long)maxC * K;
+    int gx = (int)((per + 256 * 8 - 1) / (256 * 8)); gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    hipLaunchKernelGGL(cbn_sn_wgrad_apply_kernel, dim3(gx, n), dim3(256), 0, s, (const CbnGradEntry*)entries, K, rowdot);
+    DGE_LAUNCH_CHECK("cbn_sn_wgrad_apply");
+    return 0;
+}

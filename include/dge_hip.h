@@ -446,6 +446,12 @@ int dge_nearest_up2_bwd(const void* ghi, const void* x, void* glow, float* stats
  * (dge_sn_entry_size() bytes each; t pre-zeroed in train mode; usnap / vsnap receive the u, v used for sigma). */
 int dge_sn_group(const void* entries, int n, int maxO, int maxK, float* sigma, float eps, int training, dge_stream_t stream);
 int dge_sn_entry_size(void);
+/* Weight gradients of all conditional-batch-norm linears of a backward in two launches (biggan BigGANBatchNorm :141-144 differentiated, through the
+ * spectral norm with u, v constant): entry = {dots [B][C][2] = (dL/da, dL/db) of the norm's affine, mean [C], rstd [C] (scale linear; NULL for the
+ * offset linear: kind 1), weight_orig [C][K] (live), u [C], v [K], sigma [1], out [C][K], C, kind, row0 = rows before this entry};
+ * out = (gw - <gw, W> / sigma * u v^T) / sigma with gw[o][k] = sum_b gy[b][o] cond[b][k].  rowdot: scratch of `rows` floats. */
+int dge_cbn_sn_wgrad_entry_size(void);
+int dge_cbn_sn_wgrad_group(const void* entries, int n, long long rows, int maxC, const float* cond, int B, int K, float* rowdot, dge_stream_t stream);
 
 /* ---- counter-based normal noise (Philox4x32-10 + Box-Muller; csrc/rng_kernels.hip) ----
  * Replaces the torch.randn draws of the training step (model/E/E.py:60,73 encoder noise; stylegan2_generator.py:187 new_z,
