@@ -182,8 +182,13 @@ __global__ __launch_bounds__(128, 2) void upconv_stream_kernel(UpsParams p) {
     // epilogue constants of this lane's 8 channels (gain folded: every supported activation is positively homogeneous)
     const int c0 = wave * 16 + 8 * kh;
     float bia[8];
+    {   // two 16-byte loads (eight conditional scalar loads were eight dependent round trips of the job's prologue)
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (p.bias) { b0 = *(const float4*)(p.bias + c0); b1 = *(const float4*)(p.bias + c0 + 4); }
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-    for (int e = 0; e < 8; e++) bia[e] = p.bias ? p.bias[c0 + e] * p.bias_scale * p.gain : 0.f;
+        for (int e = 0; e < 8; e++) bia[e] = bv[e] * p.bias_scale * p.gain;
+    }
     const float nwv = p.noise ? p.noise_w[0] * p.gain : 0.f;
     const float slope = p.act == DGE_ACT_LRELU ? 0.2f : (p.act == DGE_ACT_RELU ? 0.f : 1.f);
 
