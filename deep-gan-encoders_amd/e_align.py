@@ -459,7 +459,8 @@ class EAlignStep:
             for t in nxt:
                 t.record_stream(main)
             self._pref = (iteration + 1,) + tuple(nxt)
-        do_pf = prefetch_next and self._prefetch_ok()
+        # (a parity run that injects its own style-mixing latent leaves it on the adapter: the next iteration's pass must not see it)
+        do_pf = prefetch_next and self._prefetch_ok() and getattr(self.gen, "new_z", None) is None
         if do_pf and _PREFETCH_AT == "loss":
             issue_prefetch()
         if self.stage == 1:
