@@ -245,11 +245,19 @@ def _pack_all(module, sns, dt, dgrad):
     when the pass is saved for a backward) instead of one dge_pack_conv_weight launch per conv and pass (round 5 profile of --mtype 4:
     214 pack launches per step).  The W_eff are the ones sn_prepare() parked on the modules; the packed tensors are allocated on first
     use and refreshed in place afterwards (same stream: a pass reads them before the next pass rewrites them).  Returns
-    {id(sn): {mode: packed}}; modules whose W_eff is not parked (per-weight path) are left to pack_conv_weight."""
+    {id(sn): {mode: packed}}; modules whose W_eff is not parked (per-weight path) are left to pack_conv_weight.
+
+    The data-gradient copies are SHARED buffers, not snapshots: a second saved pass rewrites them (the power iteration moves W_eff on
+    every train-mode pass).  Every saved pass therefore takes a stamp (`out["_stamp"]`, kept in its records next to `wpd`): a backward
+    uses `wpd` only while its stamp is still the live one (`_wpd_live`) and otherwise packs the record's own `w` again."""
     out, entries = {}, {ops.PACK_FWD: [], ops.PACK_DGRAD: []}
     if _NO_PACK_GROUP:
         return out
     cache = module.__dict__.setdefault("_pk_cache", {})
+    if dgrad:
+        cell = module.__dict__.setdefault("_pk_stamp", [0])
+        cell[0] += 1
+        out["_stamp"] = (cell, cell[0])
     for sn in sns:
         prep = sn.__dict__.get("_prep")
         if prep is None or prep[0].dim() != 4:
@@ -258,7 +266,7 @@ def _pack_all(module, sns, dt, dgrad):
         if not w.is_contiguous():
             continue
         for mode in ((ops.PACK_FWD, ops.PACK_DGRAD) if dgrad else (ops.PACK_FWD,)):
-            key = (id(sn), mode, dt)
+            key = (id(sn), mode, dt, w.device)
             pk = cache.get(key)
             if pk is None:
                 pk = cache[key] = ops.pack_conv_weight(w, mode, dt, 1.0)        # first pass: allocates (and packs)
@@ -269,6 +277,13 @@ def _pack_all(module, sns, dt, dgrad):
         if ent:
             module.__dict__["_pk_scratch_%d" % mode] = ops.pack_conv_weights_multi(ent, module.__dict__.get("_pk_scratch_%d" % mode))
     return out
+
+
+def _wpd_live(wpd, stamp):
+    """The shared data-gradient copy `wpd` of a saved pass, or None when a later saved pass has rewritten it (see _pack_all)."""
+    if wpd is None or stamp is None or stamp[0][0] != stamp[1]:
+        return None
+    return wpd
 
 
 class GenBlock(nn.Module):
@@ -299,7 +314,7 @@ class GenBlock(nn.Module):
             if wp is None:
                 wp = ops.pack_conv_weight(w, ops.PACK_FWD, dt, 1.0)
             if saved is not None:
-                recs.append(dict(inp=inp, a=a, b=b, w=w, k=k, ctx=ctx, wpd=pk.get(ops.PACK_DGRAD)))
+                recs.append(dict(inp=inp, a=a, b=b, w=w, k=k, ctx=ctx, wpd=pk.get(ops.PACK_DGRAD), stamp=(packed or {}).get("_stamp")))
             return ops.conv2d(inp, wp, cout, k, in_scale=a, in_shift=b, in_relu=True, bias=sn.bias.detach(), **kw)
         t = conv(self.conv_0, self.bn_0, x, 1, self.mid)
         t = conv(self.conv_1, self.bn_1, t, 3, self.mid, in_up2=self.up_sample)
@@ -316,7 +331,7 @@ class GenBlock(nn.Module):
         for idx in (3, 2, 1, 0):
             r = recs[idx]
             cin = r["inp"].shape[3]
-            wpd = r.get("wpd")
+            wpd = _wpd_live(r.get("wpd"), r.get("stamp"))
             gu = ops.conv2d(g, wpd if wpd is not None else ops.pack_conv_weight(r["w"], ops.PACK_DGRAD, dt, 1.0), cin, r["k"])
             if idx == 1 and self.up_sample:
                 gu, _ = ops.nearest_up2_bwd(gu)
@@ -364,7 +379,7 @@ class SelfAttn(nn.Module):
         gam = self.gamma.detach().reshape(1, 1).expand(B, Cc).contiguous()
         if saved is not None:
             saved.append(("attn", self, dict(theta=theta, phi_pre=phi_pre, phi=phi, g_pre=g_pre, g=g, ws=ws, probs=probs,
-                                             wpd=[pk_.get(ops.PACK_DGRAD) for pk_ in pks])))
+                                             wpd=[pk_.get(ops.PACK_DGRAD) for pk_ in pks], stamp=(packed or {}).get("_stamp"))))
         return ops.conv2d(o, pk(ws[3]), Cc, 1, out_scale=gam, addend=x, add_scale=1.0)
 
     def backward(self, rec, g_out, dt):
@@ -375,7 +390,7 @@ class SelfAttn(nn.Module):
         B, H, W, D = theta.shape
         M, DV, Cc = phi.shape[1] * phi.shape[2], gv.shape[3], 8 * D
         wth, wph, wg, wo = rec["ws"]
-        dg = {id(w): p_ for w, p_ in zip(rec["ws"], rec.get("wpd") or [None] * 4)}
+        dg = {id(w): _wpd_live(p_, rec.get("stamp")) for w, p_ in zip(rec["ws"], rec.get("wpd") or [None] * 4)}
         pkd = lambda w: dg[id(w)] if dg.get(id(w)) is not None else ops.pack_conv_weight(w, ops.PACK_DGRAD, dt, 1.0)
         pkf = lambda m: ops.pack_conv_weight(m.float().contiguous().view(m.shape[0], m.shape[1], 1, 1), ops.PACK_FWD, dt, 1.0)
         gam = self.gamma.detach().reshape(1, 1).expand(B, DV).contiguous()

@@ -402,16 +402,22 @@ class EAlignStep:
         G, E = self.G, self.E
         B = self.batch_size
         from . import ops
+        # the promise is checked before this call has any side effect: a mismatch leaves the prefetched pass where it is
+        # (cancel_prefetch() drops it) and the step object as it was
+        pref = self.__dict__.get("_pref")
+        if pref is not None and (pref[0] != iteration or z is not None or noises is not None or new_z is not None or gen_noises != (None, None)):
+            raise RuntimeError(f"step({iteration}): the previous step prefetched the generator pass of iteration {pref[0]} with default "
+                               "inputs (prefetch_next=True is a promise about the next call)")
+        self.__dict__.pop("_pref", None)
         if isinstance(self.gen, _StyleGAN2Adapter):
             self.gen.new_z = new_z
         ops.zero_arena_begin(self.dev)       # one memset for all of this step's accumulation buffers
         big = isinstance(self.gen, _BigGANAdapter)
-        pref = self.__dict__.pop("_pref", None)
         if pref is not None:
-            if pref[0] != iteration or z is not None or noises is not None or new_z is not None or gen_noises != (None, None):
-                raise RuntimeError(f"step({iteration}): the previous step prefetched the generator pass of iteration {pref[0]} with default "
-                                   "inputs (prefetch_next=True is a promise about the next call)")
-            z, imgs1, w1 = pref[1:]
+            # the pass was issued on the side stream: the consumer orders itself behind the event recorded there (the issuing step's
+            # own join at its end may not have run if that step raised in between)
+            torch.cuda.current_stream(self.dev).wait_event(pref[4])
+            z, imgs1, w1 = pref[1:4]
         else:
             if z is None or not z.is_cuda:
                 set_seed(iteration % 30000)
@@ -456,9 +462,11 @@ class EAlignStep:
             pf_side.wait_stream(main)
             with torch.cuda.stream(pf_side):
                 nxt = self._draw_and_sample(iteration + 1)
+                done = torch.cuda.Event()
+                done.record(pf_side)
             for t in nxt:
                 t.record_stream(main)
-            self._pref = (iteration + 1,) + tuple(nxt)
+            self._pref = (iteration + 1,) + tuple(nxt) + (done,)
         # (a parity run that injects its own style-mixing latent leaves it on the adapter: the next iteration's pass must not see it)
         do_pf = prefetch_next and self._prefetch_ok() and getattr(self.gen, "new_z", None) is None
         if do_pf and _PREFETCH_AT == "loss":

@@ -5,7 +5,7 @@ import math
 
 import torch
 
-from ._lib import lib, check, ConvDesc, ConvPPDesc, DgeError
+from ._lib import lib, check, ConvDesc, ConvPPDesc, DgeError, last_kernel
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_LRELU, ACT_RELU, LIN_RSQRT = 0, 1, 2, 3
@@ -14,6 +14,7 @@ PACK_FRAG = 0x100     # OR-ed into a pack mode: MFMA-fragment order for the low-
 import os as _os
 import weakref as _weakref
 _PF = {"on": not _os.environ.get("DGE_NO_PREFETCH"), "prev": {}, "next": {}}     # low-resolution weight prefetch chain (conv2d)
+KERNEL_LOG = None   # tests set this to a list: (kernel instantiation name, stream handle) per conv_pp / up_pp launch (which streams ran them)
 PROFILE = None      # bench.py sets this to a list: (start_event, stop_event, algorithmic_flops, tag, algorithmic_bytes) per conv launch
 
 
@@ -625,6 +626,8 @@ def conv_pp(x, w_pp, cout, out_scale=None, bias=None, bias_scale=1.0, noise=None
         PROFILE.append((e0, e1, 2.0 * macs * B, (B, H, W, Cin, cout, 3, False, bool(in_s2d or in_t2d)), abytes))
     else:
         check(lib().dge_conv_pp(C.byref(d), _stream()), "dge_conv_pp")
+    if KERNEL_LOG is not None:
+        KERNEL_LOG.append((last_kernel(), _stream()))
     return out
 
 

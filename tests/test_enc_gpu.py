@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import golden, with_fixture_params, meas
+from tests.conftest import golden, with_fixture_params, meas, MODES
 from tests.golden import recipe as R
 from tests.helpers import enc_shapes
 from oracle import ref_torch as O
@@ -58,9 +58,15 @@ def test_state_dict_surface():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cd", ["f32", "bf16"])
-def test_encoder_backward_vs_reference_golden(cd):
-    """All parameter gradients of <w, gw> against the reference's autograd (enc_small.npz)."""
+def test_encoder_backward_vs_reference_golden(cd, mode):
+    """All parameter gradients of <w, gw> against the reference's autograd (enc_small.npz).  mode "atomics" = the library's default
+    reductions (f32 atomics in run-dependent order), bounds wide enough for their spread; "det" = tests/conftest.py's fixture."""
+    from dge_amd import ops
+    assert ops.is_deterministic() == (mode == "det")
+    f32_bound = 1e-4 if mode == "det" else 2e-3
+    l2_bound, cos_bound = (0.145, 0.994) if mode == "det" else (0.15, 0.99)
     g = golden("enc_small.npz")
     E = small_encoder(cd)
     img = R.randn("enc.img", (2, 3, 32, 32), 9, 0.5).cuda()
@@ -81,17 +87,17 @@ def test_encoder_backward_vs_reference_golden(cd):
             if cd == "f32":
                 e = ((a - b).abs().max() / b.abs().max()).item()
                 worst_f32 = max(worst_f32, e)
-                if not e < 1e-4:          # (measured 4.9e-6: kink-free fixture, deterministic run)
+                if not e < f32_bound:          # (measured 4.9e-6: kink-free fixture, deterministic run)
                     bad[k] = e
             else:
                 l2 = ((a - b).norm() / b.norm()).item()
                 cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
                 worst[0], worst[1] = max(worst[0], l2), min(worst[1], cos)
-                if not (l2 < 0.145 and cos > 0.994):      # (deterministic run: worst tensor L2 0.096, cosine 0.9962; bounds 1.5x)
+                if not (l2 < l2_bound and cos > cos_bound):      # (deterministic run: worst tensor L2 0.096, cosine 0.9962; bounds 1.5x)
                     bad[k] = (l2, cos)
         else:
             assert p.grad is None, f"{k} must not receive a gradient (reference leaves it None)"
-    meas("enc_bwd", cd=cd, worst_l2=worst[0], worst_cos=worst[1], worst_f32_maxrel=worst_f32)
+    meas("enc_bwd", cd=cd, mode=mode, worst_l2=worst[0], worst_cos=worst[1], worst_f32_maxrel=worst_f32)
     assert not bad, bad
     # retain_graph semantics: a second backward over the same saved activations works (E_align_s2.py:204-220)
     E.zero_grad()

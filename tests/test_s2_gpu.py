@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import golden
+from tests.conftest import golden, MODES
 from tests.golden import recipe as R
 from tests.helpers import s2_shapes, modconv_shapes
 from oracle import ref_torch as O
@@ -128,8 +128,9 @@ def test_conv_vs_oracle_random_shapes(cd):
         assert relerr(stats, s_ref) < (1e-4 if cd == "f32" else 4e-3)      # bf16 measured 0.8e-3 .. 1.8e-3
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cd", ["f32", "bf16"])
-def test_synthesis_grad_wp_vs_reference_golden(cd):
+def test_synthesis_grad_wp_vs_reference_golden(cd, mode):
     """d<image, gimg>/d wp (what phase E of the train step back-propagates into the encoder)."""
     import dge_amd
     g = golden("s2_small.npz")
