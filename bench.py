@@ -283,6 +283,14 @@ def main():
             ds, ss = timed_steps(lambda i: synth(), 0, n, sync)
             out["synthesis_ms_per_img"] = ds / n / a.batch * 1e3
             out["synthesis_ms_per_img_median"] = ss["median"] / a.batch
+            if a.mtype == 2 and a.img_size == 1024:
+                # the north-star's own fraction: StyleGAN2-1024 synthesis(wp) forward, 150.76 algorithmic GFLOP per image
+                # (17 modulated convs 150.23 + toRGB / skip FIR 0.53), against the dense bf16 MFMA peak
+                syn_tf = 150.76 / (out["synthesis_ms_per_img"] * 1e-3) / 1e3
+                speak = 2500.0 if a.dtype == "bf16" else 157.3
+                out["synthesis_roofline"] = {"gflop_per_img": 150.76, "achieved_tflops": syn_tf, "peak_tflops": speak, "frac": syn_tf / speak,
+                                             "target_frac": 0.5, "batch": a.batch,
+                                             "note": "north_star: >= 50 % of the bf16 MFMA roofline on the StyleGAN2 1024^2 synthesis forward (<= 0.12 ms/img)"}
 
     # ---- roofline of the dominant kernel family (conv_igemm), instrumented extra pass
     if not a.no_roofline:
@@ -315,14 +323,18 @@ def main():
         # passes over this same command, FETCH_SIZE x2 on gfx950) and committed under profiles/; only valid for the default workload
         traffic, tsrc = None, None
         # (this round's file only: a file of an earlier round describes other kernels - without it the field is null)
-        tname = "r05_conv_traffic.json"
+        tname = "r06_conv_traffic.json"
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath) and a.mtype == 2 and a.img_size == 1024 and a.batch == 8 and a.dtype == "bf16":
             with open(tpath) as f:
                 tj = json.load(f)
             traffic, tsrc = tj["traffic_bytes_per_launch"], "offline PMC (tools/pmc_traffic.sh, separate rocprofv3 --pmc passes over this command), profiles/" + tname
-        out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                           "traffic": traffic, "traffic_source": tsrc,
+        # "mixed": the family holds MFMA-bound launches (C >= 128: algorithmic flops / peak > algorithmic bytes / 8 TB/s) and HBM-bound
+        # ones (the 512^2 / 1024^2 layers); `achieved` / `peak` / `frac` price all of them against the MFMA peak, per_launch_mixed
+        # prices every launch against its own bound
+        out["roofline"] = {"bound": "mixed", "bound_split": {"mfma_bound_launches_per_step": (nlaunch - n_hbm) // 2, "hbm_bound_launches_per_step": n_hbm // 2},
+                           "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                           "traffic": traffic, "traffic_source": tsrc, "traffic_is_offline_constant": traffic is not None,
                            "kernel": "conv_igemm_kernel<*> + conv_pp_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + upconv_fir_kernel + upconv_stream_kernel (all conv launches of a step: dge_conv2d, dge_conv_pp, dge_upconv_fir)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "timing": "HIP events around every conv launch of two extra steps run on ONE stream (the timed steps above overlap the three loss windows and the weight re-pack on side streams)",

@@ -686,13 +686,20 @@ def train(tensor_writer=None, args=None):
                                     and not getattr(args, "deterministic", False))
     first = 0
     prefetch = not getattr(args, "no_prefetch", False)
+    # capture() runs its warm-up iterations for real (2, one more in the legacy stage-1 form): a run shorter than that stays eager
+    if use_graph and args.iterations <= 4:
+        use_graph = False
     if use_graph:
-        r = st.capture()
-        first = st._g_iter           # capture() ran iterations 0 .. first - 1 for real (its warm-up): the loop continues behind them,
-        # so that `--launch graph` and `--launch eager` make the same number of encoder updates on the same z / mask sequence
-        print("ep_0_iter_0 .. %d ran inside the graph capture (warm-up)" % (first - 1))
+        # iteration 0 runs eagerly: the reference logs its losses and dumps E_model_ep0_iter0.pth right after it
+        # (E_align_s2.py: iteration % 100 == 0, iteration % 5000 == 0) - the dump holds the encoder after ONE iteration, as its name says
+        r = st.step(0)
+        print("ep_0_iter_0", "loss_tsa", float(r["loss_tsa"]), "loss_w", float(r["loss_w"]))
         if getattr(args, "experiment_dir", None):
-            torch.save(E.state_dict(), "%s/E_model_ep0_iter0.pth" % args.experiment_dir)       # the reference's iteration-0 dump
+            torch.save(E.state_dict(), "%s/E_model_ep0_iter0.pth" % args.experiment_dir)
+        st.capture(start=1)
+        first = st._g_iter           # capture() ran iterations 1 .. first - 1 for real (its warm-up): the loop continues behind them,
+        # so that `--launch graph` and `--launch eager` make the same number of encoder updates on the same z / mask sequence
+        print("ep_0_iter_1 .. %d ran inside the graph capture (warm-up)" % (first - 1))
     for iteration in range(first, args.iterations):
         # (eager launches: the next iteration's generator pass goes out beside this iteration's second backward, EAlignStep.step)
         r = st.replay(iteration) if use_graph else st.step(iteration, prefetch_next=(prefetch and iteration + 1 < args.iterations))
