@@ -64,6 +64,7 @@ static void env_load() {
     g_env.wgrad_groups = env_int("DGE_WGRAD_GROUPS", 0);
     if (g_env.wgrad_groups < 0) g_env.wgrad_groups = 0;
     g_env.up_dbg = env_int("DGE_UP_DBG", 0);
+    { const char* v = getenv("DGE_UP_VARIANT"); g_env.up_variant = !v ? 0 : (v[0] == 's' ? 2 : 1); }
     g_env_loaded = true;
 }
 // (first use from several host threads - autograd's backward thread next to the caller's - loads the switches exactly once)

@@ -241,6 +241,7 @@ struct DgeEnv {
     int no_pw;                                           // DGE_NO_PW: 1x1 launches stay on conv_igemm
     int conv_dbg, conv_bn, conv_kc, conv_small, conv_nok4, conv_nok2;   // DGE_CONV_* (bn / kc 0 = default, small -1 = default)
     int torgb_thread, wgrad_th8, wgrad_groups, up_dbg;   // DGE_TORGB_THREAD, DGE_WGRAD_TH8, DGE_WGRAD_GROUPS (0 = default), DGE_UP_DBG
+    int up_variant;                                      // DGE_UP_VARIANT: 0 = by shape, 1 = "pp" (up_pp_kernel), 2 = "s4" (up_s4_kernel)
 };
 const DgeEnv& dge_env();
 // batch 1 (the embedding_img inversion loop): workgroups per sample of the flushing stream kernels.  256 = one workgroup per CU fed HBM at

@@ -73,16 +73,22 @@ constexpr int HPW = (HPIECES + 7) / 8;               // 5 halo requests per wave
 constexpr int WPIECES = 18, WPW = 3;                 // weight block of a chunk: 9 units x 2 pieces; 3 requests per wave (6 of 24 out of range)
 constexpr int WBLK = WPIECES * 1024;                 // 18,432 B per (sample, channel tile, chunk)
 constexpr int NSTORE = 16;                           // stores of one epilogue, per wave (4 rows x 2 columns x 2 channel runs)
-// LDS map: halo 0 (40 KiB) | weight slot 0 (24 KiB) | halo 1 (at 64 KiB: the buffer toggle is one XOR) | weight slots 1, 2
-// (a halo tile is requested as 40 pieces, the last four all out of range: they WRITE ZEROS, so they need LDS of their own; likewise the
-//  24 requested pieces of an 18-piece weight block)
-constexpr int H1_OFF = 65536, W0_OFF = 40960, W1_OFF = 106496, W2_OFF = 131072, UP_LDS = 163840;
-static_assert(HPW * 8 * 1024 <= W0_OFF && W0_OFF + 24576 <= H1_OFF && H1_OFF + HPW * 8 * 1024 <= W1_OFF && W1_OFF + 24576 <= W2_OFF && W2_OFF + 24576 <= UP_LDS, "LDS map");
+// LDS map (round 6): THREE halo buffers of 36 KiB | two weight slots of 18 KiB | 1 KiB that takes the zeros of the requests that do not exist
+// (a halo tile is requested as 8 waves x 5 = 40 pieces, a weight block as 8 x 3 = 24: the phantom ones carry an out-of-range offset, fetch
+//  nothing and WRITE ZEROS - into the dump piece).  The halo tile of chunk c + 2 is requested during chunk c: the wait for a halo tile
+// requested one chunk ahead was 800 - 2000 of a chunk's 3500 cycles (tools/perf_up_timing.py); weights come from L2 one chunk ahead.
+constexpr int HBUF = 36864, H0_OFF = 0, H1_OFF = HBUF, H2_OFF = 2 * HBUF, W0_OFF = 3 * HBUF, W1_OFF = W0_OFF + WBLK, DUMP_OFF = W1_OFF + WBLK, UP_LDS = 163840;
+static_assert(HPIECES * 1024 == HBUF && DUMP_OFF + 1024 <= UP_LDS, "LDS map");
 constexpr int EXCH_BYTES = 8 * 3 * 64 * 64;          // epilogue: 3 boundary t rows x 16 words per lane and wave = 96 KiB from offset 0
 static_assert(EXCH_BYTES <= UP_LDS, "exchange area");
 // slot-local unit order of a chunk's weight block: A = ee eo oe oo of tap (m, n) | B = ee eo of (m-1, n), ee of (m-1, n-1) | C = ee oe of (m, n-1)
 // -> dge_pack_upconv_weight's q (phase (0,0): q = 2a + b; (0,1): 4 + a; (1,0): 6 + b; (1,1): 8; a / b = row / column shift)
 __host__ __device__ constexpr int unit_q(int u) { return u == 0 ? 0 : u == 1 ? 4 : u == 2 ? 6 : u == 3 ? 8 : u == 4 ? 2 : u == 5 ? 5 : u == 6 ? 3 : u == 7 ? 1 : 7; }
+
+#ifdef DGE_UP_TIMING
+// tuning build (tools/build_variant_src.sh): shader-clock stamps of workgroup 0, waves 0 and 4, read back by dge_dbg_up_prof
+__device__ long long g_up_prof[2][1024];
+#endif
 
 template <bool DBG>
 __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
@@ -95,6 +101,17 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
     auto P = [&]() { kparg_t r = kp; asm volatile("" : "+s"(r)); return r; };
     const int nchunks = p_.nchunks;
     const int dbg = DBG ? p_.dbg : 0;
+#ifdef DGE_UP_TIMING
+    int pidx = 0;
+    auto stamp = [&](int tag) {
+        if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && pidx < 1022) {
+            g_up_prof[g][pidx++] = ((long long)tag << 48) | (long long)(__builtin_readcyclecounter() & 0xffffffffffffll);
+            g_up_prof[g][1023] = pidx;
+        }
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
 
     // tiles of this workgroup (XCD-aware: workgroup i lives on XCD i % 8 and walks a contiguous range of that XCD's tiles,
     // channel tiles innermost: the workgroups that share a halo tile run side by side on one L2)
@@ -123,6 +140,9 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
     }
     // DMA lane constants: this wave's halo pieces (P = wave + 8 k) and weight pieces (P = wave + 8 j; P >= 18: out of range = no traffic)
     const unsigned wm0 = rfl(lds0 + wave * 1024);
+    // LDS targets of this wave's last halo piece (32 + wave: exists for waves 0 - 3) and last weight piece (16 + wave: waves 0, 1), relative to
+    // the buffer / slot - or the dump piece
+    const bool h4_real = wave + 32 < HPIECES, w2_real = wave + 16 < WPIECES;
     unsigned wvoff[WPW];
 #pragma unroll
     for (int j = 0; j < WPW; j++) wvoff[j] = (wave + 8 * j) < WPIECES ? (unsigned)((wave + 8 * j) * 1024 + lane * 16) : 0x80000000u;
@@ -156,9 +176,19 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
             const bool ok = (hp < HPIX) & ((unsigned)gy < (unsigned)p->H) & ((unsigned)gx < (unsigned)p->W);
             hoff[k] = ok ? (unsigned)(((gy * p->W + gx) * p->Cin + qd * 8) * 2) : 0x80000000u;
         }
-        StaticFor<HPW>::run([&](auto kc_) { constexpr int k = decltype(kc_)::value; dma_buf(hoff[k], rs, 0u, rfl(wm0 + k * 8192)); });
-        StaticFor<WPW>::run([&](auto jc) { constexpr int j = decltype(jc)::value; dma_buf(wvoff[j], rw, 0u, rfl(wm0 + W0_OFF + j * 8192)); });
-        StaticFor<WPW>::run([&](auto jc) { constexpr int j = decltype(jc)::value; dma_buf(wvoff[j], rw, (unsigned)WBLK, rfl(wm0 + W1_OFF + j * 8192)); });   // (nchunks >= 4)
+        // halo tiles of chunks 0 and 1 -> buffers 0 and 1, weights of chunk 0 -> slot 0
+        StaticFor<HPW>::run([&](auto kc_) {
+            constexpr int k = decltype(kc_)::value;
+            dma_buf(hoff[k], rs, 0u, (k < 4 || h4_real) ? rfl(wm0 + H0_OFF + k * 8192) : rfl(lds0 + DUMP_OFF));
+        });
+        StaticFor<HPW>::run([&](auto kc_) {
+            constexpr int k = decltype(kc_)::value;
+            dma_buf(hoff[k], rs, 64u, (k < 4 || h4_real) ? rfl(wm0 + H1_OFF + k * 8192) : rfl(lds0 + DUMP_OFF));
+        });
+        StaticFor<WPW>::run([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            dma_buf(wvoff[j], rw, 0u, (j < 2 || w2_real) ? rfl(wm0 + W0_OFF + j * 8192) : rfl(lds0 + DUMP_OFF));
+        });
     };
     start_tile(tile);
     bool first = true;
@@ -174,19 +204,22 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "i"(NSTORE) : "memory");      // the previous tile's stores may still be in flight
         first = false;
         if (g == 1) asm volatile("s_barrier" ::: "memory");                 // group 1 runs one phase behind group 0
+        stamp(1);
 
-        unsigned hx = 0;                          // XOR of the halo buffer being READ (0 / H1_OFF)
-        unsigned wcur = W0_OFF, wnx1 = W1_OFF, wnx2 = W2_OFF;      // slot read by this chunk, by the next one, filled for the one after
+        unsigned hcur = H0_OFF, hnx1 = H1_OFF, hnx2 = H2_OFF;      // halo buffer read by this chunk, by the next one, filled for the one after
+        unsigned wcur = W0_OFF, wnx1 = W1_OFF;                     // weight slot read by this chunk, filled for the next one
         for (int kc = 0; kc < nchunks; kc++) {
             const bool lastc = kc == nchunks - 1;
             // requests beyond the last chunk go through an EMPTY descriptor (every lane out of range: zeros into a buffer nobody reads,
             // no memory traffic) so that every chunk issues the same number of requests and the wait counts stay static
-            const unsigned hsoff = (unsigned)(kc + 1) * 64u, wsoff = (unsigned)(kc + 2) * (unsigned)WBLK;
+            const unsigned hsoff = (unsigned)(kc + 2) * 64u, wsoff = (unsigned)(kc + 1) * (unsigned)WBLK;
             rsrc_t rsn = rs, rwn = rw;
-            if (kc + 1 >= nchunks) { rsn[2] = 0u; }
-            if (kc + 2 >= nchunks) { rwn[2] = 0u; }
-            const unsigned hm0 = wm0 + (hx ^ (unsigned)H1_OFF);            // this wave's first piece of the halo buffer being FILLED
-            const unsigned wfill = wm0 + wnx2;
+            if (kc + 2 >= nchunks) { rsn[2] = 0u; }
+            if (kc + 1 >= nchunks) { rwn[2] = 0u; }
+            const unsigned hm0 = wm0 + hnx2;                               // this wave's first piece of the halo buffer being FILLED
+            const unsigned hm4 = h4_real ? hm0 + 4 * 8192 : lds0 + (unsigned)DUMP_OFF;
+            const unsigned wfill = wm0 + wnx1;
+            const unsigned wf2 = w2_real ? wfill + 2 * 8192 : lds0 + (unsigned)DUMP_OFF;
             const unsigned wrd = wl + wcur;
             // ------------------------------------------------ cluster A: tap (m, n) -> ee eo oe oo
             {
@@ -194,7 +227,7 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ks++) xa[i][ks] = *(const uint4*)(lds + (xat[i + 1][0] ^ hx) + ks * 512);
+                    for (int ks = 0; ks < 2; ks++) xa[i][ks] = *(const uint4*)(lds + xat[i + 1][0] + hcur + ks * 512);
 #pragma unroll
                 for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -206,12 +239,17 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                 StaticFor<16>::run([&](auto mc) {
                     constexpr int m = decltype(mc)::value, ks = m >> 3, i = (m >> 2) & 1, u = m & 3;
                     acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wa[u][ks], *(const bf16x8_t*)&xa[i][ks], acc[i][u], 0, 0, 0);
-                    if constexpr (m == 1 || m == 4 || m == 7 || m == 10 || m == 13) {
-                        constexpr int k = (m - 1) / 3;                       // halo piece k of chunk kc + 1
+                    if constexpr (m == 2 || m == 7 || m == 12) {
+                        constexpr int j = (m - 2) / 5;                       // weight piece j of chunk kc + 1
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!(DBG && (dbg & 4)))
-                            asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
-                                         :: "v"(hoff[k]), "s"(hm0), "s"(rsn), "s"(hsoff), "i"(k * 8192) : "memory", "scc");
+                        if (!(DBG && (dbg & 1))) {
+                            if constexpr (j < 2)
+                                asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                             :: "v"(wvoff[j]), "s"(wfill), "s"(rwn), "s"(wsoff), "i"(j * 8192) : "memory", "scc");
+                            else
+                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                             :: "v"(wvoff[j]), "s"(wf2), "s"(rwn), "s"(wsoff) : "memory");
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
@@ -228,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
 #pragma unroll
                     for (int bb = 0; bb < 2; bb++)
 #pragma unroll
-                        for (int ks = 0; ks < 2; ks++) xb[i][bb][ks] = *(const uint4*)(lds + (xat[i][bb] ^ hx) + ks * 512);
+                        for (int ks = 0; ks < 2; ks++) xb[i][bb][ks] = *(const uint4*)(lds + xat[i][bb] + hcur + ks * 512);
 #pragma unroll
                 for (int u = 0; u < 3; u++)
 #pragma unroll
@@ -241,12 +279,17 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                     constexpr int m = decltype(mc)::value, ks = m / 6, r6 = m % 6, i = r6 / 3, u = r6 % 3;      // u 0: ee <- (m-1, n); 1: eo <- (m-1, n); 2: ee <- (m-1, n-1)
                     constexpr int ph = u == 1 ? 1 : 0, bb = u == 2 ? 1 : 0;
                     acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wb[u][ks], *(const bf16x8_t*)&xb[i][bb][ks], acc[i][ph], 0, 0, 0);
-                    if constexpr (m == 2 || m == 5 || m == 8) {
-                        constexpr int j = (m - 2) / 3;                       // weight piece j of chunk kc + 2
+                    if constexpr (m == 1 || m == 3 || m == 5 || m == 7 || m == 9) {
+                        constexpr int k = (m - 1) / 2;                       // halo piece k of chunk kc + 2
                         __builtin_amdgcn_sched_barrier(0);
-                        if (!(DBG && (dbg & 1)))
-                            asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
-                                         :: "v"(wvoff[j]), "s"(wfill), "s"(rwn), "s"(wsoff), "i"(j * 8192) : "memory", "scc");
+                        if (!(DBG && (dbg & 4))) {
+                            if constexpr (k < 4)
+                                asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                             :: "v"(hoff[k]), "s"(hm0), "s"(rsn), "s"(hsoff), "i"(k * 8192) : "memory", "scc");
+                            else
+                                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                             :: "v"(hoff[k]), "s"(hm4), "s"(rsn), "s"(hsoff) : "memory");
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
@@ -261,16 +304,27 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
-                    for (int ks = 0; ks < 2; ks++) xc[i][ks] = *(const uint4*)(lds + (xat[i + 1][1] ^ hx) + ks * 512);
+                    for (int ks = 0; ks < 2; ks++) xc[i][ks] = *(const uint4*)(lds + xat[i + 1][1] + hcur + ks * 512);
 #pragma unroll
                 for (int u = 0; u < 2; u++)
 #pragma unroll
                     for (int ks = 0; ks < 2; ks++) wc[u][ks] = *(const uint4*)(lds + wrd + (7 + u) * 2048 + ks * 512);
                 __builtin_amdgcn_sched_barrier(0);
-                // the halo tile of the NEXT chunk (requested during this chunk's cluster A) has landed - this wave's pieces; the barriers
-                // make it true for everybody's before anyone reads it.  Still in flight: the three weight pieces of chunk kc + 2.
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(WPW) : "memory");
+                // the halo tile (requested a chunk ago) and the weights (requested during this chunk's cluster A) of the NEXT chunk have
+                // landed - this wave's pieces; the barriers make it true for everybody's before anyone reads them.  Still in flight: the
+                // five halo pieces of chunk kc + 2.
+#ifdef DGE_UP_TIMING
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stamp(10);
+#endif
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(HPW) : "memory");
+#ifdef DGE_UP_TIMING
+                stamp(11);
+#endif
                 if (!(lastc && g == 1)) asm volatile("s_barrier" ::: "memory");
+#ifdef DGE_UP_TIMING
+                stamp(12);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
                 StaticFor<8>::run([&](auto mc) {
@@ -282,12 +336,14 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                 if (!lastc) asm volatile("s_barrier" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-            hx ^= (unsigned)H1_OFF;
-            { const unsigned t = wcur; wcur = wnx1; wnx1 = wnx2; wnx2 = t; }
+            { const unsigned t = hcur; hcur = hnx1; hnx1 = hnx2; hnx2 = t; }
+            { const unsigned t = wcur; wcur = wnx1; wnx1 = t; }
         }
 
         // ---------------------------------------------------------------- epilogue (both groups in step again)
+        stamp(2);
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");        // every request has landed (the dummies of the last chunks write zeros), every fragment read is done
+        stamp(3);
         const auto p = P();
         const int OH = 2 * p->H, OW = 2 * p->W, Cout = p->Cout;
         const int R = 2 * (y0 + 2 * wave);                                  // t row of (input row 0 of the wave, py 0); y rows R .. R + 3
@@ -366,7 +422,9 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                     *(uint4*)(ex + sl * 4096 + q4 * 16) = make_uint4(tw[rows[sl]][4 * q4], tw[rows[sl]][4 * q4 + 1], tw[rows[sl]][4 * q4 + 2], tw[rows[sl]][4 * q4 + 3]);
             }
         }
+        stamp(4);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stamp(5);
         {
             // (wave 0 / wave 7: the rows that would need the missing neighbour lie outside the tile's output range; any data will do)
             const unsigned char* exu = lds + (size_t)(wave > 0 ? wave - 1 : 0) * (3 * 4096) + lane * 64 + 2 * 4096;
@@ -380,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the exchange area is dead (and noise / bias are in registers)
+        stamp(6);
         // what the stores need of THIS tile, then the next tile's set-up and prologue requests
         const int ylo = 2 * y0 + 2, yhi = min(2 * y0 + 29, OH - 1);         // the tile's output rows [28 ty, 28 ty + 27], inside the image
         const bool colv = l31 >= 1 && l31 <= 30 && Xe >= 0 && Xe + 1 < OW && !(DBG && (dbg & 8));
@@ -394,6 +453,7 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
         }
         const unsigned cb2 = (unsigned)Cout * 2u;
         if (has_next) start_tile(next);
+        stamp(7);
         const unsigned K0 = 0x3e80u, K1 = 0x3f40u;            // bf16 0.25, 0.75
         const unsigned cL = K0 << 16, cC_e = K1 | (K1 << 16), cR_e = K0, cC_o = K0 | (K1 << 16), cR_o = K1 | (K0 << 16);
 #pragma unroll
@@ -459,11 +519,350 @@ __global__ __launch_bounds__(512, 2) void up_pp_kernel(UPParams p_) {
                     // dropped): the wait count at the top of the next tile relies on it
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, yvoff[k] + (unsigned)c * cb2, h * 32, 0);
                 }
+            stamp(8 + h);
         }
         if (!has_next) break;
         tile = next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// up_s4 (round 6): the same GEMM and the same register FIR for the layers whose FIR arithmetic is as long as their K loop
+// (Cin <= 256: layers 11 / 13 of the 1024^2 generator), as FOUR-wave workgroups with HALF the LDS, two of them resident per CU.
+//
+// Why (tools/perf_up_timing.py on up_pp_kernel, layer 13, batch 8, cycles per tile and group): K loop 14 k - at 54 KiB of LDS-DMA per
+// chunk it runs at the rate the memory side delivers (~11 B / cycle / CU with every CU streaming; 36 MFMAs per chunk and wave would
+// need 2.3 k) - and epilogue 27 k, of which 14 k are the FIR's VALU instructions (the two groups of a workgroup take turns on the
+// SIMD's VALU: 4.2 k / 7.2 k per 8-channel run) and the rest waits: noise / bias loads behind the LDS exchange, the next tile's
+// prologue burst, the slower group.  A variant whose request stream runs on across tile seams (tools/probes/
+// up_pp_seam_stream_experiment.hip.txt) removes those waits and takes the same time: the K loop then carries the traffic the seam
+// carried.  What one persistent workgroup per CU cannot do is run one tile's FIR (VALU) beside another tile's K loop (DMA + matrix
+// pipe).  Two independent workgroups per CU do that by themselves:
+//   * 4 waves, wave w = input rows 2 w, 2 w + 1 of an 8 x 32 tile x 32 output channels x 4 phases (the wave tile and the three
+//     clusters of up_pp_kernel); no ping-pong partner inside the workgroup - the co-resident workgroup's wave on the same SIMD is
+//     the partner, with no barrier between them;
+//   * LDS 80 KiB: two halo buffers (9 x 33 pixels x 64 B = 19 pieces, requested as 20) and two weight slots (18 pieces, requested as
+//     20); chunk c + 1 is requested during chunk c (one s_barrier per chunk);
+//   * one tile per workgroup: prologue latency and epilogue of a tile overlap the other workgroup's K loop; the tile's own LDS is
+//     free for the boundary-row exchange (12 KiB per wave) when its K loop is done.
+// Cost: tiles advance by 6 input rows of 8 (0.75 instead of 0.875 of the rows are useful) and every tile fetches its weight blocks for
+// half as many rows.  Same weight image as up_pp (dge_pack_up_pp).
+constexpr int Q_TR = 8, Q_HR = Q_TR + 1, Q_HPIX = Q_HR * HC;             // halo tile 9 x 33 = 297 pixels
+constexpr int Q_HPIECES = (Q_HPIX + 15) / 16;                      // 19
+constexpr int Q_HPW = 5, Q_WPW = 5;                                // requests per wave and chunk (4 waves x 5 = 20 >= 19 / 18 pieces)
+constexpr int Q_HBUF = 20480, Q_WSLOT = 20480;
+constexpr int Q_H0_OFF = 0, Q_H1_OFF = Q_HBUF, Q_W0_OFF = 2 * Q_HBUF, Q_W1_OFF = 2 * Q_HBUF + Q_WSLOT, Q_LDS = 2 * Q_HBUF + 2 * Q_WSLOT;     // 80 KiB
+static_assert(Q_HPIECES <= 4 * Q_HPW && WPIECES <= 4 * Q_WPW && Q_LDS == 81920, "LDS map");
+constexpr int Q_NSTORE = 16;
+
+__global__ __launch_bounds__(256, 2) void up_s4_kernel(UPParams p_) {
+        __shared__ __attribute__((aligned(1024))) unsigned char lds[Q_LDS];
+    const unsigned lds0 = lds_off(lds);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = rfl(tid >> 6);
+    const int nchunks = p_.nchunks;
+
+    // XCD-aware: workgroup i lives on XCD i % 8 and takes tile (i >> 3) of that XCD's contiguous range (channel tiles innermost:
+    // the workgroups that share a halo tile are neighbours on one L2)
+    const int ntiles = p_.tiles_x * p_.tiles_y * p_.B * p_.ntn;
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    int id = xcd * per_xcd + (blockIdx.x >> 3);
+    if (id >= min((xcd + 1) * per_xcd, ntiles)) return;
+    const int nt = id % p_.ntn; id /= p_.ntn;
+    const int x0 = (id % p_.tiles_x) * 30 - 1; id /= p_.tiles_x;         // first input column / row of the tile (-1: the zero border)
+    const int y0 = (id % p_.tiles_y) * 6 - 1, b = id / p_.tiles_y;
+    // stagger (experiment, p_.dbg = mode | sleeps << 4): the two workgroups of a CU start together and, with identical tiles, stay in
+    // step - K loops side by side, then FIRs side by side.  Delay one of the first generation's two by about half a tile.
+    if (p_.dbg) {
+        const int mode = p_.dbg & 15, n = p_.dbg >> 4, slot = blockIdx.x >> 3;
+        const bool late = mode == 1 ? (slot >= 32 && slot < 64) : mode == 2 ? (slot < 64 && (slot & 1)) : mode == 3 ? (blockIdx.x < 512 && (blockIdx.x & 1)) : false;
+        if (late) for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127);
+    }
+
+    // fragment addresses: halo pixel (hr, hc) -> hp = hr * 33 + hc, byte (hp >> 4) KiB + (hp & 15) * 16 + part * 256
+    unsigned xat[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int bb = 0; bb < 2; bb++) {
+            const int hp = (2 * wave + r) * HC + l31 + 1 - bb;
+            xat[r][bb] = (unsigned)((hp >> 4) * 1024 + (hp & 15) * 16 + kh * 256);
+        }
+    unsigned wl;
+    {
+        const int n = tr_chan_of_row(l31);
+        wl = (unsigned)((n >> 4) * 1024 + (n & 15) * 16 + kh * 256);
+    }
+    const unsigned wm0 = rfl(lds0 + wave * 1024);
+    unsigned wvoff[Q_WPW], hoff[Q_HPW];
+#pragma unroll
+    for (int j = 0; j < Q_WPW; j++) wvoff[j] = (wave + 4 * j) < WPIECES ? (unsigned)((wave + 4 * j) * 1024 + lane * 16) : 0x80000000u;
+    const unsigned xbytes = (unsigned)(p_.H * p_.W) * (unsigned)p_.Cin * 2u;
+    const rsrc_t rs = make_rsrc((unsigned long long)p_.x + (unsigned long long)b * xbytes, xbytes);
+    const rsrc_t rw = make_rsrc((unsigned long long)p_.w + (unsigned long long)b * (unsigned long long)p_.w_bstride +
+                                (unsigned long long)nt * nchunks * (unsigned long long)WBLK, (unsigned)nchunks * (unsigned)WBLK);
+#pragma unroll
+    for (int k = 0; k < Q_HPW; k++) {
+        const int hp = (wave + 4 * k) * 16 + (lane & 15), qd = lane >> 4;
+        const int hr = hp / HC, hc = hp - hr * HC;
+        const int gy = y0 - 1 + hr, gx = x0 - 1 + hc;
+        const bool ok = (hp < Q_HPIX) & ((unsigned)gy < (unsigned)p_.H) & ((unsigned)gx < (unsigned)p_.W);
+        hoff[k] = ok ? (unsigned)(((gy * p_.W + gx) * p_.Cin + qd * 8) * 2) : 0x80000000u;
+    }
+    // prologue: chunk 0 -> halo buffer 0, weight slot 0
+    StaticFor<Q_HPW>::run([&](auto kc_) { constexpr int k = decltype(kc_)::value; dma_buf(hoff[k], rs, 0u, rfl(wm0 + Q_H0_OFF + k * 4096)); });
+    StaticFor<Q_WPW>::run([&](auto jc) { constexpr int j = decltype(jc)::value; dma_buf(wvoff[j], rw, 0u, rfl(wm0 + Q_W0_OFF + j * 4096)); });
+
+    // everything the tail reads from memory is requested here, behind the prologue: noise of this lane's 4 rows x 2 columns, bias of its
+    // 16 channels (24 registers held through the K loop; loaded in the epilogue they cost a round trip per tile that nothing covered)
+    const int OH = 2 * p_.H, OW = 2 * p_.W, Cout = p_.Cout;
+    const int R = 2 * (y0 + 2 * wave);                                  // t row of (input row 0 of the wave, py 0); y rows R .. R + 3
+    const int Xe = 2 * (x0 + l31);                                      // this lane's even output column
+    f2_t nz[4];
+    const float nwv = p_.noise ? p_.noise_w[0] * p_.gain : 0.f;
+    {
+        const float* nzb = p_.noise ? p_.noise + (size_t)b * p_.noise_bstride : nullptr;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int oy = R + k;
+            nz[k] = f2_t{0.f, 0.f};
+            if (nzb && (unsigned)oy < (unsigned)OH && Xe >= 0 && Xe + 1 < OW) nz[k] = *(const f2_t*)(nzb + (size_t)oy * OW + Xe);
+        }
+    }
+    const float bg = p_.bias_scale * p_.gain;
+    f2_t bia[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (p_.bias) { b0 = *(const float4*)(p_.bias + nt * 32 + 16 * h + 8 * kh); b1 = *(const float4*)(p_.bias + nt * 32 + 16 * h + 8 * kh + 4); }
+        bia[h][0] = f2_t{b0.x * bg, b0.y * bg}; bia[h][1] = f2_t{b0.z * bg, b0.w * bg};
+        bia[h][2] = f2_t{b1.x * bg, b1.y * bg}; bia[h][3] = f2_t{b1.z * bg, b1.w * bg};
+    }
+    asm volatile("" :: "v"(nz[0]), "v"(nz[1]), "v"(nz[2]), "v"(nz[3]));
+
+    f32x16_t acc[2][4];                         // [input row of the wave][phase 2 py + px]
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int ph = 0; ph < 4; ph++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][ph][r] = 0.f;
+
+    unsigned hb = Q_H0_OFF, wb_ = Q_W0_OFF;          // buffers READ by this chunk
+    for (int kc = 0; kc < nchunks; kc++) {
+        // chunk kc has landed (this wave's pieces; the barrier makes it everybody's) and everybody is done reading chunk kc - 1
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        // requests of chunk kc + 1 go into the buffers chunk kc - 1 read; behind the last chunk through an EMPTY descriptor
+        rsrc_t rsn = rs, rwn = rw;
+        if (kc + 1 >= nchunks) { rsn[2] = 0u; rwn[2] = 0u; }
+        const unsigned hsoff = (unsigned)(kc + 1) * 64u, wsoff = (unsigned)(kc + 1) * (unsigned)WBLK;
+        const unsigned hfill = wm0 + (hb ^ (unsigned)(Q_H0_OFF ^ Q_H1_OFF)), wfill = wm0 + (wb_ == (unsigned)Q_W0_OFF ? (unsigned)Q_W1_OFF : (unsigned)Q_W0_OFF);
+        const unsigned wrd = wl + wb_;
+        // ------------------------------------------------ cluster A: tap (m, n) -> ee eo oe oo
+        {
+            uint4 xa[2][2], wa[4][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) xa[i][ks] = *(const uint4*)(lds + xat[i + 1][0] + hb + ks * 512);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) wa[u][ks] = *(const uint4*)(lds + wrd + u * 2048 + ks * 512);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            StaticFor<16>::run([&](auto mc) {
+                constexpr int m = decltype(mc)::value, ks = m >> 3, i = (m >> 2) & 1, u = m & 3;
+                acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wa[u][ks], *(const bf16x8_t*)&xa[i][ks], acc[i][u], 0, 0, 0);
+                if constexpr (m == 1 || m == 4 || m == 7 || m == 10 || m == 13) {
+                    constexpr int k = (m - 1) / 3;                       // halo piece k of chunk kc + 1
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                 :: "v"(hoff[k]), "s"(hfill), "s"(rsn), "s"(hsoff), "i"(k * 4096) : "memory", "scc");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ------------------------------------------------ cluster B: taps (m-1, n) -> ee eo, (m-1, n-1) -> ee
+        {
+            uint4 xb[2][2][2], wbf[3][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int bb = 0; bb < 2; bb++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) xb[i][bb][ks] = *(const uint4*)(lds + xat[i][bb] + hb + ks * 512);
+#pragma unroll
+            for (int u = 0; u < 3; u++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) wbf[u][ks] = *(const uint4*)(lds + wrd + (4 + u) * 2048 + ks * 512);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            StaticFor<12>::run([&](auto mc) {
+                constexpr int m = decltype(mc)::value, ks = m / 6, r6 = m % 6, i = r6 / 3, u = r6 % 3;      // u 0: ee <- (m-1, n); 1: eo <- (m-1, n); 2: ee <- (m-1, n-1)
+                constexpr int ph = u == 1 ? 1 : 0, bb = u == 2 ? 1 : 0;
+                acc[i][ph] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wbf[u][ks], *(const bf16x8_t*)&xb[i][bb][ks], acc[i][ph], 0, 0, 0);
+                if constexpr (m == 1 || m == 3 || m == 5 || m == 7 || m == 9) {
+                    constexpr int j = (m - 1) / 2;                       // weight piece j of chunk kc + 1
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_add_u32 m0, %1, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds"
+                                 :: "v"(wvoff[j]), "s"(wfill), "s"(rwn), "s"(wsoff), "i"(j * 4096) : "memory", "scc");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ------------------------------------------------ cluster C: tap (m, n-1) -> ee oe
+        {
+            uint4 xc[2][2], wc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) xc[i][ks] = *(const uint4*)(lds + xat[i + 1][1] + hb + ks * 512);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) wc[u][ks] = *(const uint4*)(lds + wrd + (7 + u) * 2048 + ks * 512);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            StaticFor<8>::run([&](auto mc) {
+                constexpr int m = decltype(mc)::value, ks = m >> 2, i = (m >> 1) & 1, u = m & 1;            // u 0: ee, 1: oe
+                acc[i][2 * u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&wc[u][ks], *(const bf16x8_t*)&xc[i][ks], acc[i][2 * u], 0, 0, 0);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        hb ^= (unsigned)(Q_H0_OFF ^ Q_H1_OFF);
+        wb_ = wb_ == (unsigned)Q_W0_OFF ? (unsigned)Q_W1_OFF : (unsigned)Q_W0_OFF;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    const int abl = p_.dbg >> 8;                 // timing aids (DGE_UP_DBG bits 8 ..): 1 no stores, 2 no FIR arithmetic, 4 no epilogue at all
+    if (abl & 4) {
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int ph = 0; ph < 4; ph++) asm volatile("" :: "v"(acc[i][ph][0]), "v"(acc[i][ph][15]));
+        return;
+    }
+    // t words of the wave's four t rows: (t[.][2n], t[.][2n+1]) of 16 channels, rounded to bf16 (where upconv_fir / upconv_stream round it)
+    unsigned tw[7][16];                         // row r <-> t row R - 1 + r: [0] the wave above's last row | [1..4] own | [5], [6] the wave below's first two
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) tw[1 + 2 * i + py][e] = pack2bf(acc[i][2 * py][e], acc[i][2 * py + 1][e]);
+    // every fragment read of the K loop is done (and the dummy requests of the last chunk have written their zeros): the LDS is free
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the three boundary rows go through LDS (own rows 0, 1 for the wave above, 3 for the wave below): [wave][slot][q4][lane][4 words] = 12 KiB per wave
+    {
+        unsigned char* ex = lds + (size_t)wave * (3 * 4096) + lane * 16;
+#pragma unroll
+        for (int sl = 0; sl < 3; sl++) {
+            constexpr int rows[3] = {1, 2, 4};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                *(uint4*)(ex + sl * 4096 + q4 * 1024) = make_uint4(tw[rows[sl]][4 * q4], tw[rows[sl]][4 * q4 + 1], tw[rows[sl]][4 * q4 + 2], tw[rows[sl]][4 * q4 + 3]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+        // (wave 0 / wave 3: the rows that would need the missing neighbour lie outside the tile's output range; any data will do)
+        const unsigned char* exu = lds + (size_t)(wave > 0 ? wave - 1 : 0) * (3 * 4096) + lane * 16 + 2 * 4096;
+        const unsigned char* exd = lds + (size_t)(wave < 3 ? wave + 1 : 3) * (3 * 4096) + lane * 16;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            const uint4 a = *(const uint4*)(exu + q4 * 1024), c0 = *(const uint4*)(exd + q4 * 1024), c1 = *(const uint4*)(exd + 4096 + q4 * 1024);
+            tw[0][4 * q4] = a.x; tw[0][4 * q4 + 1] = a.y; tw[0][4 * q4 + 2] = a.z; tw[0][4 * q4 + 3] = a.w;
+            tw[5][4 * q4] = c0.x; tw[5][4 * q4 + 1] = c0.y; tw[5][4 * q4 + 2] = c0.z; tw[5][4 * q4 + 3] = c0.w;
+            tw[6][4 * q4] = c1.x; tw[6][4 * q4 + 1] = c1.y; tw[6][4 * q4 + 2] = c1.z; tw[6][4 * q4 + 3] = c1.w;
+        }
+    }
+    const int ylo = 2 * y0 + 2, yhi = min(2 * y0 + 13, OH - 1);         // the tile's output rows [12 ty, 12 ty + 11], inside the image
+    const bool colv = l31 >= 1 && l31 <= 30 && Xe >= 0 && Xe + 1 < OW && !(abl & 1);
+    const float slope = p_.act == DGE_ACT_LRELU ? 0.2f : (p_.act == DGE_ACT_RELU ? 0.f : 1.f);
+    const unsigned ybytes = (unsigned)(OH * OW) * (unsigned)Cout * 2u;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(p_.y + (size_t)b * OH * OW * Cout, 0, ybytes, 0x00020000);
+    unsigned yvoff[4];                          // byte offset of (row R + k, column Xe, channel run 0); out of range = the store is dropped
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int oy = R + k;
+        yvoff[k] = (colv && oy >= ylo && oy <= yhi && oy >= 0) ? (unsigned)((oy * OW + Xe) * Cout + nt * 32 + 8 * kh) * 2u : 0x80000000u;
+    }
+    const unsigned cb2 = (unsigned)Cout * 2u;
+    const unsigned K0 = 0x3e80u, K1 = 0x3f40u;            // bf16 0.25, 0.75
+    const unsigned cL = K0 << 16, cC_e = K1 | (K1 << 16), cR_e = K0, cC_o = K0 | (K1 << 16), cR_o = K1 | (K0 << 16);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {                  // the lane's two runs of 8 channels
+        f2_t ya[4][2][4];                           // y rows R .. R + 3, columns Xe, Xe + 1, channel pairs: start from noise * strength + bias
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float nzv = (c == 0 ? nz[k][0] : nz[k][1]) * nwv;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++) ya[k][c][e2] = bia[h][e2] + f2_t{nzv, nzv};
+            }
+        StaticFor<7>::run([&](auto rc) {
+            constexpr int r = decltype(rc)::value;          // t row R - 1 + r
+            f2_t he[4], ho[4];
+            if (abl & 2) {
+                if (r >= 1 && r <= 4) {
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; e2++) {
+                        ya[r - 1][0][e2] = f2_t{__uint_as_float(tw[r][8 * h + 2 * e2] << 16), __uint_as_float(tw[r][8 * h + 2 * e2 + 1] << 16)};
+                        ya[r - 1][1][e2] = f2_t{__uint_as_float(tw[r][8 * h + 2 * e2] & 0xffff0000u), __uint_as_float(tw[r][8 * h + 2 * e2 + 1] & 0xffff0000u)};
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const unsigned wc = tw[r][8 * h + e];
+                // he = .25 t[2n-1] + .75 t[2n] + .75 t[2n+1] + .25 t[2n+2], ho = .25 t[2n] + .75 t[2n+1] + .75 t[2n+2] + .25 t[2n+3] on the
+                // bf16 pairs (t[2n], t[2n+1]) of lanes n - 1, n, n + 1 (builtins only: see up_pp_kernel)
+                const unsigned wlft = __builtin_amdgcn_mov_dpp(wc, 0x138, 0xf, 0xf, true);   // lane n - 1: (t[2n - 2], t[2n - 1])
+                const unsigned wrgt = __builtin_amdgcn_mov_dpp(wc, 0x130, 0xf, 0xf, true);   // lane n + 1: (t[2n + 2], t[2n + 3])
+                float a0, a1;
+                asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a0) : "v"(wlft), "v"(cL));
+                a0 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wc, *(const bf2_t*)&cC_e, a0, false);
+                a0 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_e, a0, false);
+                asm("v_dot2_f32_bf16 %0, %1, %2, 0" : "=v"(a1) : "v"(wc), "v"(cC_o));
+                a1 = __builtin_amdgcn_fdot2_f32_bf16(*(const bf2_t*)&wrgt, *(const bf2_t*)&cR_o, a1, false);
+                he[e >> 1][e & 1] = a0; ho[e >> 1][e & 1] = a1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                constexpr float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+                if (r - k >= 0 && r - k <= 3) {
+                    const f2_t f = f2_t{F[r - k], F[r - k]};
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; e2++) {
+                        ya[k][0][e2] = __builtin_elementwise_fma(f, he[e2], ya[k][0][e2]);
+                        ya[k][1][e2] = __builtin_elementwise_fma(f, ho[e2], ya[k][1][e2]);
+                    }
+                }
+            }
+        });
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                u32x4_t o;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; e2++) {
+                    const f2_t u = ya[k][c][e2], lo = u * slope;
+                    o[e2] = pack2bf(fmaxf(u[0], lo[0]), fmaxf(u[1], lo[1]));
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_y, yvoff[k] + (unsigned)c * cb2, h * 32, 0);
+            }
+    }
 }
 
 // per-sample weight image: [sample][channel tile 32][chunk 32][18 pieces][part 4][row 16][8] bf16, slot-local unit order (unit_q),
@@ -492,6 +891,12 @@ __global__ __launch_bounds__(256) void up_pp_pack_kernel(const bf16_t* __restric
 }
 
 }  // namespace
+
+#ifdef DGE_UP_TIMING
+extern "C" int dge_dbg_up_prof(long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_up_prof), sizeof(long long) * 2048, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int dge_up_pp_supported(int B, int H, int W, int Cin, int Cout, int dtype) {
     if (dtype != DGE_BF16 || B < 1) return 0;
@@ -527,6 +932,28 @@ extern "C" int dge_up_pp(const void* x, const void* w_img, long long w_bstride, 
     p.tiles_x = (W + 29) / 30; p.tiles_y = (H + 13) / 14;                   // 60 x 28 finished outputs per tile; tile (tx, ty) reads input positions 30 tx - 1 .. + 31, 14 ty - 1 .. + 15
     p.ntn = Cout / 32; p.nchunks = Cin / 32;
     p.dbg = dge_env().up_dbg;
+    // default: the four-wave form, two workgroups per CU, one tile each (in the step it beats the persistent eight-wave kernel on all
+    // four layers - 21.70 against 21.84 ms, same box - although isolated the latter is faster at Cin = 512: a workgroup that does not own
+    // the whole CU shares it with the launches of the other streams).  DGE_UP_VARIANT=pp / s4 forces one form: A/B runs.
+    const int variant = dge_env().up_variant;
+    if (variant != 1) {
+        p.tiles_y = (H + 5) / 6;                                             // 60 x 12 finished outputs per tile; rows 6 ty - 1 .. + 7
+        const long tiles4 = (long)p.tiles_x * p.tiles_y * B * p.ntn;
+        const long per_xcd = (tiles4 + 7) / 8;
+        dge_note_kernel("up_s4<bf16,8,32,32>");
+        if (p.dbg) {
+            static bool once = false;
+            if (!once) {
+                once = true;
+                int nb = -1;
+                hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, up_s4_kernel, 256, 0);
+                fprintf(stderr, "up_s4: occupancy query -> %d blocks per CU (err %d)\n", nb, (int)e);
+            }
+        }
+        hipLaunchKernelGGL(up_s4_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s, p);
+        DGE_LAUNCH_CHECK("up_s4");
+        return 0;
+    }
     const long tiles = (long)p.tiles_x * p.tiles_y * B * p.ntn;
     int cus = 256;
     {

@@ -527,6 +527,8 @@ def up_pp(x, w_img, cout, bias=None, bias_scale=1.0, noise=None, noise_w=None, a
         PROFILE.append((e0, e1, 2.0 * 9.0 * Cin * cout * H * W * B, (B, H, W, Cin, cout, 3, "upfir", False), abytes))
     else:
         launch()
+    if KERNEL_LOG is not None:
+        KERNEL_LOG.append((last_kernel(), _stream()))
     return y
 
 

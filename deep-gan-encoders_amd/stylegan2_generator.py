@@ -39,7 +39,7 @@ def _dt(compute_dtype):
 import os as _os
 _PP_GEN = not _os.environ.get("DGE_NO_PP_GEN")
 _DENSE_CHAIN = _os.environ.get("DGE_DENSE_CHAIN") == "1"
-_UP_PP = _os.environ.get("DGE_UP_PP") == "1"      # opt-in (round 5: equal to upconv_fir at batch 8)
+_UP_PP = _os.environ.get("DGE_UP_PP", "1") != "0"      # round 6: the default for the Cin >= 128 up layers (dge_up_pp: up_s4 / up_pp kernels; DGE_UP_PP=0: upconv_fir)
 
 
 class DenseBlock(nn.Module):

@@ -195,6 +195,7 @@ def test_generator_up_layer_fullsize(cin, cout, Rin, B, kernel):
 
 
 UP_PP_LAYERS = [
+    (512, 512, 16, 16, 8),        # layer5 (-> 32^2: the smallest layer the generator sends here)
     (512, 512, 32, 32, 8),        # layer7
     (512, 256, 64, 64, 8),        # layer9
     (256, 128, 128, 128, 8),      # layer11
@@ -204,8 +205,25 @@ UP_PP_LAYERS = [
 ]
 
 
+@pytest.fixture
+def up_variant(request):
+    """DGE_UP_VARIANT for one test (dge_up_pp picks the kernel by shape otherwise): "pp" = up_pp_kernel, "s4" = up_s4_kernel"""
+    import os
+    from dge_amd import ops
+    old = os.environ.get("DGE_UP_VARIANT")
+    os.environ["DGE_UP_VARIANT"] = request.param
+    ops.lib().dge_env_reload()
+    yield request.param
+    if old is None:
+        os.environ.pop("DGE_UP_VARIANT", None)
+    else:
+        os.environ["DGE_UP_VARIANT"] = old
+    ops.lib().dge_env_reload()
+
+
+@pytest.mark.parametrize("up_variant", ["pp", "s4"], indirect=True)
 @pytest.mark.parametrize("cin,cout,Hin,Win,B", UP_PP_LAYERS)
-def test_up_layer_ping_pong_kernel(cin, cout, Hin, Win, B):
+def test_up_layer_ping_pong_kernel(cin, cout, Hin, Win, B, up_variant):
     """csrc/up_pp.hip (dge_pack_up_pp + dge_up_pp: the up layer as a ping-pong implicit GEMM with the FIR in registers; opt-in with
     DGE_UP_PP=1) by name at the generator's four MFMA-bound up layers and on ragged shapes, against the same oracle and
     bounds as the kernels it stands in for (_up_layer_case): ModulateConvBlock.forward, scale_factor 2 (:879-896, :908-921)."""
@@ -222,7 +240,7 @@ def test_up_layer_ping_pong_kernel(cin, cout, Hin, Win, B):
     assert ops.up_pp_supported(B, Hin, Win, cin, cout, ops.BF16)
     wimg = ops.pack_up_pp(ops.pack_upconv_weight(w, ops.BF16, wscale), cout, cin, in_scale=s, out_scale=d, gain=math.sqrt(2.0))
     y = ops.up_pp(x, wimg, cout, bias=bias, bias_scale=1.0, noise=noise, noise_w=ns, act=ops.ACT_LRELU, gain=math.sqrt(2.0))
-    assert _kernel() == "up_pp<bf16,16,32,32>"
+    assert _kernel() == ("up_pp<bf16,16,32,32>" if up_variant == "pp" else "up_s4<bf16,8,32,32>")
     wq = CR.bf16_round(w.cpu() * wscale)
     for b in SAMPLES(B):
         a = (_nchw(x, b), wq, s[b:b + 1].cpu(), d[b:b + 1].cpu(), noise.cpu(), 0.37, bias.cpu(), 1.0, 1.0)
@@ -846,3 +864,26 @@ def test_top_of_the_synthesis_backward_fullsize(C, R, B):
         want = torch.stack([ref_R[:, 0] - 0.37 * ref_R[:, 1], ref_R[:, 2]], 1)
         absum = torch.stack([(gzd * zt).abs().sum((0, 2, 3)), gzd.abs().sum((0, 2, 3))], 1)
         assert ((P[b].cpu().double() - want).abs() / absum).max().item() < 5e-5, b
+
+
+def test_generator_sends_its_up_layers_to_the_default_kernel():
+    """The dispatch itself (ModulateConvBlock.conv, stylegan2_generator.py:879-896 in the reference): a bf16 synthesis pass of the
+    1024^2 generator runs the Cin >= 128 up layers at >= 16^2 input (layers 5 / 7 / 9 / 11 / 13) on dge_up_pp's default kernel;
+    layer 15 stays on upconv_stream and the 4^2 / 8^2 layers on the folded form."""
+    import dge_amd
+    from dge_amd import ops
+    from tests.golden import recipe as R
+    from tests.helpers import s2_shapes
+    G = dge_amd.StyleGAN2Generator(1024, compute_dtype="bf16").cuda()
+    G.load_state_dict(R.fill_s2(s2_shapes(1024), seed=1))
+    G.eval()
+    wp = torch.randn(1, G.num_layers, 512, device=DEV)
+    log = []
+    ops.KERNEL_LOG = log
+    try:
+        with torch.no_grad():
+            G.synthesis(wp)
+    finally:
+        ops.KERNEL_LOG = None
+    ups = [n for n, _ in log if n.startswith("up_")]
+    assert ups == ["up_s4<bf16,8,32,32>"] * 5, log

@@ -9,7 +9,7 @@ from dge_amd import ops
 
 DEV = "cuda"
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
-shapes = [(2, 64, 64, 128, 64)] if quick else [(8, 32, 32, 512, 512), (8, 64, 64, 512, 256), (8, 128, 128, 256, 128), (8, 256, 256, 128, 64), (2, 70, 66, 128, 96)]
+shapes = [(2, 64, 64, 128, 64)] if quick else [(8, 16, 16, 512, 512), (8, 32, 32, 512, 512), (8, 64, 64, 512, 256), (8, 128, 128, 256, 128), (8, 256, 256, 128, 64), (2, 70, 66, 128, 96)]
 g = torch.Generator(device=DEV); g.manual_seed(1)
 for (B, H, W, cin, cout) in shapes:
     x = (torch.randn(B, H, W, cin, device=DEV, generator=g) * 0.7).to(torch.bfloat16)
