@@ -192,4 +192,43 @@ class BlurEncoderFunction(torch.autograd.Function):
         if g_w is None:
             g_w = torch.zeros((B, 2 * ctx.E.layer_count, ctx.E.latent_size), dtype=torch.float32, device=ctx.saved_acts["img"].device)
         grads, g_img = blur_encoder_backward(ctx.E, ctx.saved_acts, g_w.float().contiguous(), g_x, need_img=ctx.need_img)
+        if _DIRECT_ACCUMULATE:
+            accumulate_param_grads(ctx.E, grads)
+            return (None, g_img, None) + (None,) * len(grads)
         return (None, g_img, None) + tuple(grads)
+
+
+import os as _os
+_DIRECT_ACCUMULATE = _os.environ.get("DGE_AUTOGRAD_ACCUMULATE") != "1"
+
+
+def accumulate_param_grads(E, grads):
+    """Adds the parameter gradients of ONE encoder call to `.grad` from inside the backward instead of handing them to autograd.
+    The inversion loop (embedding_img.py:86-88) calls the encoder twice per iteration, so autograd's AccumulateGrad node clones every
+    gradient of the first call (they are views of the step's zero-filled arena) and adds every gradient of the second: 2 x 105 launches
+    of ~4 us per backward at batch 1, where the loop is paced by launches (profiles/r05_embed_kernel_stats.txt).  Here: one
+    multi-tensor copy into a persistent flat buffer for the parameters without a gradient, one multi-tensor add for those with one.
+    Same sums in the same order (first call, then second)."""
+    import torch
+    params = list(E.parameters())
+    lay = E.__dict__.get("_grad_flat")
+    total = sum(p.numel() for p in params)
+    if lay is None or lay["total"] != total or lay["buf"].device != params[0].device:
+        buf = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        views, o = [], 0
+        for p in params:
+            views.append(buf[o:o + p.numel()].view_as(p)); o += p.numel()
+        lay = E.__dict__["_grad_flat"] = dict(total=total, buf=buf, views=views)
+    first_dst, first_src, add_dst, add_src = [], [], [], []
+    for p, v, g in zip(params, lay["views"], grads):
+        if g is None:
+            continue
+        if p.grad is None:
+            first_dst.append(v); first_src.append(g.reshape(p.shape))
+            p.grad = v
+        else:
+            add_dst.append(p.grad); add_src.append(g.reshape(p.shape))
+    if first_dst:
+        torch._foreach_copy_(first_dst, first_src)
+    if add_dst:
+        torch._foreach_add_(add_dst, add_src)

@@ -573,14 +573,6 @@ __global__ __launch_bounds__(256, 2) void up_s4_kernel(UPParams p_) {
     const int nt = id % p_.ntn; id /= p_.ntn;
     const int x0 = (id % p_.tiles_x) * 30 - 1; id /= p_.tiles_x;         // first input column / row of the tile (-1: the zero border)
     const int y0 = (id % p_.tiles_y) * 6 - 1, b = id / p_.tiles_y;
-    // stagger (experiment, p_.dbg = mode | sleeps << 4): the two workgroups of a CU start together and, with identical tiles, stay in
-    // step - K loops side by side, then FIRs side by side.  Delay one of the first generation's two by about half a tile.
-    if (p_.dbg) {
-        const int mode = p_.dbg & 15, n = p_.dbg >> 4, slot = blockIdx.x >> 3;
-        const bool late = mode == 1 ? (slot >= 32 && slot < 64) : mode == 2 ? (slot < 64 && (slot & 1)) : mode == 3 ? (blockIdx.x < 512 && (blockIdx.x & 1)) : false;
-        if (late) for (int i = 0; i < n; i++) __builtin_amdgcn_s_sleep(127);
-    }
-
     // fragment addresses: halo pixel (hr, hc) -> hp = hr * 33 + hc, byte (hp >> 4) KiB + (hp & 15) * 16 + part * 256
     unsigned xat[3][2];
 #pragma unroll
@@ -941,15 +933,6 @@ extern "C" int dge_up_pp(const void* x, const void* w_img, long long w_bstride, 
         const long tiles4 = (long)p.tiles_x * p.tiles_y * B * p.ntn;
         const long per_xcd = (tiles4 + 7) / 8;
         dge_note_kernel("up_s4<bf16,8,32,32>");
-        if (p.dbg) {
-            static bool once = false;
-            if (!once) {
-                once = true;
-                int nb = -1;
-                hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, up_s4_kernel, 256, 0);
-                fprintf(stderr, "up_s4: occupancy query -> %d blocks per CU (err %d)\n", nb, (int)e);
-            }
-        }
         hipLaunchKernelGGL(up_s4_kernel, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, s, p);
         DGE_LAUNCH_CHECK("up_s4");
         return 0;
