@@ -335,7 +335,7 @@ def main():
         out["roofline"] = {"bound": "mixed", "bound_split": {"mfma_bound_launches_per_step": (nlaunch - n_hbm) // 2, "hbm_bound_launches_per_step": n_hbm // 2},
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": tsrc, "traffic_is_offline_constant": traffic is not None,
-                           "kernel": "conv_igemm_kernel<*> + conv_pp_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + upconv_fir_kernel + upconv_stream_kernel (all conv launches of a step: dge_conv2d, dge_conv_pp, dge_upconv_fir)",
+                           "kernel": "conv_igemm_kernel<*> + conv_pp_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + up_s4_kernel + upconv_stream_kernel (all conv launches of a step: dge_conv2d, dge_conv_pp, dge_up_pp, dge_upconv_fir)",
                            "launches_per_step": nlaunch // 2, "avg_launch_us": ms / max(nlaunch, 1) * 1e3,
                            "timing": "HIP events around every conv launch of two extra steps run on ONE stream (the timed steps above overlap the three loss windows and the weight re-pack on side streams)",
                            "algorithmic_gflop_per_launch": fl / max(nlaunch, 1) / 1e9,

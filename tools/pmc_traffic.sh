@@ -6,7 +6,7 @@
 # only, no other trace domains.  FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md "HBM");
 # WRITE_SIZE is taken as reported (calibration: conv_stream 32->32 @1024^2 writes 537 MB by construction and the counter's
 # TCC_EA0_WRREQ x 64 B gives 537 MB, profiles/r02_conv_stream_pmc_32x32_1024.txt).
-TAG=${1:-r04}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 # one stream: counter collection serialises kernels (a step with its side streams did not finish under --pmc), and the stage
 # tables want every launch at its isolated duration
@@ -23,7 +23,7 @@ mkdir -p $R/gpurun_out
 python - "$R" "$TAG" <<'PY'
 import csv, glob, json, sys, collections
 R, TAG = sys.argv[1], sys.argv[2]
-FAMILY = ("conv_igemm_kernel", "conv_pp_kernel", "conv_stream_kernel", "conv_small_kernel", "conv_pw_kernel", "upconv_fir_kernel", "upconv_stream_kernel")
+FAMILY = ("conv_igemm_kernel", "conv_pp_kernel", "conv_stream_kernel", "conv_small_kernel", "conv_pw_kernel", "upconv_fir_kernel", "upconv_stream_kernel", "up_s4_kernel", "up_pp_kernel")
 tot = {}
 per = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -41,7 +41,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 nl = tot["FETCH_SIZE"][0]
 fetch = 2.0 * tot["FETCH_SIZE"][1] * 1024 / nl        # KB -> bytes, x2 gfx950 correction
 write = tot["WRITE_SIZE"][1] * 1024 / tot["WRITE_SIZE"][0]
-out = {"kernel": "conv_igemm_kernel<*> + conv_pp_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + upconv_fir_kernel + upconv_stream_kernel", "launches_profiled": nl, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+out = {"kernel": "conv_igemm_kernel<*> + conv_pp_kernel<*> + conv_stream_kernel<*> + conv_small_kernel<*> + conv_pw_kernel<*> + up_s4_kernel + upconv_stream_kernel", "launches_profiled": nl, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
        "traffic_bytes_per_launch": fetch + write, "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as reported",
        "command": "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-synthesis"}
 json.dump(out, open(f"{R}/gpurun_out/{TAG}_conv_traffic.json", "w"), indent=1)
