@@ -8,31 +8,8 @@ reference's behaviour.
 """
 import torch
 
-import os
-
 from . import ops
-from .autograd_enc import _packed, _ver, heads_layout
-
-_PP_ENC = os.environ.get("DGE_NO_PP_ENC") is None
-
-
-def _dgrad_stats(cache, conv, g, Cc, dt, H, stats, dot_src):
-    """Data gradient of a 3x3 encoder conv with the instance-norm backward's two sums (sum a * dot_src, sum a) from its epilogue
-    (model/E/E.py:55-75 differentiated).  The MFMA-bound launches - >= 128 channels on a grid of >= 192 tiles of 16 x 32 pixels: block 3
-    of E.BE(16, L=9) at batch 8, 128 / 256 -> 128 channels at 128^2 - run on the ping-pong kernel's data-gradient form (csrc/conv_pp.hip,
-    shared weight image re-folded from the live parameter: quirk Q3), 68 -> 42 us per launch at batch 8; everything else on dge_conv2d."""
-    B, Hh, Ww, K = g.shape
-    if _PP_ENC and dt == ops.BF16 and not ops.is_deterministic() and ops.conv_pp_supported(B, Hh, Ww, K, Cc, dt):
-        w = conv.weight
-        key, ver = (id(w), "pp_dgrad"), _ver(w)
-        hit = cache.get(key)
-        if hit is None:
-            hit = cache[key] = [ver, ops.pack_conv_pp(w, 1.0, dgrad=True), w]
-        elif hit[0] != ver:
-            ops.pack_conv_pp(w, 1.0, dgrad=True, out=hit[1])        # in place: the consumers of the old image are earlier on the stream
-            hit[0] = ver
-        return ops.conv_pp(g, hit[1], Cc, dgrad=True, stats=stats, dot_src=dot_src)
-    return ops.conv2d(g, _packed(cache, conv, dt, ops.PACK_DGRAD, H), Cc, 3, stats=stats, dot_src=dot_src)
+from .autograd_enc import _packed, heads_layout
 
 
 def _linear_backward(lin, g_w, musig, grads, name):
@@ -129,7 +106,7 @@ def encoder_backward(E, saved, g_w):
                 ops.conv_wgrad(g_pre2, x1, gW2, rec["sc2"], rec["sh2"])
             grads[pre + "conv_2.weight"] = gW2
             if not fuse2:
-                g_y2 = _dgrad_stats(cache, blk.conv_2, g_pre2, Cc, dt, H, dots2, x1)
+                g_y2 = ops.conv2d(g_pre2, _packed(cache, blk.conv_2, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots2, dot_src=x1)
             if has3:
                 post.append(lambda n=pre + "conv_3.bias", t=red2[2]: grads.__setitem__(n, t * 0.889))
                 gW3 = ops.zeros(tuple(blk.conv_3.weight.shape), dev)
@@ -179,7 +156,7 @@ def encoder_backward(E, saved, g_w):
             g_out = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, dot_src=x,
                                in_bwd=dict(coef=ops.in_bwd_coef(*coef1), extra=extra, extra_scale=extra_scale))
         else:
-            g_y1 = _dgrad_stats(cache, blk.conv_1, g_pre1, Cc, dt, H, dots1, x)
+            g_y1 = ops.conv2d(g_pre1, _packed(cache, blk.conv_1, dt, ops.PACK_DGRAD, H), Cc, 3, stats=dots1, dot_src=x)
         if fuse_fr or fuse_x:
             pass
         elif j == 0 and Cc <= 512:

@@ -91,11 +91,10 @@ BG_KERNELS = [IG + "16,16,128,32,1,2,2>", IG + "16,16,128,32,3,2,2>+tr", IG + "1
 BE256_KERNELS = {
     8: [IG + "16,16,128,32,1,2,2>", IG + "16,16,128,32,3,2,2>", IG + "16,16,128,32,3,2,2>+tr", IG + "16,16,64,32,1,4,1>", IG + "16,16,64,32,3,4,1>",
         IG + "16,16,64,32,3,4,1>+tr", IG + "8,8,64,128,1,2,2>", "conv_small<bf16,8,8,64,512>", "conv_stream<bf16,64,64,dot>", "conv_wgrad_tr<1,16>",
-        "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,64,64,2>",
-        "conv_pp<bf16,16,32,128>+dg"],          # round 6: the 128-channel data gradients at 64^2 x 8 samples (autograd_enc_bwd._dgrad_stats)
+        "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,64,64,2>"],
     32: [IG + "16,16,128,32,1,2,2>", IG + "16,16,128,32,3,2,2>", IG + "16,16,128,32,3,2,2>+tr", IG + "16,16,64,32,1,4,1>", IG + "16,16,64,32,3,4,1>",
          IG + "16,16,64,32,3,4,1>+tr", "conv_pw<bf16,64,128>", "conv_small<bf16,8,8,64,512>", "conv_stream<bf16,64,64,dot>", "conv_wgrad_tr<1,16>",
-         "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,64,64,2>", "conv_pp<bf16,16,32,128>+dg"],
+         "conv_wgrad_tr<3,16>", "conv_wgrad_tr<3,8>", "wgrad_dma<16,64,64,2>"],
 }
 BLUR1024_KERNELS = [IG + "16,16,32,32,1,4,1>", IG + "16,16,32,32,3,4,1>", IG + "16,16,64,32,1,4,1>", IG + "16,16,64,32,3,4,1>", IG + "16,16,64,32,3,4,1>+tr",
                     IG + "8,8,64,128,1,2,2>", IG + "8,8,64,128,3,2,2>", IG + "8,8,64,64,1,2,2>", "conv_pw<bf16,16,32>", "conv_pw<bf16,32,32>",
