@@ -74,7 +74,7 @@ def test_two_phase_step_matches_reference_run(mode):
                             assert ((du - du_ref).abs().max() / du_ref.abs().max()).item() < 0.05, (it, k)
                         else:       # (atomics: an element whose gradient sits inside the reduction-order spread may step the other way - judged in norm)
                             assert ((du - du_ref).norm() / du_ref.norm()).item() < 0.05, (it, k)
-        assert abs(R.checksum({k: v.cpu() for k, v in sd.items()}) - float(g[f"it{it}_param_checksum"])) < 1e-5 * float(g[f"it{it}_param_checksum"])
+        assert abs(R.checksum({k: v.cpu() for k, v in sd.items()}) - float(g[f"it{it}_param_checksum"])) < (1e-5 if mode == "det" else 1e-4) * float(g[f"it{it}_param_checksum"])
         assert relerr(G.truncation.w_avg, g[f"it{it}_w_avg"]) < 1e-5
 
 
