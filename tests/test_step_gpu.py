@@ -117,10 +117,7 @@ def test_stage1_step_matches_reference_run():
                     du_ref = torch.as_tensor(g[key]) - before
                     du = sd[k].cpu() - before
                     if du_ref.abs().max() > 0:
-                        if mode == "det":
-                            assert ((du - du_ref).abs().max() / du_ref.abs().max()).item() < 0.05, (it, k)
-                        else:       # (atomics: an element whose gradient sits inside the reduction-order spread may step the other way - judged in norm)
-                            assert ((du - du_ref).norm() / du_ref.norm()).item() < 0.05, (it, k)
+                        assert ((du - du_ref).abs().max() / du_ref.abs().max()).item() < 0.05, (it, k)
         assert abs(R.checksum({k: v.cpu() for k, v in sd.items()}) - float(g[f"it{it}_param_checksum"])) < 1e-5 * float(g[f"it{it}_param_checksum"])
     with pytest.raises(ValueError):
         EAlignStep(G, E, LP, stage=3)
