@@ -1,6 +1,8 @@
 // up_pp: the StyleGAN2 up layer (conv_transpose2d stride 2 + 4x4 FIR, model/stylegan2_generator.py:879-896, :603-615; demodulation,
-// noise, bias, lrelu * sqrt 2 :908-921) for the MFMA-bound layers (Cin >= 128: layers 7 / 9 / 11 / 13 of the 1024^2 generator) as a
-// ping-pong implicit GEMM on the skeleton of conv_pp.hip, with the FIR taken in registers the way upconv_stream.hip takes it.
+// noise, bias, lrelu * sqrt 2 :908-921) for the layers with Cin >= 128 (layers 5 / 7 / 9 / 11 / 13 of the 1024^2 generator) as an implicit
+// GEMM with the FIR taken in registers the way upconv_stream.hip takes it.  Two kernels behind one entry point (dge_up_pp):
+// up_pp_kernel below - eight waves, ping-pong on the skeleton of conv_pp.hip, persistent - and up_s4_kernel further down - four waves,
+// half the LDS, two workgroups per CU, one tile each: the generator's default since round 6 (DESIGN 6d has the measurements).
 //
 // Math: the transposed-conv result t ((2H+1)^2) in phase form, t[2m+py][2n+px] for input position (m, n):
 //   ee = x[m][n] W(2,2) + x[m-1][n] W(0,2) + x[m][n-1] W(2,0) + x[m-1][n-1] W(0,0)      eo = x[m][n] W(2,1) + x[m-1][n] W(0,1)
@@ -17,9 +19,9 @@
 //     activation fragments are shared by the phases, and the nine units of a 32-channel K chunk are three clusters:
 //     A = tap (m, n) -> ee eo oe oo (16 MFMAs, 12 fragment reads), B = taps (m-1, n) -> ee eo and (m-1, n-1) -> ee (12 / 14),
 //     C = tap (m, n-1) -> ee oe (8 / 8): 36 MFMAs per wave and chunk, none of them on zero blocks.
-//   * workgroup tile = 16 input rows x 32 columns x 32 channels; everything arrives by LDS-DMA: the halo tile (17 x 33 pixels x
-//     64 B, 36 one-KiB pieces, part-major: conflict-free ds_read_b128) of chunk c + 1 during cluster A of chunk c (two buffers), the
-//     18 KiB weight block of chunk c + 2 during cluster B (three slots), arrival counted with s_waitcnt vmcnt(N).
+//   * workgroup tile = 16 input rows x 32 columns x 32 channels; everything arrives by LDS-DMA: the 18 KiB weight block of chunk c + 1
+//     during cluster A of chunk c (two slots), the halo tile (17 x 33 pixels x 64 B, 36 one-KiB pieces, part-major: conflict-free
+//     ds_read_b128) of chunk c + 2 during cluster B (three buffers: round 6), arrival counted with s_waitcnt vmcnt(N).
 //   * epilogue in registers: a lane (column n, K half) ends with both column phases of 16 channels -> bf16x2 words (t is rounded to
 //     bf16 exactly where upconv_fir / upconv_stream round it), neighbour columns by DPP wave shifts, horizontal FIR as
 //     v_dot2_f32_bf16, the three boundary t rows a wave needs from its neighbours go through LDS once (96 KiB, the drained
