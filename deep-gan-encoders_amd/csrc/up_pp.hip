@@ -564,6 +564,18 @@ __global__ __launch_bounds__(256, 2) void up_s4_kernel(UPParams p_) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = rfl(tid >> 6);
     const int nchunks = p_.nchunks;
+#ifdef DGE_UP_TIMING
+    int pidx = 0;
+    auto stamp = [&](int tag) {      // tuning build: workgroups 0 and 8 (XCD 0, tiles 0 and 1), wave 0 (tools/perf_s4_timing.py)
+        const int g = blockIdx.x == 0 ? 0 : 1;
+        if ((blockIdx.x == 0 || blockIdx.x == 8) && wave == 0 && lane == 0 && pidx < 1022) {
+            g_up_prof[g][pidx++] = ((long long)tag << 48) | (long long)(__builtin_readcyclecounter() & 0xffffffffffffll);
+            g_up_prof[g][1023] = pidx;
+        }
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
 
     // XCD-aware: workgroup i lives on XCD i % 8 and takes tile (i >> 3) of that XCD's contiguous range (channel tiles innermost:
     // the workgroups that share a halo tile are neighbours on one L2)
@@ -647,7 +659,11 @@ __global__ __launch_bounds__(256, 2) void up_s4_kernel(UPParams p_) {
     unsigned hb = Q_H0_OFF, wb_ = Q_W0_OFF;          // buffers READ by this chunk
     for (int kc = 0; kc < nchunks; kc++) {
         // chunk kc has landed (this wave's pieces; the barrier makes it everybody's) and everybody is done reading chunk kc - 1
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        stamp(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(2);
+        asm volatile("s_barrier" ::: "memory");
+        stamp(3);
         // requests of chunk kc + 1 go into the buffers chunk kc - 1 read; behind the last chunk through an EMPTY descriptor
         rsrc_t rsn = rs, rwn = rw;
         if (kc + 1 >= nchunks) { rsn[2] = 0u; rwn[2] = 0u; }
@@ -667,6 +683,7 @@ __global__ __launch_bounds__(256, 2) void up_s4_kernel(UPParams p_) {
                 for (int ks = 0; ks < 2; ks++) wa[u][ks] = *(const uint4*)(lds + wrd + u * 2048 + ks * 512);
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(4);
             __builtin_amdgcn_sched_barrier(0);
             StaticFor<16>::run([&](auto mc) {
                 constexpr int m = decltype(mc)::value, ks = m >> 3, i = (m >> 2) & 1, u = m & 3;
@@ -695,7 +712,9 @@ __global__ __launch_bounds__(256, 2) void up_s4_kernel(UPParams p_) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) wbf[u][ks] = *(const uint4*)(lds + wrd + (4 + u) * 2048 + ks * 512);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(5);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(6);
             __builtin_amdgcn_sched_barrier(0);
             StaticFor<12>::run([&](auto mc) {
                 constexpr int m = decltype(mc)::value, ks = m / 6, r6 = m % 6, i = r6 / 3, u = r6 % 3;      // u 0: ee <- (m-1, n); 1: eo <- (m-1, n); 2: ee <- (m-1, n-1)
@@ -723,7 +742,9 @@ __global__ __launch_bounds__(256, 2) void up_s4_kernel(UPParams p_) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ks++) wc[u][ks] = *(const uint4*)(lds + wrd + (7 + u) * 2048 + ks * 512);
             __builtin_amdgcn_sched_barrier(0);
+            stamp(7);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stamp(8);
             __builtin_amdgcn_sched_barrier(0);
             StaticFor<8>::run([&](auto mc) {
                 constexpr int m = decltype(mc)::value, ks = m >> 2, i = (m >> 1) & 1, u = m & 1;            // u 0: ee, 1: oe
