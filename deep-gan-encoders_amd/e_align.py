@@ -383,6 +383,11 @@ class EAlignStep:
         return None if pref is None else pref[0]
 
     def _prefetch_ok(self):
+        # (data parallel: the prefetched pass's only collective is the w_avg mean - 512 floats behind the mapping network, the first
+        #  ~0.1 ms of the pass - issued from the side stream in the same program order on every rank.  ProcessGroupNCCL runs a group's
+        #  collectives in call order on its own stream, so this one sits in front of the iteration's loss sums and gradient buckets and is
+        #  long done when they are issued, several ms later: no exposed serialisation is expected.  Measured only with a one-rank RCCL
+        #  group and two gloo ranks (tests/test_ddp_gpu.py); `--no-prefetch` / prefetch_next=False is the serial form.)
         from . import ops
         return (_SIDE_STREAMS and self.stage == 2 and self.dev.type == "cuda" and not isinstance(self.gen, _BigGANAdapter) and not self.reference_noise
                 and not ops.is_deterministic() and not torch.cuda.is_current_stream_capturing())
